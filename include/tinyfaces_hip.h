@@ -1,0 +1,240 @@
+/* tinyfaces_hip.h -- C ABI of libtinyfaces_hip.so (gfx950 / MI355X).
+ *
+ * The reference (varunagrawal/tiny-faces-pytorch) has no FFI of its own: its hot path is
+ * Python calling torch / torchvision / numpy.  Each entry point below replaces the
+ * framework call(s) cited next to it (reference file:line, relative to /root/reference).
+ * The Python package tiny-faces-pytorch_amd/tinyfaces binds them with ctypes
+ * (tinyfaces/_hip.py) -- see INTEGRATION.md for the stub a maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers + sizes only; every pointer is a DEVICE pointer unless named host_*;
+ *   - the caller owns all memory; kernels never allocate or free; scratch is passed in
+ *     (`ws`, sized by the matching *_workspace_bytes());
+ *   - everything is enqueued on `stream` (a hipStream_t passed as void*), no host sync
+ *     unless stated; stateless and therefore thread-safe per stream;
+ *   - return 0 (TF_OK) or a negative TF_ERR_* code; no exceptions cross the boundary.
+ *   - activations of the network kernels are NHWC ("pixels x channels" matrices), dtype
+ *     TF_F32 or TF_BF16; maps handed to / from the reference call surface are NCHW float32.
+ */
+#ifndef TINYFACES_HIP_H
+#define TINYFACES_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TF_OK 0
+#define TF_ERR_ARG (-1)
+#define TF_ERR_LAUNCH (-2)
+#define TF_ERR_UNSUPPORTED (-3)
+#define TF_ERR_WORKSPACE (-4)
+
+#define TF_F32 0
+#define TF_BF16 1
+
+int tf_version(void);
+/* number of exported symbols a binding must resolve; names via tf_symbol_name(i) */
+int tf_symbol_count(void);
+const char* tf_symbol_name(int i);
+
+/* ---- dense_overlap + heat-map target assignment ------------------------------------
+ * Replaces compute_dense_overlap (tinyfaces/datasets/dense_overlap.py:4-75) fused with
+ * DataProcessor.get_padding / get_regression / get_heatmaps
+ * (tinyfaces/datasets/processor.py:114-277).  float64 arithmetic, IoU rounded to 14
+ * decimals exactly like the reference; the 63x63x25xG IoU tensor is never materialised.
+ *   boxes        [total][4] f64 (x1,y1,x2,y2), degenerate boxes already removed
+ *                (processor.py:228-232 is done by the host wrapper)
+ *   box_offsets  [B+1] i32   image b owns boxes [box_offsets[b], box_offsets[b+1])
+ *   templates    [nt][tstride] f64 (x1,y1,x2,y2,...)
+ *   paste_boxes  [B][4] i32 (x1,y1,x2,y2) or NULL (= whole image, no padding)
+ *   flips        [B] i32 or NULL: pad mask mirrored in x (tinyfaces/datasets/wider_face.py:165)
+ *   noise        f64 uniform[0,1) tie-break draws of processor.py:195, per image laid out
+ *                (y,x,t,g) at element offset noise_offsets[b]; NULL -> counter RNG(seed)
+ *   class_map    [B][nt][vsy][vsx] f32 in {-1,0,1};  reg_map [B][4nt][vsy][vsx] f32
+ */
+size_t tf_targets_workspace_bytes(int total_boxes);
+int tf_dense_overlap_targets(const double* boxes, const int32_t* box_offsets, int B,
+                             const double* templates, int nt, int tstride,
+                             int vsy, int vsx, int ofy, int ofx, int sty, int stx,
+                             const int32_t* paste_boxes, const int32_t* flips,
+                             const double* noise, const int64_t* noise_offsets, uint64_t seed,
+                             double pos_thresh, double neg_thresh,
+                             float* class_map, float* reg_map,
+                             void* ws, size_t ws_bytes, void* stream);
+/* test hook: the raw rounded IoU tensor [vsy][vsx][nt][G] f64 for ONE image */
+int tf_dense_overlap_iou(const double* boxes, int G, const double* templates, int nt, int tstride,
+                         int vsy, int vsx, int ofy, int ofx, int sty, int stx,
+                         double* iou_out, void* stream);
+
+/* ---- greedy NMS, float64 -----------------------------------------------------------
+ * Replaces torchvision.ops.nms as called at tinyfaces/evaluation.py:84 (float64 boxes and
+ * scores): stable descending sort, areas without +1, strict `>` on IoU.  keep_out holds the
+ * surviving INPUT indices in descending-score order; *num_keep (device int32) their count. */
+size_t tf_nms_workspace_bytes(int n);
+int tf_nms_f64(const double* boxes /*[n][4]*/, const double* scores /*[n]*/, int n, double iou_thresh,
+               int64_t* keep_out /*[n]*/, int32_t* num_keep, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- score map -> boxes: sigmoid + threshold + ORDERED compaction + refinement ------
+ * Replaces evaluation.py:61-78 + get_bboxes / regression_refinement
+ * (tinyfaces/models/utils.py:4-100).  score [5nt][H][W] f32 (one image, NCHW).
+ * Candidates are appended to dets[*count ...] as rows (x1,y1,x2,y2,score) f64 in the
+ * reference's order: C-order over (y, x, template).  valid_x[W] / valid_t[nt] (u8) express
+ * the template mask; the reference's defect D1 (utils.py:44 masks the W axis) is
+ * reproduced by the caller passing it through valid_x. */
+size_t tf_decode_workspace_bytes(int H, int W, int nt);
+int tf_decode_compact(const float* score, int nt, int H, int W,
+                      const double* templates, int tstride,
+                      const uint8_t* valid_x, const uint8_t* valid_t,
+                      float prob_thresh, double scale, int sty, int stx, int ofy, int ofx,
+                      double* dets /*[cap][5]*/, int32_t* count /*device, in/out*/, int cap,
+                      void* ws, size_t ws_bytes, void* stream);
+
+/* ---- detection criterion: OHEM + balance sampling + masked SoftMargin / SmoothL1 ----
+ * Replaces DetectionCriterion.forward and its autograd backward
+ * (tinyfaces/models/loss.py:59-93, tinyfaces/models/utils.py:103-163) with no host
+ * round trip.  output [B][5nt][H][W] f32; class_map [B][nt][H][W] f32 is mined IN PLACE
+ * (loss.py:62); label_out receives the labels after balance sampling; grad_out =
+ * d(total)/d(output); loss_out[0] = sum cls, loss_out[1] = sum reg (unweighted).
+ * pos_keep/neg_keep: optional u8 [B][nt*H*W] keep flags indexed by the C-order RANK of the
+ * positive / negative label inside its image (injects the reference's np.random
+ * permutation); NULL -> uniformly random subset from the counter RNG(seed). */
+size_t tf_criterion_workspace_bytes(int B, int nt, int H, int W);
+int tf_criterion_fwd_bwd(const float* output, float* class_map, const float* reg_map,
+                         int B, int nt, int H, int W, float ohem_thresh, int max_pos, int max_neg,
+                         float reg_weight, const uint8_t* pos_keep, const uint8_t* neg_keep, uint64_t seed,
+                         float* label_out, float* grad_out, double* loss_out /*[2]*/,
+                         int32_t* counts_out /*[B][2] or NULL*/, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- fused SGD step (momentum, weight decay) over a flat fp32 segment ---------------
+ * Replaces torch.optim.SGD.step as configured at main.py:67-70 for one parameter group. */
+int tf_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n,
+                float lr, float momentum, float weight_decay, float grad_scale, void* stream);
+
+/* ---- convolution as MFMA implicit GEMM (NHWC) --------------------------------------
+ * Replaces every nn.Conv2d on the path (tinyfaces/models/model.py:25-32,90-106 and the
+ * torchvision Bottleneck convs) plus the BN / ReLU / residual passes fused around them.
+ *   x  [N][H][W][Cin]  (dtype), w packed [CoutPad][KH*KW][Cin] K-contiguous (tf_pack_weight),
+ *   y  [M][ldy] with M = N*OH*OW, ldy >= Cout, multiple of 4.
+ * mode 0: y[p,co] = sum x[gather(p,tap),ci] w[co,tap,ci]            (forward conv)
+ * mode 1: transposed gather: "x" is dY [N][H][W][Cin'=Cout_fwd] of a conv with (stride,pad)
+ *         and y is dX [N][OH][OW][Cout'=Cin_fwd]  (data gradient)
+ * prologue (per input channel, fwd only): x <- relu?(x*pro_scale + pro_shift), padding stays 0
+ * epilogue flags (TF_EPI_*):
+ *   AFFINE  v = v*epi_scale[c] + epi_shift[c]     RES   v += aux[p,c]      RELU  v = max(v,0)
+ *   STATS   stat_out[mtile][0][c] += v, [1][c] += v*v  (raw accumulator, before AFFINE)
+ *   MASK    v = (aux[p,c]*mask_scale[c]+mask_shift[c] > 0) ? v : 0        (dgrad through ReLU(BN(aux)))
+ *   STATS2  stat_out[mtile][0][c] = sum v, [1][c] = sum v*aux[p,c]        (after MASK)
+ *   JOIN    v += (aux2[p,c] > 0) ? aux3[p,c] : 0                          (residual-join gradient)
+ */
+#define TF_EPI_AFFINE 1
+#define TF_EPI_RES 2
+#define TF_EPI_RELU 4
+#define TF_EPI_STATS 8
+#define TF_EPI_MASK 16
+#define TF_EPI_STATS2 32
+#define TF_EPI_JOIN 64
+
+typedef struct tf_conv_args {
+  int dtype, mode;
+  int N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad;
+  int ldy;            /* row stride (elements) of y, aux, aux2, aux3 */
+  int epi;
+  int pro_relu;
+  const void* x; const void* w; void* y;
+  const float* pro_scale; const float* pro_shift;
+  const float* epi_scale; const float* epi_shift;
+  const void* aux; const void* aux2; const void* aux3;
+  const float* mask_scale; const float* mask_shift;
+  float* stat_out;    /* [mtiles][2][ldy] fp32 partial sums, mtiles = tf_conv_mtiles() */
+  int tile;           /* 0 = auto; else 1:(128x128) 2:(128x64) 3:(64x64) pixels x channels */
+} tf_conv_args;
+
+int tf_conv_mtiles(const tf_conv_args* a);
+int tf_conv2d(const tf_conv_args* a, void* stream);
+
+/* OIHW fp32 -> packed [CoutPad][KH*KW][CinPad] (dtype); transpose=1 packs the data-gradient
+ * operand [CinPad'][KH*KW][Cout] (roles swapped).  Pads are zero-filled. */
+int tf_pack_weight(const float* w_oihw, int Cout, int Cin, int KH, int KW, int transpose,
+                   int dtype, void* out, int rows_pad, int cols_pad, void* stream);
+
+/* weight gradient: dW[co][ci][kh][kw] (+)= sum_p dY[p,co] * xhat[gather(p,tap),ci] (fp32 atomics
+ * into dw_oihw, which the caller zeroes).  Same prologue semantics as tf_conv2d. */
+typedef struct tf_wgrad_args {
+  int dtype;
+  int N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad;
+  int ldx, lddy;      /* row strides of x and dy */
+  int pro_relu;
+  const void* x; const void* dy; float* dw_oihw;
+  const float* pro_scale; const float* pro_shift;
+  int dw_ld;          /* elements between consecutive co rows of dw (= Cin*KH*KW normally) */
+  int splitk;         /* 0 = auto */
+} tf_wgrad_args;
+int tf_conv2d_wgrad(const tf_wgrad_args* a, void* stream);
+
+
+/* ---- HBM-bound companions of the conv engine (NHWC, dtype TF_F32 | TF_BF16) ---------- */
+/* conv1 (7x7 s2 p3, 3->64; model.py:90): x NCHW fp32 -> im2col [N*OH*OW][ldc], k = c*49+kh*7+kw
+ * (the OIHW order of conv1.weight), zero padded to ldc (>= 147, multiple of 8). */
+int tf_stem_im2col(const float* x_nchw, int N, int H, int W, int dtype, void* col, int ldc, void* stream);
+/* nn.MaxPool2d(3,2,1) (model.py:93) with the stem's BN+ReLU fused in front when scale/shift are
+ * given (training: the un-normalised conv output is read once).  argmax (u8, optional) feeds _bwd. */
+int tf_maxpool_fwd(int dtype, const void* x, int N, int H, int W, int C, const float* scale, const float* shift,
+                   void* y, uint8_t* argmax, void* stream);
+int tf_maxpool_bwd(int dtype, const void* g, const uint8_t* argmax, const void* x, const float* scale, const float* shift,
+                   int N, int H, int W, int C, void* gz, void* stream);
+/* per-channel sums over the rows of an [M][ld] matrix, block partials [nblk][nk][C]:
+ * k0 = sum g', k1 = sum g'*a, k2 = sum g'*b, g' = g*(y>0) when y != NULL.  nblk = tf_colstats_blocks(). */
+int tf_colstats_blocks(int M, int C, int dtype);
+int tf_colstats(int dtype, const void* g, const void* y, const void* a, const void* b, int M, int C, int ld,
+                float* partial, void* stream);
+/* nn.BatchNorm2d in training mode (torchvision Bottleneck / model.py:91): partial (sum, sumsq)
+ * -> y = x*scale + shift, saved mean / invstd, running statistics (momentum, unbiased var). */
+int tf_bn_finalize(const float* partial, int nblk, int ld, int C, float count, const float* gamma, const float* beta,
+                   float eps, float momentum, float* scale, float* shift, float* mean, float* invstd,
+                   float* running_mean, float* running_var, void* stream);
+/* eval-mode BN as a per-channel affine (folded into the conv epilogue) */
+int tf_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
+               int C, float* scale, float* shift, void* stream);
+/* BN backward: partial sums (k0 = sum gz, kidx = sum gz*x) -> dgamma, dbeta and g_x = A*gz + B*x + D */
+int tf_bn_bwd_finalize(const float* partial, int nblk, int nk, int kidx, int ld, int C, float count, const float* gamma,
+                       const float* mean, const float* invstd, float* dgamma, float* dbeta, float* cA, float* cB,
+                       float* cD, void* stream);
+int tf_bn_bwd_apply(int dtype, const void* g, const void* y, const void* x, const float* cA, const float* cB,
+                    const float* cD, int64_t M, int C, void* out, void* stream);
+/* Bottleneck output in training mode: y = relu(x*s1+h1 + (r*s2+h2 | r)) */
+int tf_bn_add_relu(int dtype, const void* x, const float* s1, const float* h1, const void* r, const float* s2,
+                   const float* h2, int64_t M, int C, void* y, void* stream);
+/* score4_upsample (frozen bilinear ConvTranspose2d k4 s2 p1, model.py:34-40,107) + crop (:110-124)
+ * + add (:126); wup_diag [C][4][4] = the channel diagonal of the (C,C,4,4) weight; output NCHW fp32. */
+int tf_upsample_add_crop(int dtype, const void* s3, const void* s4, const float* wup_diag, int B, int C, int ldc,
+                         int H3, int W3, int H4, int W4, float* out_nchw, void* stream);
+int tf_upsample_add_crop_bwd(int dtype, const float* g_nchw, const float* wup_diag, int B, int C, int ldc,
+                             int H3, int W3, int H4, int W4, void* g3, void* g4, void* stream);
+int tf_reduce_partials(const float* partial, int nblk, int nk, int k, int ld, int C, float* out, void* stream);
+
+/* ---- the detector network as one native graph executor -----------------------------
+ * Replaces DetectionModel.forward (tinyfaces/models/model.py:89-128) and its autograd
+ * backward (tinyfaces/trainer.py:78,86): ResNet-101 trunk minus layer4, heads, upsample+add.
+ * params / grads: tables of device pointers in tf_detnet_param_name(i) order (fp32, the
+ * layouts of the reference state_dict: OIHW conv weights, [C] BN vectors).
+ * ws: scratch of tf_detnet_workspace_bytes() bytes, carved deterministically per call; the
+ * activations a backward needs live there until tf_detnet_backward is called.            */
+int tf_detnet_num_params(void);
+const char* tf_detnet_param_name(int i);      /* state_dict key, e.g. "model.layer3.22.bn3.running_var" */
+int64_t tf_detnet_param_numel(int i, int num_out);
+size_t tf_detnet_workspace_bytes(int dtype, int N, int H, int W, int num_out, int training);
+int tf_detnet_out_shape(int H, int W, int* H3, int* W3);
+int tf_detnet_forward(int dtype, int training, const float* x_nchw, int N, int H, int W, int num_out,
+                      void* const* params, float bn_eps, float bn_momentum,
+                      float* out_nchw, void* ws, size_t ws_bytes, void* stream);
+int tf_detnet_backward(int dtype, const float* x_nchw, int N, int H, int W, int num_out,
+                       void* const* params, void* const* grads, const float* gout_nchw,
+                       void* ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TINYFACES_HIP_H */

@@ -1,0 +1,320 @@
+"""-m gpu: the MFMA implicit-GEMM conv engine, the pixel-reduction wgrad and the HBM-bound
+companions, through the C ABI, vs torch-CPU fp32 references of the same op.
+Tolerances: fp32 path 1e-4 relative to the tensor's max (exact-fp32 MFMA, different summation
+order); bf16 path compared with a reference fed the SAME bf16-rounded operands, so what is left
+is fp32 accumulation order + one bf16 rounding of the output (2^-8 relative)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_util import err, from_nhwc, q, report, to_nhwc
+
+pytestmark = pytest.mark.gpu
+
+DT = [torch.float32, torch.bfloat16]
+TOL = {torch.float32: 2e-5, torch.bfloat16: 6e-3}
+
+
+def _g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+CONV_CASES = [
+    # N, H, W, Cin, Cout, K, stride, pad
+    (2, 17, 19, 64, 64, 1, 1, 0),
+    (1, 33, 31, 128, 256, 1, 1, 0),
+    (2, 20, 21, 64, 64, 3, 1, 1),
+    (1, 21, 23, 128, 128, 3, 2, 1),
+    (2, 15, 18, 256, 512, 1, 2, 0),
+    (1, 9, 40, 512, 128, 1, 1, 0),        # Cout 125-style padding handled by ldy; here exact
+    (3, 63, 63, 256, 64, 1, 1, 0),
+]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+def test_conv_forward_plain(dtype, case, tile):
+    from tinyfaces import ops
+    N, H, W, Cin, Cout, K, s, p = case
+    g = _g(hash(case) % 1000)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5
+    ref = F.conv2d(q(x, dtype), q(w, dtype), stride=s, padding=p)
+    y = ops.conv2d_nhwc(to_nhwc(x, dtype), ops.pack_weight(w.cuda(), dtype), Cout, K, K, s, p, tile=tile)
+    d = err(from_nhwc(y)[:, :Cout], ref)
+    report(f"conv_fwd[{dtype},{case},t{tile}]", maxabs=d[0], rel=d[2])
+    assert d[2] < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_conv_forward_fused_eval_epilogue(dtype):
+    """AFFINE (folded BN) + residual + ReLU, Cout=125 padded to 128 (the head shape)."""
+    from tinyfaces import _hip, ops
+    g = _g(3)
+    N, H, W, Cin, Cout = 2, 13, 17, 512, 125
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5
+    sc, sh = torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g)
+    res = torch.randn(N, 128, H, W, generator=g)
+    ref = torch.relu(F.conv2d(q(x, dtype), q(w, dtype)) * sc[:Cout].view(1, -1, 1, 1) + sh[:Cout].view(1, -1, 1, 1) + q(res, dtype)[:, :Cout])
+    y = ops.conv2d_nhwc(to_nhwc(x, dtype), ops.pack_weight(w.cuda(), dtype), Cout, 1, 1, 1, 0, ldy=128,
+                        epi=_hip.EPI_AFFINE | _hip.EPI_RES | _hip.EPI_RELU, epi_scale=sc.cuda(), epi_shift=sh.cuda(), aux=to_nhwc(res, dtype))
+    d = err(from_nhwc(y)[:, :Cout], ref)
+    report(f"conv_epilogue_eval[{dtype}]", maxabs=d[0], rel=d[2])
+    assert d[2] < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("K,s", [(1, 1), (3, 1), (3, 2)])
+def test_conv_forward_prologue_and_stats(dtype, K, s):
+    """training form: input = relu(bn(raw)) applied while staging (padding stays 0), output raw + (sum, sumsq)."""
+    from tinyfaces import _hip, ops
+    g = _g(10 + K + s)
+    N, H, W, Cin, Cout = 2, 18, 22, 128, 256
+    p = K // 2
+    raw = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5
+    ps, ph = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
+    act = torch.relu(q(raw, dtype) * ps.view(1, -1, 1, 1) + ph.view(1, -1, 1, 1))
+    ref = F.conv2d(q(act, dtype), q(w, dtype), stride=s, padding=p)
+    y, st = ops.conv2d_nhwc(to_nhwc(raw, dtype), ops.pack_weight(w.cuda(), dtype), Cout, K, K, s, p, pro=(ps.cuda(), ph.cuda(), True),
+                            epi=_hip.EPI_STATS, want_stats=True)
+    d = err(from_nhwc(y), ref)
+    ssum = st.sum(0).cpu()
+    n = ref.numel() / Cout
+    d1 = err(ssum[0] / n, ref.mean(dim=(0, 2, 3)))
+    d2 = err(ssum[1] / n, (ref ** 2).mean(dim=(0, 2, 3)))
+    report(f"conv_pro_stats[{dtype},k{K}s{s}]", rel=d[2], mean_abs=d1[0], sq_rel=d2[2])
+    assert d[2] < TOL[dtype] and d1[0] < 2e-3 and d2[2] < 2e-3
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("K,s,H", [(1, 1, 14), (3, 1, 14), (3, 2, 14), (3, 2, 15), (1, 2, 15)])
+def test_conv_dgrad_mode(dtype, K, s, H):
+    """mode 1 == data gradient of conv(stride, pad): compared with torch autograd."""
+    from tinyfaces import ops
+    g = _g(20 + K + s + H)
+    N, W, Cin, Cout = 2, H + 3, 64, 128
+    p = K // 2
+    x = torch.randn(N, Cin, H, W, generator=g, requires_grad=True)
+    w = torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5
+    yref = F.conv2d(x, q(w, dtype), stride=s, padding=p)
+    gy = torch.randn(yref.shape, generator=g)
+    yref.backward(q(gy, dtype))
+    wt = ops.pack_weight(w.cuda(), dtype, transpose=True)
+    gx = ops.conv2d_nhwc(to_nhwc(gy, dtype), wt, Cin, K, K, s, p, mode=1, out_hw=(H, W))
+    d = err(from_nhwc(gx), x.grad)
+    report(f"conv_dgrad[{dtype},k{K}s{s}h{H}]", maxabs=d[0], rel=d[2])
+    assert d[2] < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_conv_dgrad_mask_stats2_and_join(dtype):
+    from tinyfaces import _hip, ops
+    g = _g(33)
+    N, H, W, C1, C2 = 2, 16, 18, 256, 64          # dgrad of a 1x1 conv C2 -> C1 : input grad has C2 channels
+    gy = torch.randn(N, C1, H, W, generator=g)
+    w = torch.randn(C1, C2, 1, 1, generator=g) / C2 ** 0.5
+    craw = torch.randn(N, C2, H, W, generator=g)
+    ms, mh = torch.rand(C2, generator=g) + 0.5, torch.randn(C2, generator=g) * 0.5
+    base = F.conv_transpose2d(q(gy, dtype), q(w, dtype))
+    mask = (q(craw, dtype) * ms.view(1, -1, 1, 1) + mh.view(1, -1, 1, 1)) > 0
+    ref = base * mask
+    y, st = ops.conv2d_nhwc(to_nhwc(gy, dtype), ops.pack_weight(w.cuda(), dtype, transpose=True), C2, 1, 1, 1, 0, mode=1, out_hw=(H, W),
+                            epi=_hip.EPI_MASK | _hip.EPI_STATS2, aux=to_nhwc(craw, dtype), mask=(ms.cuda(), mh.cuda()), want_stats=True)
+    d = err(from_nhwc(y), ref)
+    s = st.sum(0).cpu()
+    d1 = err(s[0], ref.sum(dim=(0, 2, 3)))
+    d2 = err(s[1], (ref * q(craw, dtype)).sum(dim=(0, 2, 3)))
+    # JOIN: out = acc + (y2 > 0 ? g3 : 0)
+    y2 = torch.randn(N, C2, H, W, generator=g)
+    g3 = torch.randn(N, C2, H, W, generator=g)
+    refj = base + q(g3, dtype) * (q(y2, dtype) > 0)
+    yj = ops.conv2d_nhwc(to_nhwc(gy, dtype), ops.pack_weight(w.cuda(), dtype, transpose=True), C2, 1, 1, 1, 0, mode=1, out_hw=(H, W),
+                         epi=_hip.EPI_JOIN, aux2=to_nhwc(y2, dtype), aux3=to_nhwc(g3, dtype))
+    dj = err(from_nhwc(yj), refj)
+    report(f"conv_dgrad_mask_join[{dtype}]", rel=d[2], s1=d1[2], s2=d2[2], join_rel=dj[2])
+    assert d[2] < TOL[dtype] and dj[2] < TOL[dtype] and d1[2] < 5e-3 and d2[2] < 5e-3
+
+
+WG_CASES = [
+    # N, H, W, Cin, Cout, K, stride
+    (2, 20, 22, 64, 64, 3, 1),
+    (2, 21, 19, 128, 128, 3, 2),
+    (3, 30, 30, 256, 1024, 1, 1),
+    (2, 31, 29, 512, 1024, 1, 2),
+    (2, 16, 16, 1024, 256, 1, 1),
+    (4, 40, 40, 64, 256, 1, 1),
+]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", WG_CASES)
+def test_wgrad(dtype, case):
+    from tinyfaces import ops
+    N, H, W, Cin, Cout, K, s = case
+    p = K // 2
+    g = _g(hash(case) % 997)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = (torch.randn(Cout, Cin, K, K, generator=g) * 0.05).requires_grad_(True)
+    y = F.conv2d(q(x, dtype), w, stride=s, padding=p)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(q(gy, dtype))
+    dw = ops.conv2d_wgrad(to_nhwc(x, dtype), to_nhwc(gy, dtype), Cin, Cout, K, K, s, p)
+    d = err(dw.cpu(), w.grad)
+    report(f"wgrad[{dtype},{case}]", maxabs=d[0], rel=d[2])
+    assert d[2] < (5e-5 if dtype == torch.float32 else 2e-3)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_wgrad_with_prologue_and_padded_head(dtype):
+    from tinyfaces import ops
+    g = _g(77)
+    N, H, W, Cin, Cout = 2, 12, 16, 128, 256
+    raw = torch.randn(N, Cin, H, W, generator=g)
+    ps, ph = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
+    act = q(torch.relu(q(raw, dtype) * ps.view(1, -1, 1, 1) + ph.view(1, -1, 1, 1)), dtype)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05).requires_grad_(True)
+    y = F.conv2d(act, w, padding=1)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(q(gy, dtype))
+    dw = ops.conv2d_wgrad(to_nhwc(raw, dtype), to_nhwc(gy, dtype), Cin, Cout, 3, 3, 1, 1, pro=(ps.cuda(), ph.cuda(), True))
+    d = err(dw.cpu(), w.grad)
+    # head: Cout = 125 stored with lddy = 128
+    x2 = torch.randn(N, 512, H, W, generator=g)
+    w2 = (torch.randn(125, 512, 1, 1, generator=g) * 0.05).requires_grad_(True)
+    y2 = F.conv2d(q(x2, dtype), w2)
+    gy2 = torch.randn(y2.shape, generator=g)
+    y2.backward(q(gy2, dtype))
+    gy2p = torch.cat([gy2, torch.zeros(N, 3, H, W)], 1)
+    dw2 = ops.conv2d_wgrad(to_nhwc(x2, dtype), to_nhwc(gy2p, dtype), 512, 125, 1, 1, 1, 0)
+    d2 = err(dw2.cpu(), w2.grad)
+    report(f"wgrad_pro_head[{dtype}]", rel=d[2], head_rel=d2[2])
+    tol = 5e-5 if dtype == torch.float32 else 3e-3
+    assert d[2] < tol and d2[2] < tol
+
+
+# ------------------------------------------------------------------ HBM-bound companions
+@pytest.mark.parametrize("dtype", DT)
+def test_stem_im2col_and_maxpool(dtype, hip):
+    from tinyfaces import ops
+    from tinyfaces._hip import lib, ptr, stream, tf_dtype
+    g = _g(5)
+    N, H, W = 2, 37, 45
+    x = torch.randn(N, 3, H, W, generator=g)
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    col = torch.empty(N * OH * OW, 192, dtype=dtype, device="cuda")
+    xd = x.cuda()
+    assert lib().tf_stem_im2col(ptr(xd), N, H, W, tf_dtype(dtype), ptr(col), 192, stream()) == 0
+    ref = F.unfold(q(x, dtype), 7, padding=3, stride=2).transpose(1, 2).reshape(-1, 147)      # k = c*49 + kh*7 + kw
+    d = err(col.float().cpu()[:, :147], ref)
+    assert d[0] == 0 and float(col.float().abs()[:, 147:].max()) == 0
+    # maxpool (+ fused BN/ReLU prologue, arg-max) and its backward
+    C = 64
+    a = torch.randn(N, C, OH, OW, generator=g)
+    sc, sh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    act = torch.relu(q(a, dtype) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).requires_grad_(True)
+    pref = F.max_pool2d(act, 3, 2, 1)
+    PH, PW = pref.shape[2:]
+    xin = to_nhwc(a, dtype)
+    y = torch.empty(N, PH, PW, C, dtype=dtype, device="cuda")
+    idx = torch.empty(N * PH * PW * C, dtype=torch.uint8, device="cuda")
+    scd, shd = sc.cuda(), sh.cuda()
+    assert lib().tf_maxpool_fwd(tf_dtype(dtype), ptr(xin), N, OH, OW, C, ptr(scd), ptr(shd), ptr(y), ptr(idx), stream()) == 0
+    d = err(from_nhwc(y), q(pref.detach(), dtype))
+    gp = torch.randn(pref.shape, generator=g)
+    pref.backward(q(gp, dtype))
+    gz = torch.empty_like(xin)
+    gpd = to_nhwc(gp, dtype)
+    assert lib().tf_maxpool_bwd(tf_dtype(dtype), ptr(gpd), ptr(idx), ptr(xin), ptr(scd), ptr(shd), N, OH, OW, C, ptr(gz), stream()) == 0
+    # reference: gradient w.r.t. the activation, then through the ReLU mask
+    gref = act.grad * (act.detach() > 0)
+    d2 = err(from_nhwc(gz), gref)
+    report(f"im2col_maxpool[{dtype}]", pool_maxabs=d[0], pool_bwd_rel=d2[2])
+    assert d[0] < (1e-6 if dtype == torch.float32 else 1e-2) and d2[2] < (1e-6 if dtype == torch.float32 else 8e-3)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_bn_train_forward_backward_chain(dtype):
+    """colstats -> bn_finalize -> bn_add_relu forward; colstats(masked) -> bn_bwd_finalize -> bn_bwd_apply backward,
+    vs torch BatchNorm2d(train) + add + relu autograd."""
+    from tinyfaces._hip import lib, ptr, stream, tf_dtype
+    g = _g(9)
+    N, H, W, C = 3, 11, 13, 256
+    M = N * H * W
+    tfd = tf_dtype(dtype)
+    xr = torch.randn(N, C, H, W, generator=g) * 1.3 + 0.2
+    idn = torch.randn(N, C, H, W, generator=g)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    xq = q(xr, dtype).requires_grad_(True)
+    gm = gamma.clone().requires_grad_(True); bt = beta.clone().requires_grad_(True)
+    rm, rv = torch.zeros(C), torch.ones(C)
+    yref = torch.relu(F.batch_norm(xq, rm, rv, gm, bt, True, 0.1, 1e-5) + q(idn, dtype))
+    gy = torch.randn(yref.shape, generator=g)
+    yref.backward(q(gy, dtype))
+    x_d, id_d = to_nhwc(xr, dtype), to_nhwc(idn, dtype)
+    nb = lib().tf_colstats_blocks(M, C, tfd)
+    part = torch.zeros(nb, 2, C, device="cuda")
+    assert lib().tf_colstats(tfd, ptr(x_d), None, ptr(x_d), None, M, C, C, ptr(part), stream()) == 0
+    bufs = [torch.zeros(C, device="cuda") for _ in range(9)]
+    scale, shift, mean, invstd, dga, dbe, cA, cB, cD = bufs
+    rmd, rvd, gd, bd = rm.clone().cuda(), rv.clone().cuda(), gamma.cuda(), beta.cuda()
+    assert lib().tf_bn_finalize(ptr(part), nb, C, C, float(M), ptr(gd), ptr(bd), 1e-5, 0.1, ptr(scale), ptr(shift), ptr(mean), ptr(invstd),
+                                ptr(rmd), ptr(rvd), stream()) == 0
+    y_d = torch.empty_like(x_d)
+    assert lib().tf_bn_add_relu(tfd, ptr(x_d), ptr(scale), ptr(shift), ptr(id_d), None, None, M, C, ptr(y_d), stream()) == 0
+    dy = err(from_nhwc(y_d), yref.detach())
+    drm, drv = err(rmd.cpu(), rm), err(rvd.cpu(), rv)
+    gy_d = to_nhwc(gy, dtype)
+    part3 = torch.zeros(nb, 2, C, device="cuda")
+    assert lib().tf_colstats(tfd, ptr(gy_d), ptr(y_d), ptr(x_d), None, M, C, C, ptr(part3), stream()) == 0
+    assert lib().tf_bn_bwd_finalize(ptr(part3), nb, 2, 1, C, C, float(M), ptr(gd), ptr(mean), ptr(invstd), ptr(dga), ptr(dbe), ptr(cA),
+                                    ptr(cB), ptr(cD), stream()) == 0
+    gx_d = torch.empty_like(x_d)
+    assert lib().tf_bn_bwd_apply(tfd, ptr(gy_d), ptr(y_d), ptr(x_d), ptr(cA), ptr(cB), ptr(cD), M, C, ptr(gx_d), stream()) == 0
+    dgx = err(from_nhwc(gx_d), xq.grad)
+    dgg, dgb = err(dga.cpu(), gm.grad), err(dbe.cpu(), bt.grad)
+    report(f"bn_chain[{dtype}]", y_rel=dy[2], rm=drm[0], rv=drv[0], gx_rel=dgx[2], dgamma_rel=dgg[2], dbeta_rel=dgb[2])
+    t = 1e-5 if dtype == torch.float32 else 1.5e-2
+    assert dy[2] < t and dgx[2] < (1e-4 if dtype == torch.float32 else 2e-2)
+    assert drm[0] < 1e-4 and drv[0] < 1e-3 and dgg[2] < (1e-4 if dtype == torch.float32 else 2e-2) and dgb[2] < (1e-4 if dtype == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("hw", [(8, 8), (13, 17), (63, 63)])
+def test_upsample_add_crop_fwd_bwd(dtype, hw):
+    """score4_upsample (ConvTranspose2d k4 s2 p1, bilinear diagonal) + crop + add, vs torch (model.py:104-126)."""
+    from tinyfaces._hip import lib, ptr, stream, tf_dtype
+    from oracle.model import bilinear_kernel
+    g = _g(hw[0])
+    B, C = 2, 125
+    H3, W3 = hw
+    H4, W4 = (H3 + 1) // 2, (W3 + 1) // 2
+    s3 = torch.randn(B, C, H3, W3, generator=g)
+    s4 = torch.randn(B, C, H4, W4, generator=g, requires_grad=False)
+    wfull = torch.zeros(C, C, 4, 4)
+    wfull[torch.arange(C), torch.arange(C)] = torch.from_numpy(bilinear_kernel(4)).float()
+    s4q = q(s4, dtype).requires_grad_(True)
+    s3q = q(s3, dtype).requires_grad_(True)
+    up = F.conv_transpose2d(s4q, wfull, stride=2, padding=1)[:, :, :H3, :W3]
+    ref = s3q + up
+    pad = lambda t: torch.cat([t, torch.zeros(B, 3, *t.shape[2:])], 1)
+    s3d, s4d = to_nhwc(pad(s3), dtype), to_nhwc(pad(s4), dtype)
+    diag = wfull[torch.arange(C), torch.arange(C)].reshape(C, 16).contiguous().cuda()
+    out = torch.empty(B, C, H3, W3, device="cuda")
+    tfd = tf_dtype(dtype)
+    assert lib().tf_upsample_add_crop(tfd, ptr(s3d), ptr(s4d), ptr(diag), B, C, 128, H3, W3, H4, W4, ptr(out), stream()) == 0
+    d = err(out.cpu(), ref.detach())
+    go = torch.randn(ref.shape, generator=g)
+    ref.backward(go)
+    g3 = torch.empty(B, H3, W3, 128, dtype=dtype, device="cuda")
+    g4 = torch.empty(B, H4, W4, 128, dtype=dtype, device="cuda")
+    god = go.cuda()
+    assert lib().tf_upsample_add_crop_bwd(tfd, ptr(god), ptr(diag), B, C, 128, H3, W3, H4, W4, ptr(g3), ptr(g4), stream()) == 0
+    d3 = err(from_nhwc(g3)[:, :C], s3q.grad)
+    d4 = err(from_nhwc(g4)[:, :C], s4q.grad)
+    report(f"upsample[{dtype},{hw}]", fwd_maxabs=d[0], g3=d3[2], g4=d4[2])
+    assert d[0] < 1e-5 and d3[2] < TOL[dtype] and d4[2] < TOL[dtype]
+    assert float(from_nhwc(g3)[:, C:].abs().max()) == 0

@@ -1,0 +1,59 @@
+"""CPU: host-side logic of the drop-in surface (no GPU compute)."""
+import numpy as np
+import pytest
+import torch
+
+
+def test_template_masks_reproduce_reference_d1(templates):
+    from tinyfaces import ops
+    from oracle.decode import invalid_template_ids
+    for scale in (0.25, 0.5, 1, 2):
+        inv = invalid_template_ids(templates, scale)
+        vx, vt = ops.template_masks(templates, scale, 40, "w")
+        assert sorted(np.where(vx == 0)[0].tolist()) == sorted(inv.tolist()) and vt.all()
+        vx, vt = ops.template_masks(templates, scale, 40, "template")
+        assert sorted(np.where(vt == 0)[0].tolist()) == sorted(inv.tolist()) and vx.all()
+    with pytest.raises(IndexError):
+        ops.template_masks(templates, 1, 20, "w")
+
+
+def test_templates_equal_reference_values(templates):
+    from tinyfaces.datasets.templates import load_templates
+    assert np.array_equal(load_templates(25), templates)      # fixture = np.round(reference templates.json, 8)
+
+
+def test_criterion_constants_and_meters():
+    from tinyfaces.models.loss import AvgMeter, DetectionCriterion
+    c = DetectionCriterion(25)
+    assert (c.max_pos, c.max_neg, c.ohem_thresh) == (128, 128, 0.03)
+    a = AvgMeter()
+    a.update(10.0, 2); a.update(20.0, 2)
+    assert a.average == 7.5 and a.num_averaged == 4                 # loss.py:13-17 semantics (sum / images)
+
+
+def test_print_state_format(capsys):
+    from tinyfaces.trainer import print_state
+    print_state(3, 1, 10, 1.5, 2.25)
+    assert capsys.readouterr().out == "Epoch: [1][3/10]\t\tloss_cls: 1.500000\tloss_reg: 2.250000\n"
+
+
+def test_write_results_format(tmp_path):
+    from tinyfaces.evaluation import write_results
+    dets = np.array([[10.4, 20.6, 50.2, 80.9, 0.75]])
+    write_results(dets, "0--Parade/img_1.jpg", "val", tmp_path)
+    txt = (tmp_path / "0--Parade" / "img_1.txt").read_text().split("\n")
+    assert txt[0] == "img_1.jpg" and txt[1] == "1" and txt[2] == "10 21 41 61 0.75"      # evaluation.py:106-112
+
+
+def test_transforms_match_oracle_restatement():
+    from oracle import refstub
+    from tinyfaces import transforms
+    g = torch.Generator().manual_seed(0)
+    img = torch.rand(3, 37, 53, generator=g)
+    a, b = transforms.to_pil_image(img), refstub.to_pil_image(img)
+    assert np.array_equal(np.array(a), np.array(b))
+    for s in (20, 74):
+        assert np.array_equal(np.array(transforms.resize(a, s)), np.array(refstub.resize(b, s)))
+    tf1 = transforms.Compose([transforms.ToTensor(), transforms.Normalize([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])])
+    tf2 = refstub.Compose([refstub.ToTensor(), refstub.Normalize([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])])
+    assert torch.equal(tf1(a), tf2(b))

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Build libtinyfaces_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python tiny-faces-pytorch_amd/build.py [--force]
+
+Objects land in tiny-faces-pytorch_amd/build/, the library IN-TREE at
+tiny-faces-pytorch_amd/tinyfaces/libtinyfaces_hip.so (git-ignored, travels with gpurun)."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
+LIB = os.path.join(HERE, "tinyfaces", "libtinyfaces_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# files whose float64 arithmetic must round exactly like numpy's: no FMA contraction
+EXACT = {"targets.hip", "nms.hip", "decode.hip"}
+
+
+def _deps_mtime():
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs.append(os.path.join(os.path.dirname(HERE), "include", "tinyfaces_hip.h"))
+    return max(os.path.getmtime(h) for h in hdrs)
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+    hdr_m = _deps_mtime()
+    jobs = []
+    for f in srcs:
+        src, obj = os.path.join(CSRC, f), os.path.join(OBJ, f[:-4] + ".o")
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_m):
+            cmd = [HIPCC] + COMMON + (["-ffp-contract=off"] if f in EXACT else []) + ["-c", src, "-o", obj]
+            jobs.append((f, cmd))
+
+    def run(job):
+        f, cmd = job
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        return f, r.returncode, r.stdout + r.stderr
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        for f, rc, out in ex.map(run, jobs):
+            if verbose:
+                print(f"[hipcc] {f}: {'ok' if rc == 0 else 'FAILED'}")
+            if rc != 0:
+                raise RuntimeError(f"hipcc failed for {f}:\n{out}")
+            if out.strip() and verbose:
+                print(out)
+    objs = [os.path.join(OBJ, f[:-4] + ".o") for f in srcs]
+    if force or jobs or not os.path.exists(LIB):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n" + r.stdout + r.stderr)
+        if verbose:
+            print(f"[link] {LIB}")
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,86 @@
+// Shared device helpers for the tiny-faces gfx950 kernels (CDNA4, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/tinyfaces_hip.h"
+
+#define TF_CHECK_LAUNCH()                                  \
+  do {                                                     \
+    hipError_t e__ = hipGetLastError();                    \
+    if (e__ != hipSuccess) return TF_ERR_LAUNCH;           \
+  } while (0)
+
+namespace tf {
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+// round-to-nearest-even (same as torch's float->bfloat16); NaN kept quiet
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static constexpr int kPer16B = 4;
+  __device__ static __forceinline__ float load(const float* p) { return *p; }
+  __device__ static __forceinline__ void store(float* p, float v) { *p = v; }
+};
+struct bf16_t { uint16_t v; };
+template <> struct Elem<bf16_t> {
+  static constexpr int kPer16B = 8;
+  __device__ static __forceinline__ float load(const bf16_t* p) { return bf16_to_f32(p->v); }
+  __device__ static __forceinline__ void store(bf16_t* p, float v) { p->v = f32_to_bf16(v); }
+};
+
+// unpack a 16-byte register into floats and back
+template <typename T> __device__ __forceinline__ void unpack16(const uint4& r, float* f);
+template <> __device__ __forceinline__ void unpack16<float>(const uint4& r, float* f) {
+  f[0] = __uint_as_float(r.x); f[1] = __uint_as_float(r.y); f[2] = __uint_as_float(r.z); f[3] = __uint_as_float(r.w);
+}
+template <> __device__ __forceinline__ void unpack16<bf16_t>(const uint4& r, float* f) {
+  f[0] = __uint_as_float(r.x << 16); f[1] = __uint_as_float(r.x & 0xffff0000u);
+  f[2] = __uint_as_float(r.y << 16); f[3] = __uint_as_float(r.y & 0xffff0000u);
+  f[4] = __uint_as_float(r.z << 16); f[5] = __uint_as_float(r.z & 0xffff0000u);
+  f[6] = __uint_as_float(r.w << 16); f[7] = __uint_as_float(r.w & 0xffff0000u);
+}
+template <typename T> __device__ __forceinline__ uint4 pack16(const float* f);
+template <> __device__ __forceinline__ uint4 pack16<float>(const float* f) {
+  return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+}
+template <> __device__ __forceinline__ uint4 pack16<bf16_t>(const float* f) {
+  return make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// counter-based RNG (splitmix64 finaliser over a 4-word key) -> uniform [0,1) double / u32
+__device__ __host__ __forceinline__ uint64_t mix64(uint64_t z) {
+  z += 0x9e3779b97f4a7c15ull;
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return z ^ (z >> 31);
+}
+__device__ __host__ __forceinline__ uint64_t hash4(uint64_t a, uint64_t b, uint64_t c, uint64_t d) {
+  return mix64(mix64(mix64(mix64(a) ^ b) ^ c) ^ d);
+}
+__device__ __host__ __forceinline__ double u01(uint64_t h) { return (double)(h >> 11) * (1.0 / 9007199254740992.0); }
+
+}  // namespace tf

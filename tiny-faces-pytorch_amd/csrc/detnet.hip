@@ -1,0 +1,534 @@
+// The detector network as a native graph executor: every kernel launch of a forward or a
+// backward pass is issued from here (one C-ABI call per pass, no Python in the loop), with all
+// activations carved from one caller-provided arena.
+// Replaces DetectionModel.forward (tinyfaces/models/model.py:89-128) over the torchvision
+// ResNet-101 trunk (Bottleneck x [3,4,23], stride on the 3x3) and the autograd backward that
+// tinyfaces/trainer.py:86 triggers.
+//
+// Data layout in HBM: activations NHWC ("pixels x channels"), dtype bf16 (fast) or fp32
+// (parity); BN vectors, statistics and all gradients fp32; weights re-packed per call from the
+// fp32 OIHW master copy into K-contiguous [Cout][tap][Cin] (forward / wgrad operand) and
+// [Cin][tap][Cout] (data-gradient operand).
+//
+// Fusion plan (what never makes an HBM round trip):
+//   eval : BN folded to a per-channel affine inside every conv epilogue, + residual + ReLU
+//   train: conv epilogue emits per-tile (sum, sumsq) partials -> tiny finalize -> the NEXT
+//          conv (and the wgrad) applies BN+ReLU while staging its input tile; only the block
+//          output y = relu(bn3(c3) + identity) is a separate pass.
+//          backward: dgrad epilogues apply the ReLU mask and emit the BN-backward sums; the
+//          residual-join gradient is folded into conv1's dgrad epilogue.
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+extern "C" {
+int tf_stem_im2col(const float*, int, int, int, int, void*, int, void*);
+int tf_maxpool_fwd(int, const void*, int, int, int, int, const float*, const float*, void*, uint8_t*, void*);
+int tf_maxpool_bwd(int, const void*, const uint8_t*, const void*, const float*, const float*, int, int, int, int, void*, void*);
+int tf_colstats_blocks(int, int, int);
+int tf_colstats(int, const void*, const void*, const void*, const void*, int, int, int, float*, void*);
+int tf_bn_finalize(const float*, int, int, int, float, const float*, const float*, float, float, float*, float*, float*, float*, float*,
+                   float*, void*);
+int tf_bn_fold(const float*, const float*, const float*, const float*, float, int, float*, float*, void*);
+int tf_bn_bwd_finalize(const float*, int, int, int, int, int, float, const float*, const float*, const float*, float*, float*, float*, float*,
+                       float*, void*);
+int tf_bn_bwd_apply(int, const void*, const void*, const void*, const float*, const float*, const float*, int64_t, int, void*, void*);
+int tf_bn_add_relu(int, const void*, const float*, const float*, const void*, const float*, const float*, int64_t, int, void*, void*);
+int tf_upsample_add_crop(int, const void*, const void*, const float*, int, int, int, int, int, int, int, float*, void*);
+int tf_upsample_add_crop_bwd(int, const float*, const float*, int, int, int, int, int, int, int, void*, void*, void*);
+int tf_reduce_partials(const float*, int, int, int, int, int, float*, void*);
+}
+
+namespace {
+
+constexpr int kStemK = 192;     // 147 taps*channels padded to 3 x 64
+constexpr int kHeadLd = 128;    // 125 outputs padded
+
+struct ConvUnit {               // one conv + (optional) BN, with indices into the parameter table
+  std::string name;             // e.g. "model.layer1.0.conv1"
+  int cin, cout, k, stride, pad;
+  int w, gamma, beta, rmean, rvar;   // param-table indices (-1 if absent)
+  int bias;                          // heads only
+};
+struct Block { ConvUnit c1, c2, c3, ds; bool has_ds; int planes, stride, cin; };
+struct Arch {
+  ConvUnit stem;
+  std::vector<Block> blocks;    // 30 bottlenecks
+  int layer_end[3];             // index of the last block of layer1/2/3
+  ConvUnit head3, head4;
+  int upsample_w;
+  std::vector<std::string> names;
+};
+
+int add_param(Arch& a, const std::string& n) { a.names.push_back(n); return (int)a.names.size() - 1; }
+
+ConvUnit make_unit(Arch& a, const std::string& conv, const std::string& bn, int cin, int cout, int k, int stride, int pad) {
+  ConvUnit u;
+  u.name = conv; u.cin = cin; u.cout = cout; u.k = k; u.stride = stride; u.pad = pad; u.bias = -1;
+  u.w = add_param(a, conv + ".weight");
+  u.gamma = add_param(a, bn + ".weight"); u.beta = add_param(a, bn + ".bias");
+  u.rmean = add_param(a, bn + ".running_mean"); u.rvar = add_param(a, bn + ".running_var");
+  return u;
+}
+
+const Arch& arch() {
+  static Arch a = [] {
+    Arch a;
+    a.stem = make_unit(a, "model.conv1", "model.bn1", 3, 64, 7, 2, 3);
+    const int nblk[3] = {3, 4, 23}, planes[3] = {64, 128, 256};
+    int inpl = 64;
+    for (int L = 0; L < 3; ++L) {
+      for (int b = 0; b < nblk[L]; ++b) {
+        Block B;
+        const std::string p = "model.layer" + std::to_string(L + 1) + "." + std::to_string(b);
+        B.planes = planes[L]; B.stride = (b == 0 && L > 0) ? 2 : 1; B.cin = inpl;
+        B.c1 = make_unit(a, p + ".conv1", p + ".bn1", inpl, planes[L], 1, 1, 0);
+        B.c2 = make_unit(a, p + ".conv2", p + ".bn2", planes[L], planes[L], 3, B.stride, 1);
+        B.c3 = make_unit(a, p + ".conv3", p + ".bn3", planes[L], planes[L] * 4, 1, 1, 0);
+        B.has_ds = (b == 0);
+        if (B.has_ds) B.ds = make_unit(a, p + ".downsample.0", p + ".downsample.1", inpl, planes[L] * 4, 1, B.stride, 0);
+        inpl = planes[L] * 4;
+        a.blocks.push_back(B);
+      }
+      a.layer_end[L] = (int)a.blocks.size() - 1;
+    }
+    auto head = [&](const std::string& n, int cin) {
+      ConvUnit u; u.name = n; u.cin = cin; u.cout = -1; u.k = 1; u.stride = 1; u.pad = 0;
+      u.w = add_param(a, n + ".weight"); u.bias = add_param(a, n + ".bias");
+      u.gamma = u.beta = u.rmean = u.rvar = -1;
+      return u;
+    };
+    a.head3 = head("score_res3", 512);
+    a.head4 = head("score_res4", 1024);
+    a.upsample_w = add_param(a, "score4_upsample.weight");
+    return a;
+  }();
+  return a;
+}
+
+inline int down2(int n) { return (n - 1) / 2 + 1; }   // every stride-2 stage of the trunk: ceil(n/2)
+inline size_t esize(int dtype) { return dtype == TF_BF16 ? 2 : 4; }
+inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Arena {
+  char* base; size_t cap, off; bool ok;
+  Arena(void* b, size_t c) : base((char*)b), cap(c), off(0), ok(true) {}
+  void* get(size_t bytes) {
+    const size_t o = off; off += up256(bytes);
+    if (off > cap && base) ok = false;
+    return base ? base + o : nullptr;
+  }
+  float* f32(size_t n) { return (float*)get(n * 4); }
+};
+
+// per-BN scratch: scale/shift (forward affine), mean/invstd, backward coefficients
+struct BnBuf { float *scale, *shift, *mean, *invstd, *cA, *cB, *cD; };
+BnBuf bn_alloc(Arena& ar, int C) {
+  BnBuf b; float* p = ar.f32((size_t)7 * C);
+  b.scale = p; b.shift = p + C; b.mean = p + 2 * C; b.invstd = p + 3 * C; b.cA = p + 4 * C; b.cB = p + 5 * C; b.cD = p + 6 * C;
+  return b;
+}
+
+struct Plan {                    // everything a forward carves; backward re-derives the same pointers
+  int dtype, N, H, W, nout, training;
+  int H1, W1, H2, W2;            // stem conv out, maxpool out
+  void *col, *cstem, *pool; uint8_t* pool_idx; BnBuf bn_stem;
+  void *wstem;
+  struct Blk {
+    int Hin, Win, Hout, Wout;
+    void *c1, *c2, *c3, *d, *y;
+    void *w1, *w2, *w3, *wd;         // packed forward weights
+    BnBuf b1, b2, b3, bd;
+  };
+  std::vector<Blk> blk;
+  void *w_h3, *w_h4, *s3, *s4; float *hbias3, *hbias4, *ones, *wup_diag;
+  float* partial; size_t partial_floats;
+  // backward-only
+  void *g3, *g4, *G0, *G1, *T1, *T2, *T3, *T4, *R3, *wt;   // gradient buffers (roles in tf_detnet_backward) + transposed-weight scratch
+  int H3, W3, H4, W4;
+  size_t total;
+};
+
+size_t packed_bytes(int dtype, int rows, int taps, int cols) { return (size_t)((rows + 127) / 128 * 128) * taps * cols * esize(dtype); }
+
+void build_plan(Plan& P, Arena& ar, int dtype, int N, int H, int W, int nout, int training) {
+  const Arch& A = arch();
+  const size_t es = esize(dtype);
+  P.dtype = dtype; P.N = N; P.H = H; P.W = W; P.nout = nout; P.training = training;
+  P.H1 = down2(H); P.W1 = down2(W); P.H2 = down2(P.H1); P.W2 = down2(P.W1);
+  const size_t M1 = (size_t)N * P.H1 * P.W1, M2 = (size_t)N * P.H2 * P.W2;
+  size_t max_partial = 0;
+  auto part = [&](size_t M, int C) { size_t t = ((M + 63) / 64) * 2 * (size_t)C; if (t > max_partial) max_partial = t; };
+  P.col = ar.get(M1 * kStemK * es);
+  P.cstem = ar.get(M1 * 64 * es);
+  P.pool = ar.get(M2 * 64 * es);
+  P.pool_idx = (uint8_t*)ar.get(training ? M2 * 64 : 0);
+  P.bn_stem = bn_alloc(ar, 64);
+  P.wstem = ar.get(packed_bytes(dtype, 64, 1, kStemK));
+  part(M1, 64);
+  int h = P.H2, w = P.W2;
+  P.blk.resize(A.blocks.size());
+  size_t max_act = M1 * 64 * es, max_wt = 0;
+  for (size_t i = 0; i < A.blocks.size(); ++i) {
+    const Block& B = A.blocks[i];
+    Plan::Blk& b = P.blk[i];
+    b.Hin = h; b.Win = w; b.Hout = B.stride == 2 ? down2(h) : h; b.Wout = B.stride == 2 ? down2(w) : w;
+    const size_t Min = (size_t)N * h * w, Mout = (size_t)N * b.Hout * b.Wout;
+    const int pl = B.planes, c4 = pl * 4;
+    b.c1 = ar.get(Min * pl * es); b.c2 = ar.get(Mout * pl * es);
+    b.c3 = training ? ar.get(Mout * c4 * es) : nullptr;
+    b.d = B.has_ds ? ar.get(Mout * c4 * es) : nullptr;
+    b.y = ar.get(Mout * c4 * es);
+    b.w1 = ar.get(packed_bytes(dtype, pl, 1, B.cin)); b.w2 = ar.get(packed_bytes(dtype, pl, 9, pl));
+    b.w3 = ar.get(packed_bytes(dtype, c4, 1, pl));
+    b.wd = B.has_ds ? ar.get(packed_bytes(dtype, c4, 1, B.cin)) : nullptr;
+    b.b1 = bn_alloc(ar, pl); b.b2 = bn_alloc(ar, pl); b.b3 = bn_alloc(ar, c4);
+    if (B.has_ds) b.bd = bn_alloc(ar, c4);
+    part(Min, pl); part(Mout, c4);
+    if (Min * (size_t)B.cin * es > max_act) max_act = Min * B.cin * es;
+    if (Mout * c4 * es > max_act) max_act = Mout * c4 * es;
+    const size_t wtb = packed_bytes(dtype, pl, 9, pl);
+    if (wtb > max_wt) max_wt = wtb;
+    if (packed_bytes(dtype, B.cin, 1, c4) > max_wt) max_wt = packed_bytes(dtype, B.cin, 1, c4);
+    h = b.Hout; w = b.Wout;
+  }
+  const Plan::Blk& l2 = P.blk[A.layer_end[1]];
+  const Plan::Blk& l3 = P.blk[A.layer_end[2]];
+  P.H3 = l2.Hout; P.W3 = l2.Wout; P.H4 = l3.Hout; P.W4 = l3.Wout;
+  const size_t M3 = (size_t)N * P.H3 * P.W3, M4 = (size_t)N * P.H4 * P.W4;
+  P.w_h3 = ar.get(packed_bytes(dtype, kHeadLd, 1, 512)); P.w_h4 = ar.get(packed_bytes(dtype, kHeadLd, 1, 1024));
+  P.s3 = ar.get(M3 * kHeadLd * es); P.s4 = ar.get(M4 * kHeadLd * es);
+  P.hbias3 = ar.f32(kHeadLd); P.hbias4 = ar.f32(kHeadLd); P.ones = ar.f32(kHeadLd);
+  P.wup_diag = ar.f32((size_t)nout * 16);
+  part(M3, kHeadLd);
+  P.partial_floats = max_partial + 4096;
+  P.partial = ar.f32(P.partial_floats);
+  if (training) {
+    P.g3 = ar.get(M3 * kHeadLd * es); P.g4 = ar.get(M4 * kHeadLd * es);
+    P.G0 = ar.get(max_act); P.G1 = ar.get(max_act); P.T1 = ar.get(max_act); P.T2 = ar.get(max_act);
+    P.T3 = ar.get(max_act); P.T4 = ar.get(max_act); P.R3 = ar.get(max_act);
+    if (packed_bytes(dtype, 1024, 1, kHeadLd) > max_wt) max_wt = packed_bytes(dtype, 1024, 1, kHeadLd);
+    P.wt = ar.get(max_wt);
+  } else {
+    P.g3 = P.g4 = P.G0 = P.G1 = P.T1 = P.T2 = P.T3 = P.T4 = P.R3 = P.wt = nullptr;
+  }
+  P.total = ar.off;
+}
+
+__global__ void head_vectors_kernel(const float* b3, const float* b4, const float* wup, int nout, float* hb3, float* hb4, float* ones,
+                                    float* diag) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < kHeadLd) { hb3[i] = i < nout ? b3[i] : 0.f; hb4[i] = i < nout ? b4[i] : 0.f; ones[i] = 1.f; }
+  if (i < nout * 16) { const int c = i / 16, k = i % 16; diag[i] = wup[((size_t)c * nout + c) * 16 + k]; }
+}
+
+struct Ctx {
+  int dtype; hipStream_t stream; void* const* params; void* const* grads; int rc;
+  const float* P(int i) const { return (const float*)params[i]; }
+  float* G(int i) const { return grads ? (float*)grads[i] : nullptr; }
+  void chk(int r) { if (r != TF_OK && rc == TF_OK) rc = r; }
+};
+
+void conv_fill(tf_conv_args& a, int dtype, int mode, int N, int H, int W, int Cin, int OH, int OW, int Cout, int k, int stride, int pad,
+               int ldy, const void* x, const void* w, void* y) {
+  memset(&a, 0, sizeof(a));
+  a.dtype = dtype; a.mode = mode; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.OH = OH; a.OW = OW; a.Cout = Cout; a.KH = k; a.KW = k;
+  a.stride = stride; a.pad = pad; a.ldy = ldy; a.x = x; a.w = w; a.y = y;
+}
+
+void pack(Ctx& c, const ConvUnit& u, int cout, void* out, bool transpose, int cin_override = 0, int cols_pad_override = 0,
+          int k_override = 0) {
+  const int cin = cin_override ? cin_override : u.cin;
+  const int taps = k_override ? k_override : u.k;
+  if (!transpose) {
+    const int cols = cols_pad_override ? cols_pad_override : cin;
+    c.chk(tf_pack_weight(c.P(u.w), cout, cin, taps, taps, 0, c.dtype, out, (cout + 127) / 128 * 128, cols, c.stream));
+  } else {
+    const int cols = cols_pad_override ? cols_pad_override : cout;
+    c.chk(tf_pack_weight(c.P(u.w), cout, cin, taps, taps, 1, c.dtype, out, (cin + 127) / 128 * 128, cols, c.stream));
+  }
+}
+
+// BN after a conv: eval -> fold running stats; train -> finalize batch partials (+ running update)
+void bn_forward(Ctx& c, const ConvUnit& u, int C, BnBuf& b, bool training, const tf_conv_args* conv, float* partial, float count, float eps,
+                float mom) {
+  if (!training) {
+    c.chk(tf_bn_fold(c.P(u.gamma), c.P(u.beta), c.P(u.rmean), c.P(u.rvar), eps, C, b.scale, b.shift, c.stream));
+  } else {
+    c.chk(tf_bn_finalize(partial, tf_conv_mtiles(conv), conv->ldy, C, count, c.P(u.gamma), c.P(u.beta), eps, mom, b.scale, b.shift, b.mean,
+                         b.invstd, (float*)c.params[u.rmean], (float*)c.params[u.rvar], c.stream));
+  }
+}
+
+}  // namespace
+
+extern "C" int tf_detnet_num_params(void) { return (int)arch().names.size(); }
+extern "C" const char* tf_detnet_param_name(int i) {
+  const Arch& a = arch();
+  return (i >= 0 && i < (int)a.names.size()) ? a.names[i].c_str() : nullptr;
+}
+extern "C" int64_t tf_detnet_param_numel(int i, int nout) {
+  const Arch& a = arch();
+  auto unit = [&](const ConvUnit& u, int cout) -> int64_t {
+    if (i == u.w) return (int64_t)cout * u.cin * u.k * u.k;
+    if (i == u.gamma || i == u.beta || i == u.rmean || i == u.rvar || i == u.bias) return cout;
+    return -1;
+  };
+  int64_t r;
+  if ((r = unit(a.stem, 64)) >= 0) return r;
+  for (const Block& B : a.blocks) {
+    if ((r = unit(B.c1, B.planes)) >= 0) return r;
+    if ((r = unit(B.c2, B.planes)) >= 0) return r;
+    if ((r = unit(B.c3, B.planes * 4)) >= 0) return r;
+    if (B.has_ds && (r = unit(B.ds, B.planes * 4)) >= 0) return r;
+  }
+  if ((r = unit(a.head3, nout)) >= 0) return r;
+  if ((r = unit(a.head4, nout)) >= 0) return r;
+  if (i == a.upsample_w) return (int64_t)nout * nout * 16;
+  return -1;
+}
+
+extern "C" int tf_detnet_out_shape(int H, int W, int* H3, int* W3) {
+  if (H3) *H3 = down2(down2(down2(H)));
+  if (W3) *W3 = down2(down2(down2(W)));
+  return TF_OK;
+}
+
+extern "C" size_t tf_detnet_workspace_bytes(int dtype, int N, int H, int W, int nout, int training) {
+  Plan P; Arena ar(nullptr, 0);
+  build_plan(P, ar, dtype, N, H, W, nout, training);
+  return P.total + 4096;
+}
+
+extern "C" int tf_detnet_forward(int dtype, int training, const float* x, int N, int H, int W, int nout, void* const* params, float eps,
+                                 float mom, float* out, void* ws, size_t ws_bytes, void* stream_) {
+  if (!x || !params || !out || !ws || nout <= 0 || nout > kHeadLd) return TF_ERR_ARG;
+  if (dtype != TF_BF16 && dtype != TF_F32) return TF_ERR_UNSUPPORTED;
+  const Arch& A = arch();
+  Plan P; Arena ar(ws, ws_bytes);
+  build_plan(P, ar, dtype, N, H, W, nout, training);
+  if (!ar.ok) return TF_ERR_WORKSPACE;
+  Ctx c{dtype, (hipStream_t)stream_, params, nullptr, TF_OK};
+  tf_conv_args a;
+  const bool tr = training != 0;
+
+  // ---- stem: im2col + GEMM (+BN+ReLU) + maxpool
+  const int M1 = N * P.H1 * P.W1;
+  c.chk(tf_stem_im2col(x, N, H, W, dtype, P.col, kStemK, c.stream));
+  pack(c, A.stem, 64, P.wstem, false, 147, kStemK, 1);     // conv1.weight flattened OIHW == im2col k order
+  conv_fill(a, dtype, 0, 1, 1, M1, kStemK, 1, M1, 64, 1, 1, 0, 64, P.col, P.wstem, P.cstem);
+  if (tr) { a.epi = TF_EPI_STATS; a.stat_out = P.partial; }
+  else {
+    bn_forward(c, A.stem, 64, P.bn_stem, false, nullptr, nullptr, 0, eps, mom);
+    a.epi = TF_EPI_AFFINE | TF_EPI_RELU; a.epi_scale = P.bn_stem.scale; a.epi_shift = P.bn_stem.shift;
+  }
+  c.chk(tf_conv2d(&a, c.stream));
+  if (tr) bn_forward(c, A.stem, 64, P.bn_stem, true, &a, P.partial, (float)M1, eps, mom);
+  c.chk(tf_maxpool_fwd(dtype, P.cstem, N, P.H1, P.W1, 64, tr ? P.bn_stem.scale : nullptr, tr ? P.bn_stem.shift : nullptr, P.pool,
+                       tr ? P.pool_idx : nullptr, c.stream));
+
+  // ---- bottlenecks
+  const void* yin = P.pool;
+  for (size_t i = 0; i < A.blocks.size(); ++i) {
+    const Block& B = A.blocks[i];
+    Plan::Blk& b = P.blk[i];
+    const int pl = B.planes, c4 = pl * 4;
+    const int Min = N * b.Hin * b.Win, Mout = N * b.Hout * b.Wout;
+    pack(c, B.c1, pl, b.w1, false); pack(c, B.c2, pl, b.w2, false); pack(c, B.c3, c4, b.w3, false);
+    if (B.has_ds) pack(c, B.ds, c4, b.wd, false);
+    // conv1 1x1
+    conv_fill(a, dtype, 0, N, b.Hin, b.Win, B.cin, b.Hin, b.Win, pl, 1, 1, 0, pl, yin, b.w1, b.c1);
+    if (tr) { a.epi = TF_EPI_STATS; a.stat_out = P.partial; }
+    else { bn_forward(c, B.c1, pl, b.b1, false, nullptr, nullptr, 0, eps, mom); a.epi = TF_EPI_AFFINE | TF_EPI_RELU; a.epi_scale = b.b1.scale; a.epi_shift = b.b1.shift; }
+    c.chk(tf_conv2d(&a, c.stream));
+    if (tr) bn_forward(c, B.c1, pl, b.b1, true, &a, P.partial, (float)Min, eps, mom);
+    // conv2 3x3 (stride here)
+    conv_fill(a, dtype, 0, N, b.Hin, b.Win, pl, b.Hout, b.Wout, pl, 3, B.stride, 1, pl, b.c1, b.w2, b.c2);
+    if (tr) { a.pro_scale = b.b1.scale; a.pro_shift = b.b1.shift; a.pro_relu = 1; a.epi = TF_EPI_STATS; a.stat_out = P.partial; }
+    else { bn_forward(c, B.c2, pl, b.b2, false, nullptr, nullptr, 0, eps, mom); a.epi = TF_EPI_AFFINE | TF_EPI_RELU; a.epi_scale = b.b2.scale; a.epi_shift = b.b2.shift; }
+    c.chk(tf_conv2d(&a, c.stream));
+    if (tr) bn_forward(c, B.c2, pl, b.b2, true, &a, P.partial, (float)Mout, eps, mom);
+    // downsample 1x1 (stride)
+    if (B.has_ds) {
+      conv_fill(a, dtype, 0, N, b.Hin, b.Win, B.cin, b.Hout, b.Wout, c4, 1, B.stride, 0, c4, yin, b.wd, b.d);
+      if (tr) { a.epi = TF_EPI_STATS; a.stat_out = P.partial; }
+      else { bn_forward(c, B.ds, c4, b.bd, false, nullptr, nullptr, 0, eps, mom); a.epi = TF_EPI_AFFINE; a.epi_scale = b.bd.scale; a.epi_shift = b.bd.shift; }
+      c.chk(tf_conv2d(&a, c.stream));
+      if (tr) bn_forward(c, B.ds, c4, b.bd, true, &a, P.partial, (float)Mout, eps, mom);
+    }
+    // conv3 1x1 (+ BN + residual + ReLU)
+    conv_fill(a, dtype, 0, N, b.Hout, b.Wout, pl, b.Hout, b.Wout, c4, 1, 1, 0, c4, b.c2, b.w3, tr ? b.c3 : b.y);
+    if (tr) { a.pro_scale = b.b2.scale; a.pro_shift = b.b2.shift; a.pro_relu = 1; a.epi = TF_EPI_STATS; a.stat_out = P.partial; }
+    else {
+      bn_forward(c, B.c3, c4, b.b3, false, nullptr, nullptr, 0, eps, mom);
+      a.epi = TF_EPI_AFFINE | TF_EPI_RES | TF_EPI_RELU; a.epi_scale = b.b3.scale; a.epi_shift = b.b3.shift; a.aux = B.has_ds ? b.d : yin;
+    }
+    c.chk(tf_conv2d(&a, c.stream));
+    if (tr) {
+      bn_forward(c, B.c3, c4, b.b3, true, &a, P.partial, (float)Mout, eps, mom);
+      c.chk(tf_bn_add_relu(dtype, b.c3, b.b3.scale, b.b3.shift, B.has_ds ? b.d : yin, B.has_ds ? b.bd.scale : nullptr,
+                           B.has_ds ? b.bd.shift : nullptr, Mout, c4, b.y, c.stream));
+    }
+    yin = b.y;
+  }
+
+  // ---- heads + bilinear upsample + crop + add
+  const void* res3 = P.blk[A.layer_end[1]].y;
+  const void* res4 = P.blk[A.layer_end[2]].y;
+  hipLaunchKernelGGL(head_vectors_kernel, dim3((nout * 16 + 255) / 256), dim3(256), 0, c.stream, c.P(A.head3.bias), c.P(A.head4.bias),
+                     c.P(A.upsample_w), nout, P.hbias3, P.hbias4, P.ones, P.wup_diag);
+  c.chk(tf_pack_weight(c.P(A.head3.w), nout, 512, 1, 1, 0, dtype, P.w_h3, kHeadLd, 512, c.stream));
+  c.chk(tf_pack_weight(c.P(A.head4.w), nout, 1024, 1, 1, 0, dtype, P.w_h4, kHeadLd, 1024, c.stream));
+  conv_fill(a, dtype, 0, N, P.H3, P.W3, 512, P.H3, P.W3, kHeadLd, 1, 1, 0, kHeadLd, res3, P.w_h3, P.s3);
+  a.epi = TF_EPI_AFFINE; a.epi_scale = P.ones; a.epi_shift = P.hbias3;
+  c.chk(tf_conv2d(&a, c.stream));
+  conv_fill(a, dtype, 0, N, P.H4, P.W4, 1024, P.H4, P.W4, kHeadLd, 1, 1, 0, kHeadLd, res4, P.w_h4, P.s4);
+  a.epi = TF_EPI_AFFINE; a.epi_scale = P.ones; a.epi_shift = P.hbias4;
+  c.chk(tf_conv2d(&a, c.stream));
+  c.chk(tf_upsample_add_crop(dtype, P.s3, P.s4, P.wup_diag, N, nout, kHeadLd, P.H3, P.W3, P.H4, P.W4, out, c.stream));
+  if (hipGetLastError() != hipSuccess && c.rc == TF_OK) c.rc = TF_ERR_LAUNCH;
+  return c.rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward
+namespace {
+
+// g_x for a BN whose output-gradient sums are in `partial`: finalize (dgamma, dbeta, coefficients)
+void bn_backward_coefs(Ctx& c, const ConvUnit& u, int C, BnBuf& b, const float* partial, int nblk, int nk, int kidx, int ld, float count) {
+  c.chk(tf_bn_bwd_finalize(partial, nblk, nk, kidx, ld, C, count, c.P(u.gamma), b.mean, b.invstd, c.G(u.gamma), c.G(u.beta), b.cA, b.cB,
+                           b.cD, c.stream));
+}
+
+void wgrad(Ctx& c, const ConvUnit& u, int cout, int N, int H, int W, int OH, int OW, const void* x, int ldx, const void* dy, int lddy,
+           const BnBuf* pro, int cin_override = 0, int k_override = 0, int dw_ld = 0) {
+  tf_wgrad_args w;
+  memset(&w, 0, sizeof(w));
+  const int cin = cin_override ? cin_override : u.cin, k = k_override ? k_override : u.k;
+  w.dtype = c.dtype; w.N = N; w.H = H; w.W = W; w.Cin = cin; w.OH = OH; w.OW = OW; w.Cout = cout; w.KH = k; w.KW = k;
+  w.stride = u.stride; w.pad = u.pad; w.ldx = ldx; w.lddy = lddy; w.x = x; w.dy = dy; w.dw_oihw = c.G(u.w);
+  w.dw_ld = dw_ld ? dw_ld : cin * k * k;
+  if (pro) { w.pro_scale = pro->scale; w.pro_shift = pro->shift; w.pro_relu = 1; }
+  if (hipMemsetAsync(w.dw_oihw, 0, (size_t)cout * w.dw_ld * 4, c.stream) != hipSuccess) c.chk(TF_ERR_LAUNCH);
+  c.chk(tf_conv2d_wgrad(&w, c.stream));
+}
+
+}  // namespace
+
+extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W, int nout, void* const* params, void* const* grads,
+                                  const float* gout, void* ws, size_t ws_bytes, void* stream_) {
+  if (!x || !params || !grads || !gout || !ws) return TF_ERR_ARG;
+  const Arch& A = arch();
+  Plan P; Arena ar(ws, ws_bytes);
+  build_plan(P, ar, dtype, N, H, W, nout, 1);
+  if (!ar.ok) return TF_ERR_WORKSPACE;
+  Ctx c{dtype, (hipStream_t)stream_, params, grads, TF_OK};
+  tf_conv_args a;
+  const int M3 = N * P.H3 * P.W3, M4 = N * P.H4 * P.W4;
+  const void* res3 = P.blk[A.layer_end[1]].y;
+  const void* res4 = P.blk[A.layer_end[2]].y;
+
+  // ---- heads
+  c.chk(tf_upsample_add_crop_bwd(dtype, gout, P.wup_diag, N, nout, kHeadLd, P.H3, P.W3, P.H4, P.W4, P.g3, P.g4, c.stream));
+  {
+    const int nb3 = tf_colstats_blocks(M3, kHeadLd, dtype), nb4 = tf_colstats_blocks(M4, kHeadLd, dtype);
+    c.chk(tf_colstats(dtype, P.g3, nullptr, nullptr, nullptr, M3, kHeadLd, kHeadLd, P.partial, c.stream));
+    c.chk(tf_reduce_partials(P.partial, nb3, 1, 0, kHeadLd, nout, c.G(A.head3.bias), c.stream));
+    c.chk(tf_colstats(dtype, P.g4, nullptr, nullptr, nullptr, M4, kHeadLd, kHeadLd, P.partial, c.stream));
+    c.chk(tf_reduce_partials(P.partial, nb4, 1, 0, kHeadLd, nout, c.G(A.head4.bias), c.stream));
+  }
+  {
+    ConvUnit h3 = A.head3, h4 = A.head4;
+    wgrad(c, h3, nout, N, P.H3, P.W3, P.H3, P.W3, res3, 512, P.g3, kHeadLd, nullptr);
+    wgrad(c, h4, nout, N, P.H4, P.W4, P.H4, P.W4, res4, 1024, P.g4, kHeadLd, nullptr);
+  }
+  // score4_upsample.weight has lr 0 (model.py:84): its gradient is defined as zero here
+  if (c.G(A.upsample_w) && hipMemsetAsync(c.G(A.upsample_w), 0, (size_t)nout * nout * 16 * 4, c.stream) != hipSuccess) c.chk(TF_ERR_LAUNCH);
+
+  // Buffer roles: Gcur/Gnext ping-pong the gradient w.r.t. a block output / input; T1 = g_c3 then g_c1;
+  // T2 = gz2 -> g_c2; T3 = g_d; T4 = downsample-branch input gradient; R3 = gradient w.r.t. res3 from the head.
+  void *Gcur = P.G0, *Gnext = P.G1;
+  c.chk(tf_pack_weight(c.P(A.head4.w), nout, 1024, 1, 1, 1, dtype, P.wt, 1024, kHeadLd, c.stream));
+  conv_fill(a, dtype, 1, N, P.H4, P.W4, kHeadLd, P.H4, P.W4, 1024, 1, 1, 0, 1024, P.g4, P.wt, Gcur);
+  c.chk(tf_conv2d(&a, c.stream));
+  c.chk(tf_pack_weight(c.P(A.head3.w), nout, 512, 1, 1, 1, dtype, P.wt, 512, kHeadLd, c.stream));
+  conv_fill(a, dtype, 1, N, P.H3, P.W3, kHeadLd, P.H3, P.W3, 512, 1, 1, 0, 512, P.g3, P.wt, P.R3);
+  c.chk(tf_conv2d(&a, c.stream));
+
+  // ---- bottlenecks in reverse
+  for (int i = (int)A.blocks.size() - 1; i >= 0; --i) {
+    const Block& B = A.blocks[i];
+    Plan::Blk& b = P.blk[i];
+    const int pl = B.planes, c4 = pl * 4;
+    const int Min = N * b.Hin * b.Win, Mout = N * b.Hout * b.Wout;
+    const void* yin = i == 0 ? P.pool : P.blk[i - 1].y;
+    const void* extra = (i == A.layer_end[1] + 1) ? P.R3 : nullptr;     // the block whose INPUT is res3
+    // (1) per-channel sums for bn3 (and the downsample BN) with gz = g_y * (y > 0)
+    const int nb = tf_colstats_blocks(Mout, c4, dtype);
+    c.chk(tf_colstats(dtype, Gcur, b.y, b.c3, B.has_ds ? b.d : nullptr, Mout, c4, c4, P.partial, c.stream));
+    const int nk = B.has_ds ? 3 : 2;
+    bn_backward_coefs(c, B.c3, c4, b.b3, P.partial, nb, nk, 1, c4, (float)Mout);
+    if (B.has_ds) bn_backward_coefs(c, B.ds, c4, b.bd, P.partial, nb, nk, 2, c4, (float)Mout);
+    // (2) g_c3 -> T1
+    c.chk(tf_bn_bwd_apply(dtype, Gcur, b.y, b.c3, b.b3.cA, b.b3.cB, b.b3.cD, Mout, c4, P.T1, c.stream));
+    // (3) wgrad conv3 (its input is relu(bn2(c2)), re-materialised in the loader)
+    wgrad(c, B.c3, c4, N, b.Hout, b.Wout, b.Hout, b.Wout, b.c2, pl, P.T1, c4, &b.b2);
+    // (4) dgrad conv3 -> gz2 in T2 (masked by relu(bn2(c2))) + BN-backward sums
+    pack(c, B.c3, c4, P.wt, true);
+    conv_fill(a, dtype, 1, N, b.Hout, b.Wout, c4, b.Hout, b.Wout, pl, 1, 1, 0, pl, P.T1, P.wt, P.T2);
+    a.epi = TF_EPI_MASK | TF_EPI_STATS2; a.aux = b.c2; a.mask_scale = b.b2.scale; a.mask_shift = b.b2.shift; a.stat_out = P.partial;
+    c.chk(tf_conv2d(&a, c.stream));
+    bn_backward_coefs(c, B.c2, pl, b.b2, P.partial, tf_conv_mtiles(&a), 2, 1, pl, (float)Mout);
+    // (5) g_c2 in place
+    c.chk(tf_bn_bwd_apply(dtype, P.T2, nullptr, b.c2, b.b2.cA, b.b2.cB, b.b2.cD, Mout, pl, P.T2, c.stream));
+    // (6) wgrad conv2 (input relu(bn1(c1)))
+    wgrad(c, B.c2, pl, N, b.Hin, b.Win, b.Hout, b.Wout, b.c1, pl, P.T2, pl, &b.b1);
+    // (7) dgrad conv2 -> gz1 in T1 (+ sums); output spatial = conv2's input
+    pack(c, B.c2, pl, P.wt, true);
+    conv_fill(a, dtype, 1, N, b.Hout, b.Wout, pl, b.Hin, b.Win, pl, 3, B.stride, 1, pl, P.T2, P.wt, P.T1);
+    a.epi = TF_EPI_MASK | TF_EPI_STATS2; a.aux = b.c1; a.mask_scale = b.b1.scale; a.mask_shift = b.b1.shift; a.stat_out = P.partial;
+    c.chk(tf_conv2d(&a, c.stream));
+    bn_backward_coefs(c, B.c1, pl, b.b1, P.partial, tf_conv_mtiles(&a), 2, 1, pl, (float)Min);
+    // (8) g_c1 in place
+    c.chk(tf_bn_bwd_apply(dtype, P.T1, nullptr, b.c1, b.b1.cA, b.b1.cB, b.b1.cD, Min, pl, P.T1, c.stream));
+    // (9) wgrad conv1 (input = block input, already activated)
+    wgrad(c, B.c1, pl, N, b.Hin, b.Win, b.Hin, b.Win, yin, B.cin, P.T1, pl, nullptr);
+    // (10) gradient w.r.t. the block input -> Gnext
+    if (B.has_ds) {
+      c.chk(tf_bn_bwd_apply(dtype, Gcur, b.y, b.d, b.bd.cA, b.bd.cB, b.bd.cD, Mout, c4, P.T3, c.stream));
+      wgrad(c, B.ds, c4, N, b.Hin, b.Win, b.Hout, b.Wout, yin, B.cin, P.T3, c4, nullptr);
+      pack(c, B.ds, c4, P.wt, true);
+      conv_fill(a, dtype, 1, N, b.Hout, b.Wout, c4, b.Hin, b.Win, B.cin, 1, B.stride, 0, B.cin, P.T3, P.wt, P.T4);
+      if (extra) { a.epi = TF_EPI_RES; a.aux = extra; }
+      c.chk(tf_conv2d(&a, c.stream));
+      pack(c, B.c1, pl, P.wt, true);
+      conv_fill(a, dtype, 1, N, b.Hin, b.Win, pl, b.Hin, b.Win, B.cin, 1, 1, 0, B.cin, P.T1, P.wt, Gnext);
+      a.epi = TF_EPI_RES; a.aux = P.T4;
+      c.chk(tf_conv2d(&a, c.stream));
+    } else {
+      pack(c, B.c1, pl, P.wt, true);
+      conv_fill(a, dtype, 1, N, b.Hin, b.Win, pl, b.Hin, b.Win, B.cin, 1, 1, 0, B.cin, P.T1, P.wt, Gnext);
+      a.epi = TF_EPI_JOIN; a.aux2 = b.y; a.aux3 = Gcur;       // identity branch: + g_y * (y > 0)
+      c.chk(tf_conv2d(&a, c.stream));
+    }
+    void* t = Gcur; Gcur = Gnext; Gnext = t;
+  }
+
+  // ---- stem
+  const int M1 = N * P.H1 * P.W1;
+  void* gz = P.T1;
+  c.chk(tf_maxpool_bwd(dtype, Gcur, P.pool_idx, P.cstem, P.bn_stem.scale, P.bn_stem.shift, N, P.H1, P.W1, 64, gz, c.stream));
+  const int nb = tf_colstats_blocks(M1, 64, dtype);
+  c.chk(tf_colstats(dtype, gz, nullptr, P.cstem, nullptr, M1, 64, 64, P.partial, c.stream));
+  bn_backward_coefs(c, A.stem, 64, P.bn_stem, P.partial, nb, 2, 1, 64, (float)M1);
+  c.chk(tf_bn_bwd_apply(dtype, gz, nullptr, P.cstem, P.bn_stem.cA, P.bn_stem.cB, P.bn_stem.cD, M1, 64, gz, c.stream));
+  c.chk(tf_stem_im2col(x, N, H, W, dtype, P.col, kStemK, c.stream));
+  {
+    ConvUnit s = A.stem; s.stride = 1; s.pad = 0;
+    wgrad(c, s, 64, 1, 1, M1, 1, M1, P.col, kStemK, gz, 64, nullptr, 147, 1, 147);
+  }
+  if (hipGetLastError() != hipSuccess && c.rc == TF_OK) c.rc = TF_ERR_LAUNCH;
+  return c.rc;
+}

@@ -1,0 +1,552 @@
+// HBM-bound companions of the conv engine (all NHWC "pixels x channels", 16-byte vector
+// accesses, fp32 math): weight packing, stem im2col, max-pool, BN statistics / finalize /
+// backward, residual join, bilinear head upsample + crop + add and their gradients.
+// Each replaces the torch op cited in tinyfaces_hip.h (tinyfaces/models/model.py:90-126).
+#include "common.h"
+
+namespace {
+
+using tf::bf16_t;
+
+// ---------------------------------------------------------------- weight packing
+template <typename T>
+__global__ void pack_weight_kernel(const float* __restrict__ w, int Cout, int Cin, int KH, int KW, int transpose,
+                                   T* __restrict__ out, int rows_pad, int cols_pad) {
+  // normal:    out[co][tap][ci]  rows = co (pad rows_pad), inner = ci (pad cols_pad)
+  // transpose: out[ci][tap][co]  rows = ci,                 inner = co
+  const int taps = KH * KW;
+  const size_t total = (size_t)rows_pad * taps * cols_pad;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int inner = (int)(i % cols_pad);
+    const int tap = (int)((i / cols_pad) % taps);
+    const int row = (int)(i / ((size_t)cols_pad * taps));
+    const int co = transpose ? inner : row, ci = transpose ? row : inner;
+    float v = 0.f;
+    if (co < Cout && ci < Cin) v = w[((size_t)co * Cin + ci) * taps + tap];
+    tf::Elem<T>::store(out + i, v);
+  }
+}
+
+// ---------------------------------------------------------------- stem im2col
+// x NCHW fp32 [N][3][H][W] -> col [M][ldc], k = c*49 + kh*7 + kw (== OIHW order of conv1.weight), zero padded
+template <typename T>
+__global__ void __launch_bounds__(256) stem_im2col_kernel(const float* __restrict__ x, int N, int H, int W, int OH, int OW,
+                                                          T* __restrict__ col, int ldc) {
+  constexpr int EPS = tf::Elem<T>::kPer16B;
+  const int spr = ldc / EPS;
+  const size_t total = (size_t)N * OH * OW * spr;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int s = (int)(i % spr);
+    const size_t p = i / spr;
+    const int ow = (int)(p % OW), oh = (int)((p / OW) % OH), n = (int)(p / ((size_t)OW * OH));
+    float f[EPS];
+#pragma unroll
+    for (int j = 0; j < EPS; ++j) {
+      const int k = s * EPS + j;
+      float v = 0.f;
+      if (k < 147) {
+        const int c = k / 49, r = k - c * 49, kh = r / 7, kw = r - kh * 7;
+        const int ih = oh * 2 - 3 + kh, iw = ow * 2 - 3 + kw;
+        if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) v = x[(((size_t)n * 3 + c) * H + ih) * W + iw];
+      }
+      f[j] = v;
+    }
+    *reinterpret_cast<uint4*>(reinterpret_cast<char*>(col) + i * 16) = tf::pack16<T>(f);
+  }
+}
+
+// ---------------------------------------------------------------- max-pool 3x3 s2 p1 (+ fused BN/ReLU of the stem)
+template <typename T>
+__global__ void __launch_bounds__(256) maxpool_fwd_kernel(const T* __restrict__ x, int N, int H, int W, int C, const float* __restrict__ sc,
+                                                          const float* __restrict__ sh, T* __restrict__ y, uint8_t* __restrict__ idx,
+                                                          int OH, int OW) {
+  constexpr int EPS = tf::Elem<T>::kPer16B;
+  const int spr = C / EPS;
+  const size_t total = (size_t)N * OH * OW * spr;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int s = (int)(i % spr);
+    const size_t p = i / spr;
+    const int ow = (int)(p % OW), oh = (int)((p / OW) % OH), n = (int)(p / ((size_t)OW * OH));
+    float best[EPS]; int bi[EPS];
+#pragma unroll
+    for (int j = 0; j < EPS; ++j) { best[j] = -INFINITY; bi[j] = 0; }
+    float fs[EPS], fh[EPS];
+    if (sc) {
+#pragma unroll
+      for (int j = 0; j < EPS; ++j) { fs[j] = sc[s * EPS + j]; fh[j] = sh[s * EPS + j]; }
+    }
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int ih = oh * 2 - 1 + kh, iw = ow * 2 - 1 + kw;
+        if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
+          const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(x) + ((((size_t)n * H + ih) * W + iw) * spr + s) * 16);
+          float f[EPS];
+          tf::unpack16<T>(v, f);
+#pragma unroll
+          for (int j = 0; j < EPS; ++j) {
+            float t = f[j];
+            if (sc) t = fmaxf(t * fs[j] + fh[j], 0.f);
+            if (t > best[j]) { best[j] = t; bi[j] = kh * 3 + kw; }     // first max wins (torch CPU max_pool2d)
+          }
+        }
+      }
+    *reinterpret_cast<uint4*>(reinterpret_cast<char*>(y) + i * 16) = tf::pack16<T>(best);
+    if (idx) {
+#pragma unroll
+      for (int j = 0; j < EPS; ++j) idx[i * EPS + j] = (uint8_t)bi[j];
+    }
+  }
+}
+
+// gz[n,ih,iw,c] = (relu mask of BN(x)) * sum over windows whose arg-max is this position of g[window]
+template <typename T>
+__global__ void __launch_bounds__(256) maxpool_bwd_kernel(const T* __restrict__ g, const uint8_t* __restrict__ idx, const T* __restrict__ x,
+                                                          const float* __restrict__ sc, const float* __restrict__ sh, int N, int H, int W,
+                                                          int C, int OH, int OW, T* __restrict__ gz) {
+  constexpr int EPS = tf::Elem<T>::kPer16B;
+  const int spr = C / EPS;
+  const size_t total = (size_t)N * H * W * spr;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int s = (int)(i % spr);
+    const size_t p = i / spr;
+    const int iw = (int)(p % W), ih = (int)((p / W) % H), n = (int)(p / ((size_t)W * H));
+    float acc[EPS];
+#pragma unroll
+    for (int j = 0; j < EPS; ++j) acc[j] = 0.f;
+    // windows (oh, ow) with ih = 2*oh - 1 + kh  ->  oh = (ih + 1 - kh) / 2
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int th = ih + 1 - kh;
+      if (th < 0 || (th & 1)) continue;
+      const int oh = th >> 1;
+      if (oh >= OH) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int tw = iw + 1 - kw;
+        if (tw < 0 || (tw & 1)) continue;
+        const int ow = tw >> 1;
+        if (ow >= OW) continue;
+        const size_t o = (((size_t)n * OH + oh) * OW + ow) * spr + s;
+        const uint4 gv = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(g) + o * 16);
+        float gf[EPS];
+        tf::unpack16<T>(gv, gf);
+        const uint8_t* ip = idx + o * EPS;
+#pragma unroll
+        for (int j = 0; j < EPS; ++j) if (ip[j] == kh * 3 + kw) acc[j] += gf[j];
+      }
+    }
+    const uint4 xv = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(x) + i * 16);
+    float xf[EPS];
+    tf::unpack16<T>(xv, xf);
+#pragma unroll
+    for (int j = 0; j < EPS; ++j) if (!(xf[j] * sc[s * EPS + j] + sh[s * EPS + j] > 0.f)) acc[j] = 0.f;
+    *reinterpret_cast<uint4*>(reinterpret_cast<char*>(gz) + i * 16) = tf::pack16<T>(acc);
+  }
+}
+
+// ---------------------------------------------------------------- column statistics  (M x C matrix)
+// out[blk][k][c]:  k=0: sum g'   k=1: sum g'*a   k=2: sum g'*b      with g' = g * (y > 0) if y given
+// (a == nullptr -> only k=0;  "sum x, sum x^2" is obtained with g = a = x)
+template <typename T>
+__global__ void __launch_bounds__(256) colstats_kernel(const T* __restrict__ g, const T* __restrict__ y, const T* __restrict__ a,
+                                                       const T* __restrict__ b, int M, int C, int ld, int rows_per_block,
+                                                       float* __restrict__ out, int nk) {
+  constexpr int EPS = tf::Elem<T>::kPer16B;
+  const int ct = C / EPS;                         // threads across channels (<= 256)
+  const int rt = 256 / ct;                        // rows in flight
+  const int tc = threadIdx.x % ct, tr = threadIdx.x / ct;
+  extern __shared__ float red[];                  // [rt][nk][C]
+  float s0[EPS], s1[EPS], s2[EPS];
+#pragma unroll
+  for (int j = 0; j < EPS; ++j) { s0[j] = 0.f; s1[j] = 0.f; s2[j] = 0.f; }
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  if (tr < rt) {
+    for (int r = r0 + tr; r < r1; r += rt) {
+      const size_t o = ((size_t)r * ld + tc * EPS) * sizeof(T);
+      float gf[EPS], f[EPS];
+      tf::unpack16<T>(*reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(g) + o), gf);
+      if (y) {
+        tf::unpack16<T>(*reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(y) + o), f);
+#pragma unroll
+        for (int j = 0; j < EPS; ++j) if (!(f[j] > 0.f)) gf[j] = 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < EPS; ++j) s0[j] += gf[j];
+      if (a) {
+        tf::unpack16<T>(*reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a) + o), f);
+#pragma unroll
+        for (int j = 0; j < EPS; ++j) s1[j] += gf[j] * f[j];
+      }
+      if (b) {
+        tf::unpack16<T>(*reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(b) + o), f);
+#pragma unroll
+        for (int j = 0; j < EPS; ++j) s2[j] += gf[j] * f[j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < EPS; ++j) {
+      red[(tr * nk + 0) * C + tc * EPS + j] = s0[j];
+      if (nk > 1) red[(tr * nk + 1) * C + tc * EPS + j] = s1[j];
+      if (nk > 2) red[(tr * nk + 2) * C + tc * EPS + j] = s2[j];
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < nk * C; e += 256) {
+    float t = 0.f;
+    for (int r = 0; r < rt; ++r) t += red[r * nk * C + e];
+    out[(size_t)blockIdx.x * nk * C + e] = t;
+  }
+}
+
+// ---------------------------------------------------------------- BN finalize (forward, batch statistics)
+// partial[blk][2][ld] (sum, sumsq) -> scale/shift for y = x*scale+shift, saved mean/invstd, running stats
+__global__ void bn_finalize_kernel(const float* __restrict__ partial, int nblk, int ld, int C, float count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float eps, float momentum, float* __restrict__ scale,
+                                   float* __restrict__ shift, float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int b = 0; b < nblk; ++b) { s += partial[((size_t)b * 2) * ld + c]; q += partial[((size_t)b * 2 + 1) * ld + c]; }
+  const double mean = s / count;
+  double var = q / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float sc = gamma[c] * invstd;
+  scale[c] = sc; shift[c] = beta[c] - (float)mean * sc;
+  mean_out[c] = (float)mean; invstd_out[c] = invstd;
+  if (running_mean) {
+    const double unbiased = count > 1.f ? var * count / (count - 1.0) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+// eval-mode BN fold: scale = gamma/sqrt(var+eps), shift = beta - mean*scale
+__global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ rm,
+                               const float* __restrict__ rv, float eps, int C, float* __restrict__ scale, float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float sc = gamma[c] / sqrtf(rv[c] + eps);
+  scale[c] = sc; shift[c] = beta[c] - rm[c] * sc;
+}
+
+// BN backward finalize: partial[blk][nk][ld] with k0 = sum gz, kidx = sum gz*x  ->
+//   dgamma, dbeta and the affine form  g_x = A*gz + B*x + D
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int nk, int kidx, int ld, int C, float count,
+                                       const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ cA, float* __restrict__ cB,
+                                       float* __restrict__ cD) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int b = 0; b < nblk; ++b) { s1 += partial[((size_t)b * nk) * ld + c]; s2 += partial[((size_t)b * nk + kidx) * ld + c]; }
+  const double mu = mean[c], is = invstd[c], ga = gamma[c];
+  const double dg = (s2 - mu * s1) * is;         // sum gz * xhat
+  dgamma[c] = (float)dg; dbeta[c] = (float)s1;
+  const double A = ga * is;
+  cA[c] = (float)A;
+  cB[c] = (float)(-A * is * dg / count);
+  cD[c] = (float)(-A * s1 / count + A * mu * is * dg / count);
+}
+
+// out = A*g' + B*x + D   (g' = g*(y>0) when y given).  BN input gradient, materialised for dgrad / wgrad.
+template <typename T>
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__ g, const T* __restrict__ y, const T* __restrict__ x,
+                                                           const float* __restrict__ cA, const float* __restrict__ cB,
+                                                           const float* __restrict__ cD, size_t M, int C, T* __restrict__ out) {
+  constexpr int EPS = tf::Elem<T>::kPer16B;
+  const int spr = C / EPS;
+  const size_t total = M * spr;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int s = (int)(i % spr);
+    float gf[EPS], xf[EPS], yf[EPS];
+    tf::unpack16<T>(*reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(g) + i * 16), gf);
+    tf::unpack16<T>(*reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(x) + i * 16), xf);
+    if (y) {
+      tf::unpack16<T>(*reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(y) + i * 16), yf);
+#pragma unroll
+      for (int j = 0; j < EPS; ++j) if (!(yf[j] > 0.f)) gf[j] = 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < EPS; ++j) { const int c = s * EPS + j; gf[j] = cA[c] * gf[j] + cB[c] * xf[j] + cD[c]; }
+    *reinterpret_cast<uint4*>(reinterpret_cast<char*>(out) + i * 16) = tf::pack16<T>(gf);
+  }
+}
+
+// y = relu(x*s1+h1 + (r*s2+h2  |  r))      block output of a Bottleneck in training mode
+template <typename T>
+__global__ void __launch_bounds__(256) bn_add_relu_kernel(const T* __restrict__ x, const float* __restrict__ s1, const float* __restrict__ h1,
+                                                          const T* __restrict__ r, const float* __restrict__ s2, const float* __restrict__ h2,
+                                                          size_t M, int C, T* __restrict__ y) {
+  constexpr int EPS = tf::Elem<T>::kPer16B;
+  const int spr = C / EPS;
+  const size_t total = M * spr;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int s = (int)(i % spr);
+    float xf[EPS], rf[EPS];
+    tf::unpack16<T>(*reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(x) + i * 16), xf);
+    tf::unpack16<T>(*reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(r) + i * 16), rf);
+#pragma unroll
+    for (int j = 0; j < EPS; ++j) {
+      const int c = s * EPS + j;
+      const float res = s2 ? rf[j] * s2[c] + h2[c] : rf[j];
+      xf[j] = fmaxf(xf[j] * s1[c] + h1[c] + res, 0.f);
+    }
+    *reinterpret_cast<uint4*>(reinterpret_cast<char*>(y) + i * 16) = tf::pack16<T>(xf);
+  }
+}
+
+// ---------------------------------------------------------------- head: bilinear ConvTranspose2d(k4,s2,p1) + crop + add
+// out NCHW fp32 [B][C][H3][W3] = s3[(b,y,x)][c] + sum_{ky,kx} s4[(b,i,j)][c] * wup[c][ky][kx],  y = 2i-1+ky, x = 2j-1+kx
+// (model.py:104-126; only the channel diagonal of score4_upsample.weight is non-zero, model.py:61-65)
+template <typename T>
+__global__ void __launch_bounds__(256) upsample_add_kernel(const T* __restrict__ s3, const T* __restrict__ s4, const float* __restrict__ wup,
+                                                           int B, int C, int ldc, int H3, int W3, int H4, int W4, float* __restrict__ out) {
+  // block: 64 consecutive pixels of one image x all channels; LDS transpose for coalesced NCHW rows
+  extern __shared__ float tile[];                 // [C][65]
+  const int hw = H3 * W3;
+  const int tiles_per_img = (hw + 63) / 64;
+  const int b = blockIdx.x / tiles_per_img, p0 = (blockIdx.x % tiles_per_img) * 64;
+  const int cq = ldc / 4;                         // 4-channel groups per pixel
+  for (int e = threadIdx.x; e < 64 * cq; e += 256) {
+    const int px = e / cq, c4 = (e % cq) * 4;
+    const int p = p0 + px;
+    if (p >= hw) continue;
+    const int y = p / W3, x = p - y * W3;
+    float v[4], t[4];
+    {
+      const T* src = s3 + ((size_t)b * hw + p) * ldc + c4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = tf::Elem<T>::load(src + j);
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int ky = ((y + 1) & 1) + 2 * a, ty = y + 1 - ky;
+      if (ty < 0) continue;
+      const int i = ty >> 1;
+      if (i >= H4) continue;
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb) {
+        const int kx = ((x + 1) & 1) + 2 * bb, tx = x + 1 - kx;
+        if (tx < 0) continue;
+        const int jx = tx >> 1;
+        if (jx >= W4) continue;
+        const T* src = s4 + (((size_t)b * H4 + i) * W4 + jx) * ldc + c4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j] = tf::Elem<T>::load(src + j);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (c4 + j < C) v[j] += t[j] * wup[(c4 + j) * 16 + ky * 4 + kx];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (c4 + j < C) tile[(c4 + j) * 65 + px] = v[j];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < C * 64; e += 256) {
+    const int c = e / 64, px = e % 64;
+    if (p0 + px < hw) out[((size_t)b * C + c) * hw + p0 + px] = tile[c * 65 + px];
+  }
+}
+
+// backward of the head: g NCHW fp32 -> g3 NHWC [B*H3*W3][ldc] (transpose), g4 NHWC [B*H4*W4][ldc] (transposed upsample)
+template <typename T>
+__global__ void __launch_bounds__(256) upsample_add_bwd_kernel(const float* __restrict__ g, const float* __restrict__ wup, int B, int C, int ldc,
+                                                               int H3, int W3, int H4, int W4, T* __restrict__ g3, T* __restrict__ g4) {
+  const size_t n3 = (size_t)B * H3 * W3, n4 = (size_t)B * H4 * W4;
+  const size_t total = (n3 + n4) * ldc;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int c = (int)(e % ldc);
+    const size_t p = e / ldc;
+    float v = 0.f;
+    if (p < n3) {
+      if (c < C) { const size_t b = p / ((size_t)H3 * W3), r = p % ((size_t)H3 * W3); v = g[(b * C + c) * ((size_t)H3 * W3) + r]; }
+      tf::Elem<T>::store(g3 + p * ldc + c, v);
+    } else {
+      const size_t q = p - n3;
+      if (c < C) {
+        const int jx = (int)(q % W4), i = (int)((q / W4) % H4);
+        const size_t b = q / ((size_t)W4 * H4);
+        const float* gp = g + (b * C + c) * ((size_t)H3 * W3);
+#pragma unroll
+        for (int ky = 0; ky < 4; ++ky) {
+          const int y = 2 * i - 1 + ky;
+          if ((unsigned)y >= (unsigned)H3) continue;
+#pragma unroll
+          for (int kx = 0; kx < 4; ++kx) {
+            const int x = 2 * jx - 1 + kx;
+            if ((unsigned)x >= (unsigned)W3) continue;
+            v += gp[(size_t)y * W3 + x] * wup[c * 16 + ky * 4 + kx];
+          }
+        }
+      }
+      tf::Elem<T>::store(g4 + q * ldc + c, v);
+    }
+  }
+}
+
+// sum over blocks of partial[blk][nk][ld] row k -> out[c]  (bias gradients)
+__global__ void reduce_partials_kernel(const float* __restrict__ partial, int nblk, int nk, int k, int ld, int C, float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += partial[((size_t)b * nk + k) * ld + c];
+  out[c] = (float)s;
+}
+
+inline unsigned grid_for(size_t total) {
+  size_t b = (total + 255) / 256;
+  if (b > 8192) b = 8192;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, ...)                                  \
+  do {                                                          \
+    if ((dtype) == TF_BF16) { using T = tf::bf16_t; __VA_ARGS__; } \
+    else if ((dtype) == TF_F32) { using T = float; __VA_ARGS__; }  \
+    else return TF_ERR_UNSUPPORTED;                             \
+  } while (0)
+
+extern "C" int tf_pack_weight(const float* w_oihw, int Cout, int Cin, int KH, int KW, int transpose, int dtype, void* out,
+                              int rows_pad, int cols_pad, void* stream) {
+  if (!w_oihw || !out) return TF_ERR_ARG;
+  const size_t total = (size_t)rows_pad * KH * KW * cols_pad;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(pack_weight_kernel<T>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, w_oihw, Cout, Cin, KH, KW,
+                                       transpose, (T*)out, rows_pad, cols_pad));
+  TF_CHECK_LAUNCH();
+  return TF_OK;
+}
+
+extern "C" int tf_stem_im2col(const float* x_nchw, int N, int H, int W, int dtype, void* col, int ldc, void* stream) {
+  if (!x_nchw || !col || ldc < 147 || ldc % 8) return TF_ERR_ARG;
+  const int OH = (H + 6 - 7) / 2 + 1, OW = (W + 6 - 7) / 2 + 1;
+  const size_t total = (size_t)N * OH * OW * (ldc / (dtype == TF_BF16 ? 8 : 4));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(stem_im2col_kernel<T>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x_nchw, N, H, W, OH, OW,
+                                       (T*)col, ldc));
+  TF_CHECK_LAUNCH();
+  return TF_OK;
+}
+
+extern "C" int tf_maxpool_fwd(int dtype, const void* x, int N, int H, int W, int C, const float* scale, const float* shift, void* y,
+                              uint8_t* argmax, void* stream) {
+  if (!x || !y || C % 8) return TF_ERR_ARG;
+  const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+  const size_t total = (size_t)N * OH * OW * (C / (dtype == TF_BF16 ? 8 : 4));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const T*)x, N, H, W, C,
+                                       scale, shift, (T*)y, argmax, OH, OW));
+  TF_CHECK_LAUNCH();
+  return TF_OK;
+}
+
+extern "C" int tf_maxpool_bwd(int dtype, const void* g, const uint8_t* argmax, const void* x, const float* scale, const float* shift, int N,
+                              int H, int W, int C, void* gz, void* stream) {
+  if (!g || !argmax || !x || !scale || !shift || !gz || C % 8) return TF_ERR_ARG;
+  const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+  const size_t total = (size_t)N * H * W * (C / (dtype == TF_BF16 ? 8 : 4));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const T*)g, argmax,
+                                       (const T*)x, scale, shift, N, H, W, C, OH, OW, (T*)gz));
+  TF_CHECK_LAUNCH();
+  return TF_OK;
+}
+
+extern "C" int tf_colstats_blocks(int M, int C, int dtype) {
+  const int eps = dtype == TF_BF16 ? 8 : 4;
+  const int rt = 256 / (C / eps);
+  int rows = 64 * (rt > 0 ? rt : 1);              // 64 row-iterations per thread
+  return (M + rows - 1) / rows;
+}
+
+extern "C" int tf_colstats(int dtype, const void* g, const void* y, const void* a, const void* b, int M, int C, int ld, float* partial,
+                           void* stream) {
+  const int eps = dtype == TF_BF16 ? 8 : 4;
+  if (!g || !partial || C % eps || C / eps > 256 || 256 % (C / eps)) return TF_ERR_ARG;
+  const int nk = b ? 3 : (a ? 2 : 1);
+  const int rt = 256 / (C / eps);
+  const int rows = 64 * rt;
+  const int nblk = (M + rows - 1) / rows;
+  const size_t lds = (size_t)rt * nk * C * 4;
+  if (lds > 64 * 1024) return TF_ERR_UNSUPPORTED;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(colstats_kernel<T>, dim3(nblk), dim3(256), lds, (hipStream_t)stream, (const T*)g, (const T*)y,
+                                       (const T*)a, (const T*)b, M, C, ld, rows, partial, nk));
+  TF_CHECK_LAUNCH();
+  return TF_OK;
+}
+
+extern "C" int tf_bn_finalize(const float* partial, int nblk, int ld, int C, float count, const float* gamma, const float* beta, float eps,
+                              float momentum, float* scale, float* shift, float* mean, float* invstd, float* running_mean,
+                              float* running_var, void* stream) {
+  if (!partial || !gamma || !beta || !scale || !shift || !mean || !invstd) return TF_ERR_ARG;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, partial, nblk, ld, C, count, gamma, beta, eps,
+                     momentum, scale, shift, mean, invstd, running_mean, running_var);
+  TF_CHECK_LAUNCH();
+  return TF_OK;
+}
+
+extern "C" int tf_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps, int C,
+                          float* scale, float* shift, void* stream) {
+  hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, gamma, beta, running_mean, running_var, eps, C,
+                     scale, shift);
+  TF_CHECK_LAUNCH();
+  return TF_OK;
+}
+
+extern "C" int tf_bn_bwd_finalize(const float* partial, int nblk, int nk, int kidx, int ld, int C, float count, const float* gamma,
+                                  const float* mean, const float* invstd, float* dgamma, float* dbeta, float* cA, float* cB, float* cD,
+                                  void* stream) {
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, partial, nblk, nk, kidx, ld, C, count,
+                     gamma, mean, invstd, dgamma, dbeta, cA, cB, cD);
+  TF_CHECK_LAUNCH();
+  return TF_OK;
+}
+
+extern "C" int tf_bn_bwd_apply(int dtype, const void* g, const void* y, const void* x, const float* cA, const float* cB, const float* cD,
+                               int64_t M, int C, void* out, void* stream) {
+  if (!g || !x || !out || C % 8) return TF_ERR_ARG;
+  const size_t total = (size_t)M * (C / (dtype == TF_BF16 ? 8 : 4));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const T*)g, (const T*)y,
+                                       (const T*)x, cA, cB, cD, (size_t)M, C, (T*)out));
+  TF_CHECK_LAUNCH();
+  return TF_OK;
+}
+
+extern "C" int tf_bn_add_relu(int dtype, const void* x, const float* s1, const float* h1, const void* r, const float* s2, const float* h2,
+                              int64_t M, int C, void* y, void* stream) {
+  if (!x || !r || !y || !s1 || !h1 || C % 8) return TF_ERR_ARG;
+  const size_t total = (size_t)M * (C / (dtype == TF_BF16 ? 8 : 4));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_add_relu_kernel<T>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const T*)x, s1, h1,
+                                       (const T*)r, s2, h2, (size_t)M, C, (T*)y));
+  TF_CHECK_LAUNCH();
+  return TF_OK;
+}
+
+extern "C" int tf_upsample_add_crop(int dtype, const void* s3, const void* s4, const float* wup_diag, int B, int C, int ldc, int H3, int W3,
+                                    int H4, int W4, float* out_nchw, void* stream) {
+  if (!s3 || !s4 || !wup_diag || !out_nchw || ldc % 4 || ldc < C) return TF_ERR_ARG;
+  const int tiles = (H3 * W3 + 63) / 64;
+  const size_t lds = (size_t)C * 65 * 4;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(upsample_add_kernel<T>, dim3(B * tiles), dim3(256), lds, (hipStream_t)stream, (const T*)s3, (const T*)s4,
+                                       wup_diag, B, C, ldc, H3, W3, H4, W4, out_nchw));
+  TF_CHECK_LAUNCH();
+  return TF_OK;
+}
+
+extern "C" int tf_upsample_add_crop_bwd(int dtype, const float* g_nchw, const float* wup_diag, int B, int C, int ldc, int H3, int W3, int H4,
+                                        int W4, void* g3, void* g4, void* stream) {
+  if (!g_nchw || !wup_diag || !g3 || !g4) return TF_ERR_ARG;
+  const size_t total = ((size_t)B * H3 * W3 + (size_t)B * H4 * W4) * ldc;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(upsample_add_bwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, g_nchw, wup_diag, B,
+                                       C, ldc, H3, W3, H4, W4, (T*)g3, (T*)g4));
+  TF_CHECK_LAUNCH();
+  return TF_OK;
+}
+
+extern "C" int tf_reduce_partials(const float* partial, int nblk, int nk, int k, int ld, int C, float* out, void* stream) {
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, partial, nblk, nk, k, ld, C, out);
+  TF_CHECK_LAUNCH();
+  return TF_OK;
+}

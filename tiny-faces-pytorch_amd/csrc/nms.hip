@@ -1,0 +1,141 @@
+// Greedy NMS in float64, index-exact vs torchvision.ops.nms' CPU kernel as called at
+// tinyfaces/evaluation.py:84 (see tinyfaces_hip.h).  Compiled with -ffp-contract=off.
+//
+//   1 rank sort   rank[i] = #{j : s_j > s_i  or (s_j == s_i and j < i)}  -> stable descending
+//                 order without a sorting network; O(N^2) compares, same order as the IoU work.
+//   2 bit matrix  mask[i][w] bit j = IoU(sorted i, sorted 64w+j) > thr, j > i (upper triangle),
+//                 one 64-thread wave per 64x64 block, column boxes staged in LDS.
+//   3 scan        one workgroup walks the 64-box chunks in order: wave 0 resolves the chunk's
+//                 diagonal 64x64 block in registers (readlane broadcast), then all waves OR the
+//                 kept rows into the running `removed` bit-vector held in LDS.
+#include "common.h"
+
+namespace {
+
+__global__ void __launch_bounds__(256) nms_rank_kernel(const double* __restrict__ scores, const double* __restrict__ boxes,
+                                                       int n, int* __restrict__ order, double* __restrict__ sboxes) {
+  __shared__ double tile[1024];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const double si = i < n ? scores[i] : 0.0;
+  int rank = 0;
+  for (int j0 = 0; j0 < n; j0 += 1024) {
+    __syncthreads();
+    for (int k = threadIdx.x; k < 1024; k += 256) tile[k] = (j0 + k < n) ? scores[j0 + k] : 0.0;
+    __syncthreads();
+    const int lim = min(1024, n - j0);
+    if (i < n) {
+      for (int k = 0; k < lim; ++k) {
+        const double sj = tile[k];
+        rank += (sj > si) || (sj == si && (j0 + k) < i);
+      }
+    }
+  }
+  if (i < n) {
+    order[rank] = i;
+    const double4 b = *reinterpret_cast<const double4*>(boxes + 4 * (size_t)i);
+    *reinterpret_cast<double4*>(sboxes + 4 * (size_t)rank) = b;
+  }
+}
+
+__global__ void __launch_bounds__(64) nms_mask_kernel(const double* __restrict__ sboxes, int n, double thr, int nwords,
+                                                      unsigned long long* __restrict__ mask) {
+  const int rb = blockIdx.y, cb = blockIdx.x;
+  if (cb < rb) return;                       // lower triangle never read
+  __shared__ double cbox[64][4];
+  __shared__ double carea[64];
+  const int t = threadIdx.x;
+  const int cj = cb * 64 + t;
+  if (cj < n) {
+    const double4 b = *reinterpret_cast<const double4*>(sboxes + 4 * (size_t)cj);
+    cbox[t][0] = b.x; cbox[t][1] = b.y; cbox[t][2] = b.z; cbox[t][3] = b.w;
+    carea[t] = (b.z - b.x) * (b.w - b.y);
+  }
+  __syncthreads();
+  const int i = rb * 64 + t;
+  if (i >= n) return;
+  const double4 a = *reinterpret_cast<const double4*>(sboxes + 4 * (size_t)i);
+  const double iarea = (a.z - a.x) * (a.w - a.y);
+  unsigned long long bits = 0;
+  const int lim = min(64, n - cb * 64);
+  for (int j = 0; j < lim; ++j) {
+    if (cb * 64 + j <= i) continue;
+    const double xx1 = fmax(a.x, cbox[j][0]), yy1 = fmax(a.y, cbox[j][1]);
+    const double xx2 = fmin(a.z, cbox[j][2]), yy2 = fmin(a.w, cbox[j][3]);
+    const double w = fmax(0.0, xx2 - xx1), h = fmax(0.0, yy2 - yy1);
+    const double inter = w * h;
+    const double ovr = inter / (iarea + carea[j] - inter);
+    if (ovr > thr) bits |= 1ull << j;
+  }
+  mask[(size_t)i * nwords + cb] = bits;
+}
+
+__global__ void __launch_bounds__(1024) nms_scan_kernel(const unsigned long long* __restrict__ mask, const int* __restrict__ order,
+                                                        int n, int nwords, int64_t* __restrict__ keep, int* __restrict__ num_keep) {
+  extern __shared__ unsigned long long removed[];   // nwords + 1 (slot nwords = keep bits of the current chunk)
+  for (int w = threadIdx.x; w <= nwords; w += blockDim.x) removed[w] = 0;
+  __syncthreads();
+  int kcount = 0;                                    // meaningful in wave 0 only
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int c = 0; c < nwords; ++c) {
+    if (wave == 0) {
+      const int i = c * 64 + lane;
+      unsigned long long diag = (i < n) ? mask[(size_t)i * nwords + c] : 0ull;
+      unsigned long long rem = removed[c];
+      if (n - c * 64 < 64) rem |= ~0ull << (n - c * 64);   // boxes past n do not exist
+      unsigned long long kb = 0;
+      const unsigned int dlo = (unsigned int)diag, dhi = (unsigned int)(diag >> 32);
+      for (int b = 0; b < 64; ++b) {
+        const unsigned long long d = ((unsigned long long)__builtin_amdgcn_readlane(dhi, b) << 32) |
+                                     (unsigned long long)__builtin_amdgcn_readlane(dlo, b);
+        if (!((rem >> b) & 1ull)) { kb |= 1ull << b; rem |= d; }
+      }
+      if ((kb >> lane) & 1ull) keep[kcount + __popcll(kb & ((1ull << lane) - 1ull))] = (int64_t)order[i];
+      kcount += __popcll(kb);
+      if (lane == 0) removed[nwords] = kb;
+    }
+    __syncthreads();
+    const unsigned long long kb = removed[nwords];
+    for (int w = c + 1 + threadIdx.x; w < nwords; w += blockDim.x) {
+      unsigned long long acc = 0, k = kb;
+      while (k) {
+        const int b = __ffsll((long long)k) - 1;
+        k &= k - 1;
+        acc |= mask[(size_t)(c * 64 + b) * nwords + w];
+      }
+      removed[w] |= acc;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *num_keep = kcount;
+}
+
+}  // namespace
+
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+extern "C" size_t tf_nms_workspace_bytes(int n) {
+  if (n <= 0) return 256;
+  size_t nwords = (size_t)(n + 63) / 64;
+  return align256((size_t)n * 4) + align256((size_t)n * 32) + align256((size_t)n * nwords * 8) + 256;
+}
+
+extern "C" int tf_nms_f64(const double* boxes, const double* scores, int n, double iou_thresh,
+                          int64_t* keep_out, int32_t* num_keep, void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n < 0 || !num_keep) return TF_ERR_ARG;
+  if (n == 0) return hipMemsetAsync(num_keep, 0, 4, stream) == hipSuccess ? TF_OK : TF_ERR_LAUNCH;
+  if (!boxes || !scores || !keep_out) return TF_ERR_ARG;
+  if (!ws || ws_bytes < tf_nms_workspace_bytes(n)) return TF_ERR_WORKSPACE;
+  const int nwords = (n + 63) / 64;
+  if ((size_t)(nwords + 1) * 8 > 64 * 1024) return TF_ERR_UNSUPPORTED;   // n <= 524k
+  char* w = (char*)ws;
+  int* order = (int*)w;                 w += align256((size_t)n * 4);
+  double* sboxes = (double*)w;          w += align256((size_t)n * 32);
+  unsigned long long* mask = (unsigned long long*)w;
+  hipLaunchKernelGGL(nms_rank_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, scores, boxes, n, order, sboxes);
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(nwords, nwords), dim3(64), 0, stream, sboxes, n, iou_thresh, nwords, mask);
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(1024), (size_t)(nwords + 1) * 8, stream, mask, order, n, nwords,
+                     keep_out, num_keep);
+  TF_CHECK_LAUNCH();
+  return TF_OK;
+}

@@ -1,0 +1,140 @@
+"""ctypes binding of libtinyfaces_hip.so (C ABI declared in include/tinyfaces_hip.h).
+
+The library is loaded AFTER `import torch` so that it binds to the HIP runtime torch already
+mapped (same soname libamdhip64.so.7) -- one runtime, torch's streams and allocations are
+directly usable.  There is no fallback: if the library is missing every op raises.
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must be imported before the .so is mapped)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtinyfaces_hip.so")
+
+TF_F32, TF_BF16 = 0, 1
+EPI_AFFINE, EPI_RES, EPI_RELU, EPI_STATS, EPI_MASK, EPI_STATS2, EPI_JOIN = 1, 2, 4, 8, 16, 32, 64
+ERRORS = {-1: "TF_ERR_ARG", -2: "TF_ERR_LAUNCH", -3: "TF_ERR_UNSUPPORTED", -4: "TF_ERR_WORKSPACE"}
+
+vp, i32, i64, u64, f32, f64, sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_double, C.c_size_t
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [("dtype", i32), ("mode", i32),
+                ("N", i32), ("H", i32), ("W", i32), ("Cin", i32), ("OH", i32), ("OW", i32), ("Cout", i32),
+                ("KH", i32), ("KW", i32), ("stride", i32), ("pad", i32),
+                ("ldy", i32), ("epi", i32), ("pro_relu", i32),
+                ("x", vp), ("w", vp), ("y", vp),
+                ("pro_scale", vp), ("pro_shift", vp), ("epi_scale", vp), ("epi_shift", vp),
+                ("aux", vp), ("aux2", vp), ("aux3", vp), ("mask_scale", vp), ("mask_shift", vp),
+                ("stat_out", vp), ("tile", i32)]
+
+
+class WgradArgs(C.Structure):
+    _fields_ = [("dtype", i32),
+                ("N", i32), ("H", i32), ("W", i32), ("Cin", i32), ("OH", i32), ("OW", i32), ("Cout", i32),
+                ("KH", i32), ("KW", i32), ("stride", i32), ("pad", i32),
+                ("ldx", i32), ("lddy", i32), ("pro_relu", i32),
+                ("x", vp), ("dy", vp), ("dw_oihw", vp), ("pro_scale", vp), ("pro_shift", vp),
+                ("dw_ld", i32), ("splitk", i32)]
+
+
+_SIGNATURES = {
+    "tf_version": (i32, []),
+    "tf_symbol_count": (i32, []),
+    "tf_symbol_name": (C.c_char_p, [i32]),
+    "tf_targets_workspace_bytes": (sz, [i32]),
+    "tf_dense_overlap_targets": (i32, [vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, u64, f64, f64,
+                                       vp, vp, vp, sz, vp]),
+    "tf_dense_overlap_iou": (i32, [vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "tf_nms_workspace_bytes": (sz, [i32]),
+    "tf_nms_f64": (i32, [vp, vp, i32, f64, vp, vp, vp, sz, vp]),
+    "tf_decode_workspace_bytes": (sz, [i32, i32, i32]),
+    "tf_decode_compact": (i32, [vp, i32, i32, i32, vp, i32, vp, vp, f32, f64, i32, i32, i32, i32, vp, vp, i32, vp, sz, vp]),
+    "tf_criterion_workspace_bytes": (sz, [i32, i32, i32, i32]),
+    "tf_criterion_fwd_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, f32, i32, i32, f32, vp, vp, u64, vp, vp, vp, vp, vp, sz, vp]),
+    "tf_sgd_step": (i32, [vp, vp, vp, i64, f32, f32, f32, f32, vp]),
+    "tf_conv_mtiles": (i32, [C.POINTER(ConvArgs)]),
+    "tf_conv2d": (i32, [C.POINTER(ConvArgs), vp]),
+    "tf_pack_weight": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp]),
+    "tf_conv2d_wgrad": (i32, [C.POINTER(WgradArgs), vp]),
+    "tf_stem_im2col": (i32, [vp, i32, i32, i32, i32, vp, i32, vp]),
+    "tf_maxpool_fwd": (i32, [i32, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
+    "tf_maxpool_bwd": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
+    "tf_colstats_blocks": (i32, [i32, i32, i32]),
+    "tf_colstats": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, vp, vp]),
+    "tf_bn_finalize": (i32, [vp, i32, i32, i32, f32, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp]),
+    "tf_bn_fold": (i32, [vp, vp, vp, vp, f32, i32, vp, vp, vp]),
+    "tf_bn_bwd_finalize": (i32, [vp, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "tf_bn_bwd_apply": (i32, [i32, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp]),
+    "tf_bn_add_relu": (i32, [i32, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp]),
+    "tf_upsample_add_crop": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "tf_upsample_add_crop_bwd": (i32, [i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
+    "tf_reduce_partials": (i32, [vp, i32, i32, i32, i32, i32, vp, vp]),
+    "tf_detnet_num_params": (i32, []),
+    "tf_detnet_param_name": (C.c_char_p, [i32]),
+    "tf_detnet_param_numel": (i64, [i32, i32]),
+    "tf_detnet_workspace_bytes": (sz, [i32, i32, i32, i32, i32, i32]),
+    "tf_detnet_out_shape": (i32, [i32, i32, C.POINTER(i32), C.POINTER(i32)]),
+    "tf_detnet_forward": (i32, [i32, i32, vp, i32, i32, i32, i32, vp, f32, f32, vp, vp, sz, vp]),
+    "tf_detnet_backward": (i32, [i32, vp, i32, i32, i32, i32, vp, vp, vp, vp, sz, vp]),
+    "tf_probe_tr16": (i32, [vp, vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library (raises HipLibraryMissing with build instructions if absent)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryMissing(
+                f"{LIB_PATH} not found: build it with `python tiny-faces-pytorch_amd/build.py` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback for the hot path.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(l, name)          # AttributeError here == ABI mismatch with include/tinyfaces_hip.h
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def symbols():
+    l = lib()
+    return [l.tf_symbol_name(i).decode() for i in range(l.tf_symbol_count())]
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed: {ERRORS.get(rc, rc)}")
+
+
+def require_gpu(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(f"{what}: tensor is on {t.device}; the tiny-faces hot path only exists as HIP kernels "
+                           "for MI355X (gfx950) -- there is no CPU fallback.")
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def tf_dtype(dtype):
+    if dtype in (torch.float32, "fp32", "f32", TF_F32):
+        return TF_F32
+    if dtype in (torch.bfloat16, "bf16", TF_BF16):
+        return TF_BF16
+    raise ValueError(f"unsupported compute dtype {dtype}")
+
+
+def torch_dtype(tfd):
+    return torch.float32 if tfd == TF_F32 else torch.bfloat16

@@ -1,0 +1,238 @@
+"""DetectionModel -- same call surface as the reference's tinyfaces/models/model.py:7-128,
+executed by the native HIP graph executor (csrc/detnet.hip) on MI355X.
+
+What is kept from the reference:
+  * constructor signature (model.py:12-16), `.forward(x)` (:89), `.learnable_parameters(lr)` (:67-87)
+  * the exact state_dict (571 entries: torchvision resnet101 names under `model.` incl. the dead
+    `model.fc.*` that model.py:23 leaves behind, `score_res3.*`, `score_res4.*`,
+    `score4_upsample.weight` initialised to the bilinear kernel of model.py:45-65)
+  * real nn.Parameters, so torch.optim.SGD / StepLR (main.py:67-83) work unchanged.
+What is different: forward/backward never run torch ops.  One C-ABI call per pass launches the
+hand-written gfx950 kernels; a CPU tensor raises (there is no CPU fallback).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import _hip
+from .._hip import check, lib, ptr, stream
+
+
+class _Bottleneck(nn.Module):
+    """Parameter container with torchvision's Bottleneck attribute names (never called)."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+
+class _ResNet101Trunk(nn.Module):
+    """Parameter container with torchvision resnet101's names; `layer4` is deleted by the owner
+    exactly like model.py:23, `avgpool`/`fc` stay (dead, but part of the checkpoint contract)."""
+
+    def __init__(self):
+        super().__init__()
+        self.inplanes = 64
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, stride=2, padding=1)
+        self.layer1 = self._make_layer(64, 3)
+        self.layer2 = self._make_layer(128, 4, stride=2)
+        self.layer3 = self._make_layer(256, 23, stride=2)
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.fc = nn.Linear(2048, 1000)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+    def _make_layer(self, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * 4:
+            downsample = nn.Sequential(nn.Conv2d(self.inplanes, planes * 4, 1, stride=stride, bias=False),
+                                       nn.BatchNorm2d(planes * 4))
+        layers = [_Bottleneck(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * 4
+        layers += [_Bottleneck(self.inplanes, planes) for _ in range(1, blocks)]
+        return nn.Sequential(*layers)
+
+
+def resnet101(weights=None, **_):
+    """Stand-in for `torchvision.models.resnet101` in the constructor signature (model.py:13)."""
+    return _ResNet101Trunk()
+
+
+class _DetNetFunction(torch.autograd.Function):
+    """forward = tf_detnet_forward, backward = tf_detnet_backward (csrc/detnet.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, owner, *params):
+        out = owner._run_forward(x, training=True)
+        ctx.owner = owner
+        ctx.save_for_backward(x)
+        ctx.ws_generation = owner._ws_generation
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        owner = ctx.owner
+        (x,) = ctx.saved_tensors
+        if ctx.ws_generation != owner._ws_generation:
+            raise RuntimeError("DetectionModel: the activation arena was reused by a later forward before this "
+                               "backward ran (one in-flight training step per model)")
+        grads = owner._run_backward(x, gout.contiguous().float())
+        return (None, None) + tuple(grads)
+
+
+class DetectionModel(nn.Module):
+    """Hybrid-resolution Tiny Faces detector (model.py:7-128) on the MI355X executor."""
+
+    def __init__(self, base_model=resnet101, pretrained_weights=None, num_templates=1, num_objects=1):
+        super().__init__()
+        output = (num_objects + 4) * num_templates                       # model.py:19
+        self.num_out = output
+        self.model = base_model(weights=None) if callable(base_model) else _ResNet101Trunk()
+        if hasattr(self.model, "layer4"):
+            del self.model.layer4                                        # model.py:23
+        self.score_res3 = nn.Conv2d(512, output, 1)                      # model.py:25-28
+        self.score_res4 = nn.Conv2d(1024, output, 1)                     # model.py:29-32
+        self.score4_upsample = nn.ConvTranspose2d(output, output, 4, stride=2, padding=1, bias=False)   # :34-39
+        self._init_bilinear()
+        self.compute_dtype = _hip.tf_dtype(os.environ.get("TINYFACES_DTYPE", "bf16"))
+        self._ws = None
+        self._ws_generation = 0
+        self._table_key = None
+        if isinstance(pretrained_weights, (str, os.PathLike)):           # no network here: a local file only
+            sd = torch.load(pretrained_weights, map_location="cpu")
+            self.load_state_dict(sd.get("model", sd), strict=False)
+
+    # ---- reference surface ---------------------------------------------------------------
+    def _init_bilinear(self):
+        """model.py:45-65: diagonal bilinear kernel [.25,.75,.75,.25] (x) [.25,.75,.75,.25]."""
+        k = self.score4_upsample.kernel_size[0]
+        factor = np.floor((k + 1) / 2)
+        center = factor if k % 2 == 1 else factor + 0.5
+        c = np.arange(1, k + 1)
+        v = np.ones((1, k)) - (np.abs(c - center) / factor)
+        f = np.zeros((self.score4_upsample.in_channels, self.score4_upsample.out_channels, k, k))
+        idx = np.arange(self.score4_upsample.out_channels)
+        f[idx, idx] = v.T @ v
+        self.score4_upsample.weight = nn.Parameter(torch.Tensor(f))
+
+    def learnable_parameters(self, lr):
+        """model.py:67-87: 4 SGD groups (trunk lr, score_res3 0.1*lr, score_res4 lr, upsample 0)."""
+        return [{"params": self.model.parameters(), "lr": lr},
+                {"params": self.score_res3.parameters(), "lr": 0.1 * lr},
+                {"params": self.score_res4.parameters(), "lr": 1 * lr},
+                {"params": self.score4_upsample.parameters(), "lr": 0}]
+
+    def set_compute_dtype(self, dtype):
+        """torch.float32 (exact-fp32 MFMA, parity path) or torch.bfloat16 (fast path)."""
+        self.compute_dtype = _hip.tf_dtype(dtype)
+        return self
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("DetectionModel.forward: input is on the CPU. This build has no CPU path: the forward/"
+                               "backward of the detector only exist as HIP kernels for MI355X (gfx950).")
+        x = x.contiguous().float()
+        self._sync_tables(x.device)
+        if self.training and torch.is_grad_enabled():
+            params = [p for p in self._grad_params]
+            return _DetNetFunction.apply(x, self, *params)
+        return self._run_forward(x, training=self.training)
+
+    # ---- executor plumbing ---------------------------------------------------------------
+    def _named_tensors(self):
+        d = dict(self.named_parameters())
+        d.update(dict(self.named_buffers()))
+        return d
+
+    def _sync_tables(self, device):
+        """(Re)build the device-pointer tables the executor reads; cheap, keyed on storage identity."""
+        named = self._named_tensors()
+        n = lib().tf_detnet_num_params()
+        names = [lib().tf_detnet_param_name(i).decode() for i in range(n)]
+        key = tuple(named[k].data_ptr() for k in names)
+        if key == self._table_key:
+            return
+        for i, k in enumerate(names):
+            t = named[k]
+            if t.device != device:
+                raise RuntimeError(f"parameter {k} is on {t.device}, input on {device}: call model.to(device) first")
+            if not t.is_contiguous() or t.dtype != torch.float32:
+                raise RuntimeError(f"parameter {k} must be contiguous float32")
+            want = lib().tf_detnet_param_numel(i, self.num_out)
+            if t.numel() != want:
+                raise RuntimeError(f"parameter {k}: {t.numel()} elements, executor expects {want}")
+        up = self.score4_upsample.weight.detach()
+        off = up.clone()
+        idx = torch.arange(self.num_out, device=up.device)
+        off[idx, idx] = 0
+        if float(off.abs().sum()) != 0.0:
+            raise RuntimeError("score4_upsample.weight has off-diagonal entries: the executor implements the frozen "
+                               "per-channel bilinear upsample of model.py:45-65 (lr=0, model.py:84) only")
+        self._names = names
+        self._param_ptrs = (C.c_void_p * n)(*[named[k].data_ptr() for k in names])
+        self._grad_names = [k for k in names if k in dict(self.named_parameters())]
+        pd = dict(self.named_parameters())
+        self._grad_params = [pd[k] for k in self._grad_names]
+        self._grad_numels = [pd[k].numel() for k in self._grad_names]
+        self._bn_modules = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
+        self._table_key = key
+
+    def _workspace(self, device, nbytes):
+        if self._ws is None or self._ws.device != device or self._ws.numel() < nbytes:
+            self._ws = None
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        return self._ws
+
+    def _run_forward(self, x, training):
+        N, _, H, W = x.shape
+        H3, W3 = C.c_int(), C.c_int()
+        lib().tf_detnet_out_shape(H, W, C.byref(H3), C.byref(W3))
+        nbytes = lib().tf_detnet_workspace_bytes(self.compute_dtype, N, H, W, self.num_out, int(training))
+        ws = self._workspace(x.device, nbytes)
+        self._ws_generation += 1
+        self._ws_shape = (N, H, W)
+        out = torch.empty(N, self.num_out, H3.value, W3.value, dtype=torch.float32, device=x.device)
+        bn = self.model.bn1
+        with torch.cuda.device(x.device):
+            check(lib().tf_detnet_forward(self.compute_dtype, int(training), ptr(x), N, H, W, self.num_out, self._param_ptrs,
+                                          float(bn.eps), float(bn.momentum), ptr(out), ptr(ws), ws.numel(), stream()),
+                  "tf_detnet_forward")
+        if training:
+            for m in self._bn_modules:                                   # BatchNorm2d bookkeeping
+                if m.num_batches_tracked is not None:
+                    m.num_batches_tracked += 1
+        return out
+
+    def _run_backward(self, x, gout):
+        N, _, H, W = x.shape
+        assert (N, H, W) == self._ws_shape
+        total = sum((n + 3) // 4 * 4 for n in self._grad_numels)       # every segment 16-byte aligned
+        gflat = torch.empty(total, dtype=torch.float32, device=x.device)
+        views, ptrs, o = {}, {}, 0
+        for k, n in zip(self._grad_names, self._grad_numels):
+            views[k] = gflat[o:o + n]
+            ptrs[k] = gflat.data_ptr() + 4 * o
+            o += (n + 3) // 4 * 4
+        table = (C.c_void_p * len(self._names))(*[ptrs.get(k, 0) for k in self._names])
+        with torch.cuda.device(x.device):
+            check(lib().tf_detnet_backward(self.compute_dtype, ptr(x), N, H, W, self.num_out, self._param_ptrs, table, ptr(gout),
+                                           ptr(self._ws), self._ws.numel(), stream()), "tf_detnet_backward")
+        self._last_grad_flat = gflat
+        pd = dict(self.named_parameters())
+        return [views[k].view_as(pd[k]) for k in self._grad_names]
