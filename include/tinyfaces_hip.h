@@ -234,6 +234,16 @@ int tf_detnet_backward(int dtype, const float* x_nchw, int N, int H, int W, int 
                        void* const* params, void* const* grads, const float* gout_nchw,
                        void* ws, size_t ws_bytes, void* stream);
 
+/* ---- measurement hooks (bench.py `roofline`) ------------------------------------------
+ * While enabled, every MFMA kernel launch (conv_igemm / wgrad) is bracketed by HIP events on
+ * the stream it is launched on.  tf_profile_collect blocks until they completed and writes
+ * rows of 5 doubles to HOST memory: kind, launches, total_ms, algorithmic flops, algorithmic
+ * bytes.  kind 0..5 = conv (dtype*3 + tile-1), 8..11 = wgrad (8 + dtype*2 + (tile==128)). */
+int tf_profile_enable(int on);
+int tf_profile_collect(double* host_out, int max_rows);
+/* test hook: raw lane mapping of ds_read_b64_tr_b16 (see tests/test_gpu_small_ops.py) */
+int tf_probe_tr16(unsigned short* out256, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,8 +31,7 @@ def test_library_exports_every_declared_symbol(built, hip):
     for name in declared:
         assert hasattr(l, name), f"{name} declared in include/tinyfaces_hip.h but not exported"
     listed = hip.symbols()
-    assert set(declared) <= set(listed) | {"tf_probe_tr16"}
-    assert set(listed) - {"tf_probe_tr16"} <= set(declared)
+    assert set(declared) == set(listed)
     assert hip.lib().tf_version() >= 100
 
 

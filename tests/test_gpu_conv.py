@@ -251,6 +251,7 @@ def test_bn_train_forward_backward_chain(dtype):
     xq = q(xr, dtype).requires_grad_(True)
     gm = gamma.clone().requires_grad_(True); bt = beta.clone().requires_grad_(True)
     rm, rv = torch.zeros(C), torch.ones(C)
+    rmd, rvd = rm.clone().cuda(), rv.clone().cuda()          # before torch updates rm / rv in place
     yref = torch.relu(F.batch_norm(xq, rm, rv, gm, bt, True, 0.1, 1e-5) + q(idn, dtype))
     gy = torch.randn(yref.shape, generator=g)
     yref.backward(q(gy, dtype))
@@ -260,7 +261,7 @@ def test_bn_train_forward_backward_chain(dtype):
     assert lib().tf_colstats(tfd, ptr(x_d), None, ptr(x_d), None, M, C, C, ptr(part), stream()) == 0
     bufs = [torch.zeros(C, device="cuda") for _ in range(9)]
     scale, shift, mean, invstd, dga, dbe, cA, cB, cD = bufs
-    rmd, rvd, gd, bd = rm.clone().cuda(), rv.clone().cuda(), gamma.cuda(), beta.cuda()
+    gd, bd = gamma.cuda(), beta.cuda()
     assert lib().tf_bn_finalize(ptr(part), nb, C, C, float(M), ptr(gd), ptr(bd), 1e-5, 0.1, ptr(scale), ptr(shift), ptr(mean), ptr(invstd),
                                 ptr(rmd), ptr(rvd), stream()) == 0
     y_d = torch.empty_like(x_d)

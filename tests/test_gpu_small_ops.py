@@ -142,8 +142,10 @@ def test_decode_golden(golden, ci):
     report(f"decode[{ci}]", n=b.shape[0], nref=rb.shape[0], box_maxabs=d)
     assert same_n                                                       # same candidates ...
     assert np.array_equal(s, rs)                                        # ... in the same order (scores are the raw logits)
-    # boxes: exp() of a float32 is evaluated by numpy in f32; the kernel rounds an f64 exp to f32 -> <= 1 f32 ulp on w/h
-    assert np.allclose(b, rb, rtol=3e-7, atol=1e-9)
+    # boxes: np.exp of a float32 array is numpy's own f32 routine (faithful, not always correctly rounded); the
+    # kernel rounds an f64 exp to f32.  They differ by <= 1 f32 ulp of exp(), i.e. <= 1.2e-7 * (box size / scale).
+    size = float(max((rb[:, 2] - rb[:, 0]).max(), (rb[:, 3] - rb[:, 1]).max()))
+    assert np.abs(b - rb).max() <= 1.3e-7 * size
 
 
 def test_decode_w_lt_25_raises_like_reference(golden):
@@ -180,7 +182,12 @@ def test_criterion_golden(golden, ci):
     loss2 = loss2.cpu().numpy()
     ref = g[f"{tag}_loss"]
     lab_mis = int((labels.cpu() != r["class_map_final"]).sum())
-    ohem_mis = int((cm_d.cpu().numpy().astype(np.int8) != g[f"{tag}_class_after_ohem_inplace"]).sum())
+    # loss.py:62 mines the caller's tensor in place.  (On a CPU tensor the reference's balance_sample ALSO writes
+    # through .cpu().numpy() aliasing, which is what the fixture recorded; on a device tensor only OHEM does.)
+    mined = cm.clone()
+    mined[torch.nn.functional.soft_margin_loss(out[:, :25], cm, reduction="none") < 0.03] = 0
+    ohem_mis = int((cm_d.cpu() != mined).sum())
+    assert np.array_equal(r["class_map_final"].numpy().astype(np.int8), g[f"{tag}_class_after_ohem_inplace"])
     gd = err(grad.cpu().numpy(), g[f"{tag}_grad"])
     report(f"criterion[{ci}]", cls=loss2[0], cls_ref=ref[1], reg=loss2[1], reg_ref=ref[2], label_mismatch=lab_mis,
            ohem_mismatch=ohem_mis, grad_maxabs=gd[0])

@@ -21,6 +21,7 @@
 //   * blockIdx is remapped so that each XCD (private L2) owns a contiguous range of tiles:
 //     the channel tiles that re-read one pixel tile stay on one L2.
 #include "common.h"
+#include "profile.h"
 
 namespace {
 
@@ -332,7 +333,16 @@ int launch_conv(const tf_conv_args* A, hipStream_t stream) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN>), dim3(mtiles * k.ntiles), dim3(256), lds, stream, k);
+  {
+    // algorithmic work of this launch: 2*M*Cout*K flops; each operand / result touched once
+    const double es = sizeof(T), M = k.M, Kt = k.Ktot;
+    const double in_px = (double)A->N * A->H * A->W;
+    double bytes = (in_px * A->Cin + (double)A->Cout * Kt + M * A->Cout) * es;
+    if (A->epi & (TF_EPI_RES | TF_EPI_MASK | TF_EPI_STATS2)) bytes += M * A->Cout * es;
+    if (A->epi & TF_EPI_JOIN) bytes += 2 * M * A->Cout * es;
+    tf::ProfScope prof((sizeof(T) == 2 ? 3 : 0) + (BM == 64 ? 2 : (BN == 64 ? 1 : 0)), 2.0 * M * A->Cout * Kt, bytes, stream);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN>), dim3(mtiles * k.ntiles), dim3(256), lds, stream, k);
+  }
   return hipGetLastError() == hipSuccess ? TF_OK : TF_ERR_LAUNCH;
 }
 

@@ -81,13 +81,14 @@ __global__ void __launch_bounds__(1024) nms_scan_kernel(const unsigned long long
       const int i = c * 64 + lane;
       unsigned long long diag = (i < n) ? mask[(size_t)i * nwords + c] : 0ull;
       unsigned long long rem = removed[c];
-      if (n - c * 64 < 64) rem |= ~0ull << (n - c * 64);   // boxes past n do not exist
+      const int nvalid = min(64, n - c * 64);                // boxes past n do not exist
       unsigned long long kb = 0;
       const unsigned int dlo = (unsigned int)diag, dhi = (unsigned int)(diag >> 32);
       for (int b = 0; b < 64; ++b) {
-        const unsigned long long d = ((unsigned long long)__builtin_amdgcn_readlane(dhi, b) << 32) |
-                                     (unsigned long long)__builtin_amdgcn_readlane(dlo, b);
-        if (!((rem >> b) & 1ull)) { kb |= 1ull << b; rem |= d; }
+        // readlane returns a SIGNED int: go through unsigned or the low word sign-extends into the high word
+        const unsigned long long d = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dhi, b) << 32) |
+                                     (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dlo, b);
+        if (b < nvalid && !((rem >> b) & 1ull)) { kb |= 1ull << b; rem |= d; }
       }
       if ((kb >> lane) & 1ull) keep[kcount + __popcll(kb & ((1ull << lane) - 1ull))] = (int64_t)order[i];
       kcount += __popcll(kb);

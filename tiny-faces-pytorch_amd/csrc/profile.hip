@@ -1,0 +1,63 @@
+// HIP-event bracketing of individual kernel launches on the stream they are launched on.
+// kinds: 0..5 = conv_igemm (dtype*3 + tile-1), 8..11 = wgrad (8 + dtype*2 + (BC==128)).
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+#include "profile.h"
+
+namespace {
+struct Rec { int kind; double flops, bytes; hipEvent_t a, b; };
+std::mutex g_mu;
+bool g_on = false;
+std::vector<Rec> g_recs;
+std::vector<hipEvent_t> g_pool;
+
+hipEvent_t get_event() {
+  if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+  hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
+}  // namespace
+
+tf::ProfScope::ProfScope(int kind, double flops, double bytes, hipStream_t s) : slot(-1), stream(s) {
+  if (!g_on) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  Rec r{kind, flops, bytes, get_event(), get_event()};
+  (void)hipEventRecord(r.a, s);
+  g_recs.push_back(r);
+  slot = (int)g_recs.size() - 1;
+}
+tf::ProfScope::~ProfScope() {
+  if (slot < 0) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  (void)hipEventRecord(g_recs[slot].b, stream);
+}
+
+extern "C" int tf_profile_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_on = on != 0;
+  return TF_OK;
+}
+
+// rows of 5 doubles: kind, launches, total_ms, total_flops, total_bytes.  Blocks until the recorded events completed.
+extern "C" int tf_profile_collect(double* host_out, int max_rows) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  double acc[16][4] = {};
+  for (const Rec& r : g_recs) {
+    (void)hipEventSynchronize(r.b);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess && r.kind >= 0 && r.kind < 16) {
+      acc[r.kind][0] += 1; acc[r.kind][1] += ms; acc[r.kind][2] += r.flops; acc[r.kind][3] += r.bytes;
+    }
+    g_pool.push_back(r.a); g_pool.push_back(r.b);
+  }
+  g_recs.clear();
+  int n = 0;
+  for (int k = 0; k < 16 && n < max_rows; ++k)
+    if (acc[k][0] > 0) {
+      host_out[n * 5 + 0] = k; host_out[n * 5 + 1] = acc[k][0]; host_out[n * 5 + 2] = acc[k][1];
+      host_out[n * 5 + 3] = acc[k][2]; host_out[n * 5 + 4] = acc[k][3];
+      ++n;
+    }
+  return n;
+}

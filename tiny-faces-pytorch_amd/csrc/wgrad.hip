@@ -14,6 +14,7 @@
 // Split-K partial tiles are combined with fp32 atomics straight into the OIHW gradient
 // (coalesced 64-byte runs along ci for 1x1 convs).
 #include "common.h"
+#include "profile.h"
 
 namespace {
 
@@ -206,6 +207,9 @@ int launch_wgrad(const tf_wgrad_args* A, hipStream_t stream) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, BC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
+  const double es = sizeof(T), Md = k.M;
+  tf::ProfScope prof(8 + (sizeof(T) == 2 ? 2 : 0) + (BC == 128 ? 1 : 0), 2.0 * Md * A->Cout * A->Cin * k.ntaps,
+                     (Md * A->Cout + (double)A->N * A->H * A->W * A->Cin) * es + (double)A->Cout * A->Cin * k.ntaps * 4, stream);
   hipLaunchKernelGGL((wgrad_kernel<T, BC>), dim3(tiles * k.splitk), dim3(256), lds, stream, k);
   return hipGetLastError() == hipSuccess ? TF_OK : TF_ERR_LAUNCH;
 }
