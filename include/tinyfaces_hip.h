@@ -171,8 +171,12 @@ typedef struct tf_wgrad_args {
   const float* pro_scale; const float* pro_shift;
   int dw_ld;          /* elements between consecutive co rows of dw (= Cin*KH*KW normally) */
   int splitk;         /* 0 = auto */
+  int tile;           /* 0 = auto; 64 or 128 = channels per tile side */
+  int packed;         /* 1: dw is [Cout][KH*KW][Cin] (coalesced atomics; tf_unpack_dw -> OIHW) */
 } tf_wgrad_args;
 int tf_conv2d_wgrad(const tf_wgrad_args* a, void* stream);
+/* [Cout][taps][Cin] fp32 -> OIHW fp32 (overwrites) */
+int tf_unpack_dw(const float* packed, int Cout, int Cin, int taps, float* dw_oihw, void* stream);
 
 
 /* ---- HBM-bound companions of the conv engine (NHWC, dtype TF_F32 | TF_BF16) ---------- */

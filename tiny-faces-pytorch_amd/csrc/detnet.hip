@@ -146,7 +146,7 @@ struct Plan {                    // everything a forward carves; backward re-der
   void *w_h3, *w_h4, *s3, *s4; float *hbias3, *hbias4, *ones, *wup_diag;
   float* partial; size_t partial_floats;
   // backward-only
-  void *g3, *g4, *G0, *G1, *T1, *T2, *T3, *T4, *R3, *wt;   // gradient buffers (roles in tf_detnet_backward) + transposed-weight scratch
+  void *g3, *g4, *G0, *G1, *T1, *T2, *T3, *T4, *R3, *wt; float* dwp;   // gradient buffers (roles in tf_detnet_backward) + transposed-weight scratch
   int H3, W3, H4, W4;
   size_t total;
 };
@@ -211,8 +211,9 @@ void build_plan(Plan& P, Arena& ar, int dtype, int N, int H, int W, int nout, in
     P.T3 = ar.get(max_act); P.T4 = ar.get(max_act); P.R3 = ar.get(max_act);
     if (packed_bytes(dtype, 1024, 1, kHeadLd) > max_wt) max_wt = packed_bytes(dtype, 1024, 1, kHeadLd);
     P.wt = ar.get(max_wt);
+    P.dwp = ar.f32((size_t)256 * 9 * 256);      // packed [Cout][tap][Cin] scratch of the 3x3 weight gradients
   } else {
-    P.g3 = P.g4 = P.G0 = P.G1 = P.T1 = P.T2 = P.T3 = P.T4 = P.R3 = P.wt = nullptr;
+    P.g3 = P.g4 = P.G0 = P.G1 = P.T1 = P.T2 = P.T3 = P.T4 = P.R3 = P.wt = nullptr; P.dwp = nullptr;
   }
   P.total = ar.off;
 }
@@ -403,7 +404,7 @@ void bn_backward_coefs(Ctx& c, const ConvUnit& u, int C, BnBuf& b, const float* 
 }
 
 void wgrad(Ctx& c, const ConvUnit& u, int cout, int N, int H, int W, int OH, int OW, const void* x, int ldx, const void* dy, int lddy,
-           const BnBuf* pro, int cin_override = 0, int k_override = 0, int dw_ld = 0) {
+           const BnBuf* pro, int cin_override = 0, int k_override = 0, int dw_ld = 0, float* packed_scratch = nullptr) {
   tf_wgrad_args w;
   memset(&w, 0, sizeof(w));
   const int cin = cin_override ? cin_override : u.cin, k = k_override ? k_override : u.k;
@@ -411,6 +412,14 @@ void wgrad(Ctx& c, const ConvUnit& u, int cout, int N, int H, int W, int OH, int
   w.stride = u.stride; w.pad = u.pad; w.ldx = ldx; w.lddy = lddy; w.x = x; w.dy = dy; w.dw_oihw = c.G(u.w);
   w.dw_ld = dw_ld ? dw_ld : cin * k * k;
   if (pro) { w.pro_scale = pro->scale; w.pro_shift = pro->shift; w.pro_relu = 1; }
+  if (k > 1 && packed_scratch) {          // 3x3: coalesced atomics into [Cout][tap][Cin], then one transposing copy to OIHW
+    float* oihw = w.dw_oihw;
+    w.dw_oihw = packed_scratch; w.packed = 1;
+    if (hipMemsetAsync(packed_scratch, 0, (size_t)cout * w.dw_ld * 4, c.stream) != hipSuccess) c.chk(TF_ERR_LAUNCH);
+    c.chk(tf_conv2d_wgrad(&w, c.stream));
+    c.chk(tf_unpack_dw(packed_scratch, cout, cin, k * k, oihw, c.stream));
+    return;
+  }
   if (hipMemsetAsync(w.dw_oihw, 0, (size_t)cout * w.dw_ld * 4, c.stream) != hipSuccess) c.chk(TF_ERR_LAUNCH);
   c.chk(tf_conv2d_wgrad(&w, c.stream));
 }
@@ -484,7 +493,7 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
     // (5) g_c2 in place
     c.chk(tf_bn_bwd_apply(dtype, P.T2, nullptr, b.c2, b.b2.cA, b.b2.cB, b.b2.cD, Mout, pl, P.T2, c.stream));
     // (6) wgrad conv2 (input relu(bn1(c1)))
-    wgrad(c, B.c2, pl, N, b.Hin, b.Win, b.Hout, b.Wout, b.c1, pl, P.T2, pl, &b.b1);
+    wgrad(c, B.c2, pl, N, b.Hin, b.Win, b.Hout, b.Wout, b.c1, pl, P.T2, pl, &b.b1, 0, 0, 0, P.dwp);
     // (7) dgrad conv2 -> gz1 in T1 (+ sums); output spatial = conv2's input
     pack(c, B.c2, pl, P.wt, true);
     conv_fill(a, dtype, 1, N, b.Hout, b.Wout, pl, b.Hin, b.Win, pl, 3, B.stride, 1, pl, P.T2, P.wt, P.T1);

@@ -201,15 +201,47 @@ __global__ void __launch_bounds__(256) colstats_kernel(const T* __restrict__ g, 
 }
 
 // ---------------------------------------------------------------- BN finalize (forward, batch statistics)
+// Partials come as [nblk][nk][ld] rows (conv epilogue tiles or colstats blocks).  A block owns 32 channels and
+// sums the nblk rows with 32 row-lanes per channel (coalesced 128-byte reads), then 32 threads finalize.
+constexpr int kFinCh = 32, kFinLanes = 32;
+template <int NK>
+__device__ __forceinline__ void reduce_partial_rows(const float* __restrict__ partial, int nblk, int nk, const int* kidx, int ld, int C,
+                                                    double (*out)[kFinCh]) {
+  __shared__ double red[NK][kFinLanes][kFinCh];
+  const int tc = threadIdx.x % kFinCh, tr = threadIdx.x / kFinCh;
+  const int c = blockIdx.x * kFinCh + tc;
+  double acc[NK];
+#pragma unroll
+  for (int k = 0; k < NK; ++k) acc[k] = 0.0;
+  if (c < C) {
+    for (int b = tr; b < nblk; b += kFinLanes) {
+#pragma unroll
+      for (int k = 0; k < NK; ++k) acc[k] += (double)partial[((size_t)b * nk + kidx[k]) * ld + c];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NK; ++k) red[k][tr][tc] = acc[k];
+  __syncthreads();
+  if (tr < NK) {                      // lane tr finalizes statistic tr for channel tc
+    double t = 0.0;
+    for (int r = 0; r < kFinLanes; ++r) t += red[tr][r][tc];
+    out[tr][tc] = t;
+  }
+  __syncthreads();
+}
+
 // partial[blk][2][ld] (sum, sumsq) -> scale/shift for y = x*scale+shift, saved mean/invstd, running stats
-__global__ void bn_finalize_kernel(const float* __restrict__ partial, int nblk, int ld, int C, float count, const float* __restrict__ gamma,
-                                   const float* __restrict__ beta, float eps, float momentum, float* __restrict__ scale,
-                                   float* __restrict__ shift, float* __restrict__ mean_out, float* __restrict__ invstd_out,
-                                   float* __restrict__ running_mean, float* __restrict__ running_var) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, q = 0.0;
-  for (int b = 0; b < nblk; ++b) { s += partial[((size_t)b * 2) * ld + c]; q += partial[((size_t)b * 2 + 1) * ld + c]; }
+__global__ void __launch_bounds__(kFinCh* kFinLanes) bn_finalize_kernel(const float* __restrict__ partial, int nblk, int ld, int C, float count,
+                                                                        const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                                        float momentum, float* __restrict__ scale, float* __restrict__ shift,
+                                                                        float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                                                        float* __restrict__ running_mean, float* __restrict__ running_var) {
+  __shared__ double sums[2][kFinCh];
+  const int kidx[2] = {0, 1};
+  reduce_partial_rows<2>(partial, nblk, 2, kidx, ld, C, sums);
+  const int c = blockIdx.x * kFinCh + threadIdx.x;
+  if (threadIdx.x >= kFinCh || c >= C) return;
+  const double s = sums[0][threadIdx.x], q = sums[1][threadIdx.x];
   const double mean = s / count;
   double var = q / count - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -235,14 +267,17 @@ __global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __r
 
 // BN backward finalize: partial[blk][nk][ld] with k0 = sum gz, kidx = sum gz*x  ->
 //   dgamma, dbeta and the affine form  g_x = A*gz + B*x + D
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int nk, int kidx, int ld, int C, float count,
-                                       const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ cA, float* __restrict__ cB,
-                                       float* __restrict__ cD) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int b = 0; b < nblk; ++b) { s1 += partial[((size_t)b * nk) * ld + c]; s2 += partial[((size_t)b * nk + kidx) * ld + c]; }
+__global__ void __launch_bounds__(kFinCh* kFinLanes) bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int nk, int kidx_, int ld, int C,
+                                                                            float count, const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                                            const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                                                            float* __restrict__ dbeta, float* __restrict__ cA, float* __restrict__ cB,
+                                                                            float* __restrict__ cD) {
+  __shared__ double sums[2][kFinCh];
+  const int kidx[2] = {0, kidx_};
+  reduce_partial_rows<2>(partial, nblk, nk, kidx, ld, C, sums);
+  const int c = blockIdx.x * kFinCh + threadIdx.x;
+  if (threadIdx.x >= kFinCh || c >= C) return;
+  const double s1 = sums[0][threadIdx.x], s2 = sums[1][threadIdx.x];
   const double mu = mean[c], is = invstd[c], ga = gamma[c];
   const double dg = (s2 - mu * s1) * is;         // sum gz * xhat
   dgamma[c] = (float)dg; dbeta[c] = (float)s1;
@@ -388,12 +423,13 @@ __global__ void __launch_bounds__(256) upsample_add_bwd_kernel(const float* __re
 }
 
 // sum over blocks of partial[blk][nk][ld] row k -> out[c]  (bias gradients)
-__global__ void reduce_partials_kernel(const float* __restrict__ partial, int nblk, int nk, int k, int ld, int C, float* __restrict__ out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += partial[((size_t)b * nk + k) * ld + c];
-  out[c] = (float)s;
+__global__ void __launch_bounds__(kFinCh* kFinLanes) reduce_partials_kernel(const float* __restrict__ partial, int nblk, int nk, int k, int ld, int C,
+                                                                            float* __restrict__ out) {
+  __shared__ double sums[1][kFinCh];
+  const int kidx[1] = {k};
+  reduce_partial_rows<1>(partial, nblk, nk, kidx, ld, C, sums);
+  const int c = blockIdx.x * kFinCh + threadIdx.x;
+  if (threadIdx.x < kFinCh && c < C) out[c] = (float)sums[0][threadIdx.x];
 }
 
 inline unsigned grid_for(size_t total) {
@@ -481,7 +517,7 @@ extern "C" int tf_bn_finalize(const float* partial, int nblk, int ld, int C, flo
                               float momentum, float* scale, float* shift, float* mean, float* invstd, float* running_mean,
                               float* running_var, void* stream) {
   if (!partial || !gamma || !beta || !scale || !shift || !mean || !invstd) return TF_ERR_ARG;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, partial, nblk, ld, C, count, gamma, beta, eps,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinCh * kFinLanes), 0, (hipStream_t)stream, partial, nblk, ld, C, count, gamma, beta, eps,
                      momentum, scale, shift, mean, invstd, running_mean, running_var);
   TF_CHECK_LAUNCH();
   return TF_OK;
@@ -498,7 +534,7 @@ extern "C" int tf_bn_fold(const float* gamma, const float* beta, const float* ru
 extern "C" int tf_bn_bwd_finalize(const float* partial, int nblk, int nk, int kidx, int ld, int C, float count, const float* gamma,
                                   const float* mean, const float* invstd, float* dgamma, float* dbeta, float* cA, float* cB, float* cD,
                                   void* stream) {
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, partial, nblk, nk, kidx, ld, C, count,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinCh * kFinLanes), 0, (hipStream_t)stream, partial, nblk, nk, kidx, ld, C, count,
                      gamma, mean, invstd, dgamma, dbeta, cA, cB, cD);
   TF_CHECK_LAUNCH();
   return TF_OK;
@@ -546,7 +582,7 @@ extern "C" int tf_upsample_add_crop_bwd(int dtype, const float* g_nchw, const fl
 }
 
 extern "C" int tf_reduce_partials(const float* partial, int nblk, int nk, int k, int ld, int C, float* out, void* stream) {
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, partial, nblk, nk, k, ld, C, out);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinCh * kFinLanes), 0, (hipStream_t)stream, partial, nblk, nk, k, ld, C, out);
   TF_CHECK_LAUNCH();
   return TF_OK;
 }

@@ -26,7 +26,7 @@ struct WgK {
   const char* x; const char* dy; float* dw;
   const float* pro_scale; const float* pro_shift;
   int H, W, Cin, OH, OW, Cout, KH, KW, stride, pad;
-  int M, OHW, ldx, lddy, dw_ld, pro_relu;
+  int M, OHW, ldx, lddy, dw_ld, pro_relu, ci_stride, tap_stride;
   int nco, nci, ntaps, splitk, chunk;
 };
 
@@ -167,7 +167,6 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgK a) {
   }
   if (nst == 0) return;
   // D[co][ci]: lane holds co = (l>>4)*4 + r, ci = l&15
-  const int khw = a.KH * a.KW;
 #pragma unroll
   for (int n = 0; n < NF; ++n)
 #pragma unroll
@@ -176,7 +175,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgK a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int co = co0 + wco * WC + n * 16 + lg * 4 + r;
-        if (co < a.Cout && ci < a.Cin) atomicAdd(a.dw + (size_t)co * a.dw_ld + (size_t)ci * khw + tap, acc[n][m][r]);
+        if (co < a.Cout && ci < a.Cin) atomicAdd(a.dw + (size_t)co * a.dw_ld + (size_t)ci * a.ci_stride + (size_t)tap * a.tap_stride, acc[n][m][r]);
       }
     }
 }
@@ -189,11 +188,12 @@ int launch_wgrad(const tf_wgrad_args* A, hipStream_t stream) {
   k.H = A->H; k.W = A->W; k.Cin = A->Cin; k.OH = A->OH; k.OW = A->OW; k.Cout = A->Cout; k.KH = A->KH; k.KW = A->KW;
   k.stride = A->stride; k.pad = A->pad; k.M = A->N * A->OH * A->OW; k.OHW = A->OH * A->OW;
   k.ldx = A->ldx; k.lddy = A->lddy; k.dw_ld = A->dw_ld; k.pro_relu = A->pro_relu;
+  if (A->packed) { k.ci_stride = 1; k.tap_stride = A->Cin; } else { k.ci_stride = A->KH * A->KW; k.tap_stride = 1; }
   k.nco = (A->Cout + BC - 1) / BC; k.nci = (A->Cin + BC - 1) / BC; k.ntaps = A->KH * A->KW;
   const int tiles = k.nco * k.nci * k.ntaps;
   int sk = A->splitk;
   if (sk <= 0) {
-    sk = (768 + tiles - 1) / tiles;
+    sk = (640 + tiles - 1) / tiles;                         // ~640 blocks measured best on the layer shapes (scripts/microbench.py)
     const int maxsk = (k.M + 4 * PK - 1) / (4 * PK);        // at least 4 stages per block
     if (sk > maxsk) sk = maxsk;
     if (sk < 1) sk = 1;
@@ -223,7 +223,27 @@ extern "C" int tf_conv2d_wgrad(const tf_wgrad_args* a, void* stream_) {
   const int eps = a->dtype == TF_BF16 ? 8 : 4;
   if (a->ldx % eps || a->lddy % eps || a->ldx < a->Cin || a->lddy < a->Cout) return TF_ERR_ARG;   // 16-byte slots
   if (a->pro_scale && (!a->pro_shift || a->Cin % eps)) return TF_ERR_ARG;
-  const bool small = a->Cout <= 64 || a->Cin <= 64;
+  const bool small = a->tile ? a->tile == 64 : true;   // 64x64 tiles: 4x fewer split-K partials per MFMA flop than 128x128
   if (a->dtype == TF_BF16) return small ? launch_wgrad<tf::bf16_t, 64>(a, stream) : launch_wgrad<tf::bf16_t, 128>(a, stream);
   return small ? launch_wgrad<float, 64>(a, stream) : launch_wgrad<float, 128>(a, stream);
+}
+
+namespace {
+__global__ void unpack_dw_kernel(const float* __restrict__ p, int Cout, int Cin, int taps, float* __restrict__ out) {
+  const size_t total = (size_t)Cout * Cin * taps;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int tap = (int)(i % taps);
+    const int ci = (int)((i / taps) % Cin);
+    const int co = (int)(i / ((size_t)taps * Cin));
+    out[i] = p[((size_t)co * taps + tap) * Cin + ci];
+  }
+}
+}  // namespace
+extern "C" int tf_unpack_dw(const float* packed, int Cout, int Cin, int taps, float* dw_oihw, void* stream) {
+  if (!packed || !dw_oihw) return TF_ERR_ARG;
+  const size_t total = (size_t)Cout * Cin * taps;
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(unpack_dw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, packed, Cout, Cin, taps, dw_oihw);
+  return hipGetLastError() == hipSuccess ? TF_OK : TF_ERR_LAUNCH;
 }

@@ -40,7 +40,7 @@ class WgradArgs(C.Structure):
                 ("KH", i32), ("KW", i32), ("stride", i32), ("pad", i32),
                 ("ldx", i32), ("lddy", i32), ("pro_relu", i32),
                 ("x", vp), ("dy", vp), ("dw_oihw", vp), ("pro_scale", vp), ("pro_shift", vp),
-                ("dw_ld", i32), ("splitk", i32)]
+                ("dw_ld", i32), ("splitk", i32), ("tile", i32), ("packed", i32)]
 
 
 _SIGNATURES = {
@@ -62,6 +62,7 @@ _SIGNATURES = {
     "tf_conv2d": (i32, [C.POINTER(ConvArgs), vp]),
     "tf_pack_weight": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp]),
     "tf_conv2d_wgrad": (i32, [C.POINTER(WgradArgs), vp]),
+    "tf_unpack_dw": (i32, [vp, i32, i32, i32, vp, vp]),
     "tf_stem_im2col": (i32, [vp, i32, i32, i32, i32, vp, i32, vp]),
     "tf_maxpool_fwd": (i32, [i32, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
     "tf_maxpool_bwd": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),

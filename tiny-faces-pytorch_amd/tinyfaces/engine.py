@@ -1,0 +1,63 @@
+"""Fused training engine: one reference training step (tinyfaces/trainer.py:72-87) with no autograd graph,
+no per-parameter Python loop and no host sync:
+
+    targets (HIP) -> forward (HIP executor) -> criterion fwd+bwd (HIP) -> backward (HIP executor)
+    -> [RCCL all-reduce of the flat gradient] -> fused SGD (one launch per parameter group)
+
+Semantics are those of main.py:67-70 (SGD momentum 0.9, weight decay 5e-4, the 4 learning-rate groups of
+model.py:67-87) and of DetectionCriterion (loss.py).  `trainer.train` (autograd + torch.optim) remains the
+drop-in path; this engine is what bench.py and the bundled main.py use."""
+import torch
+import torch.distributed as dist
+
+from . import ops, parallel
+
+
+class TrainEngine:
+    def __init__(self, model, criterion, lr=1e-4, momentum=0.9, weight_decay=5e-4, device="cuda", bucket_mb=32):
+        self.device = torch.device(device)
+        self.model = model.to(self.device).train()
+        self.criterion = criterion
+        if parallel.is_distributed():
+            parallel.broadcast_module(self.model)
+        self.flat_p = self.model.flatten_parameters()
+        self.flat_m = torch.zeros_like(self.flat_p)
+        self.groups = self.model.group_ranges()
+        self.lr, self.momentum, self.weight_decay = lr, momentum, weight_decay
+        self.bucket_elems = int(bucket_mb * (1 << 20) // 4)
+        self.steps = 0
+
+    def set_lr(self, lr):
+        self.lr = lr
+
+    def _allreduce(self, gflat):
+        """Few large buckets, launched in reverse-execution order (heads / layer3 first), async on RCCL's stream."""
+        works, end = [], gflat.numel()
+        while end > 0:
+            start = max(0, end - self.bucket_elems)
+            works.append(dist.all_reduce(gflat[start:end], op=dist.ReduceOp.SUM, async_op=True))
+            end = start
+        for w in works:
+            w.wait()
+
+    def step(self, x, class_map, regression_map):
+        """x (B,3,H,W) f32, class_map (B,nt,h,w) f32 (mined in place), regression_map (B,4nt,h,w) f32: all on the device.
+        Returns the device tensor [sum cls loss, sum reg loss] (float64) without synchronising."""
+        m, c = self.model, self.criterion
+        m._sync_tables(x.device)
+        out = m._run_forward(x, training=True)
+        loss2, grad, _ = ops.criterion_fwd_bwd(out, class_map, regression_map, c.n_templates, c.reg_weight, c.ohem_thresh, c.max_pos,
+                                               c.max_neg, c._pos_keep, c._neg_keep, c._next_seed())
+        gflat = m._run_backward(x, grad, persistent=True)
+        scale = 1.0
+        if parallel.is_distributed():
+            self._allreduce(gflat)
+            scale = 1.0 / parallel.world_size()          # average over ranks, folded into the SGD kernel
+        for s, e, mult in self.groups:
+            if mult == 0.0:
+                continue                                  # score4_upsample: lr 0 (model.py:84) -> nothing to do
+            ops.sgd_step(self.flat_p[s:e], gflat[s:e], self.flat_m[s:e], self.lr * mult, self.momentum, self.weight_decay, scale)
+        self.steps += 1
+        if hasattr(c, "_pending"):
+            c._pending.append((loss2, x.shape[0]))
+        return loss2

@@ -193,6 +193,44 @@ class DetectionModel(nn.Module):
         self._bn_modules = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
         self._table_key = key
 
+    def flatten_parameters(self):
+        """Re-point every parameter the executor trains into ONE flat fp32 buffer (executor order, each
+        segment 16-byte aligned) and all BatchNorm counters into one int64 buffer.  The nn.Parameter objects
+        keep their identity (optimizers stay valid); afterwards a whole parameter group is one contiguous
+        range, so the fused SGD step and the RCCL all-reduce work on a handful of large segments."""
+        dev = next(self.parameters()).device
+        self._sync_tables(dev)
+        pd = dict(self.named_parameters())
+        total = sum((n + 3) // 4 * 4 for n in self._grad_numels)
+        flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self._segments, o = {}, 0
+        for k, n in zip(self._grad_names, self._grad_numels):
+            p = pd[k]
+            flat[o:o + n].copy_(p.data.reshape(-1))
+            p.data = flat[o:o + n].view_as(p)
+            self._segments[k] = (o, n)
+            o += (n + 3) // 4 * 4
+        self._flat_params = flat
+        nbt = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
+        cnt = torch.zeros(len(nbt), dtype=torch.int64, device=dev)
+        for i, m in enumerate(nbt):
+            cnt[i] = m.num_batches_tracked
+            m.num_batches_tracked = cnt[i]
+            m._buffers["num_batches_tracked"] = cnt[i:i + 1].view(())
+        self._flat_nbt = cnt
+        self._grad_flat_persistent = torch.zeros(total, dtype=torch.float32, device=dev)
+        self._table_key = None
+        self._sync_tables(dev)
+        return flat
+
+    def group_ranges(self):
+        """[(start, end, lr_multiplier)] of the 4 reference parameter groups (model.py:67-87) inside the flat buffer."""
+        seg = self._segments
+        def span(prefix):
+            ks = [k for k in self._grad_names if k.startswith(prefix)]
+            return seg[ks[0]][0], seg[ks[-1]][0] + (seg[ks[-1]][1] + 3) // 4 * 4
+        return [span("model.") + (1.0,), span("score_res3.") + (0.1,), span("score_res4.") + (1.0,), span("score4_upsample.") + (0.0,)]
+
     def _workspace(self, device, nbytes):
         if self._ws is None or self._ws.device != device or self._ws.numel() < nbytes:
             self._ws = None
@@ -214,25 +252,46 @@ class DetectionModel(nn.Module):
                                           float(bn.eps), float(bn.momentum), ptr(out), ptr(ws), ws.numel(), stream()),
                   "tf_detnet_forward")
         if training:
-            for m in self._bn_modules:                                   # BatchNorm2d bookkeeping
-                if m.num_batches_tracked is not None:
-                    m.num_batches_tracked += 1
+            if getattr(self, "_flat_nbt", None) is not None:
+                self._flat_nbt += 1                                      # all 94 counters in one launch
+            else:
+                for m in self._bn_modules:                               # BatchNorm2d bookkeeping
+                    if m.num_batches_tracked is not None:
+                        m.num_batches_tracked += 1
         return out
 
-    def _run_backward(self, x, gout):
+    def _run_backward(self, x, gout, persistent=False):
+        """persistent=False (autograd path): a fresh flat gradient buffer per call, returned as per-parameter views.
+        persistent=True (fused trainer): gradients land in self._grad_flat_persistent (same layout as the flat
+        parameter buffer); returns that buffer."""
         N, _, H, W = x.shape
         assert (N, H, W) == self._ws_shape
         total = sum((n + 3) // 4 * 4 for n in self._grad_numels)       # every segment 16-byte aligned
-        gflat = torch.empty(total, dtype=torch.float32, device=x.device)
-        views, ptrs, o = {}, {}, 0
-        for k, n in zip(self._grad_names, self._grad_numels):
-            views[k] = gflat[o:o + n]
-            ptrs[k] = gflat.data_ptr() + 4 * o
-            o += (n + 3) // 4 * 4
-        table = (C.c_void_p * len(self._names))(*[ptrs.get(k, 0) for k in self._names])
+        if persistent:
+            gflat = self._grad_flat_persistent
+            cache = getattr(self, "_persist_table", None)
+        else:
+            gflat = torch.zeros(total, dtype=torch.float32, device=x.device)
+            cache = None
+        if cache is None or cache[0] != gflat.data_ptr():
+            ptrs, o = {}, 0
+            for k, n in zip(self._grad_names, self._grad_numels):
+                ptrs[k] = gflat.data_ptr() + 4 * o
+                o += (n + 3) // 4 * 4
+            table = (C.c_void_p * len(self._names))(*[ptrs.get(k, 0) for k in self._names])
+            if persistent:
+                self._persist_table = (gflat.data_ptr(), table)
+        else:
+            table = cache[1]
         with torch.cuda.device(x.device):
             check(lib().tf_detnet_backward(self.compute_dtype, ptr(x), N, H, W, self.num_out, self._param_ptrs, table, ptr(gout),
                                            ptr(self._ws), self._ws.numel(), stream()), "tf_detnet_backward")
         self._last_grad_flat = gflat
+        if persistent:
+            return gflat
         pd = dict(self.named_parameters())
-        return [views[k].view_as(pd[k]) for k in self._grad_names]
+        views, o = [], 0
+        for k, n in zip(self._grad_names, self._grad_numels):
+            views.append(gflat[o:o + n].view_as(pd[k]))
+            o += (n + 3) // 4 * 4
+        return views

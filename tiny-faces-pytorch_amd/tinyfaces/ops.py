@@ -81,6 +81,28 @@ def dense_overlap_targets(boxes_per_image, templates, heatmap_size=(63, 63), rf=
     return cls, reg
 
 
+def dense_overlap_targets_device(boxes_d, offs_d, total_boxes, templates_d, heatmap_size=(63, 63), rf=RF, paste_d=None, flips_d=None,
+                                 seed=0, pos_thresh=0.7, neg_thresh=0.3, out=None):
+    """Same kernel as dense_overlap_targets with every operand already resident in HBM:
+    boxes_d (total,4) f64 (degenerate boxes removed), offs_d (B+1,) i32, templates_d (nt,5) f64, paste_d (B,4) i32."""
+    require_gpu(boxes_d, "dense_overlap_targets_device")
+    B = offs_d.numel() - 1
+    vsy, vsx = heatmap_size
+    nt, tstride = templates_d.shape
+    dev = boxes_d.device
+    if out is None:
+        out = (torch.empty(B, nt, vsy, vsx, dtype=torch.float32, device=dev), torch.empty(B, 4 * nt, vsy, vsx, dtype=torch.float32, device=dev))
+    cls, reg = out
+    wsb = lib().tf_targets_workspace_bytes(total_boxes)
+    ws = _workspace("targets", wsb, dev)
+    ofy, ofx = rf["offset"]
+    sty, stx = rf["stride"]
+    check(lib().tf_dense_overlap_targets(ptr(boxes_d), ptr(offs_d), B, ptr(templates_d), nt, tstride, vsy, vsx, ofy, ofx, sty, stx,
+                                         ptr(paste_d), ptr(flips_d), None, None, int(seed) & (2**64 - 1), float(pos_thresh),
+                                         float(neg_thresh), ptr(cls), ptr(reg), ptr(ws), wsb, stream()), "tf_dense_overlap_targets")
+    return cls, reg
+
+
 def dense_overlap_iou(boxes, templates, heatmap_size=(63, 63), rf=RF, device="cuda"):
     """Raw rounded IoU tensor (vsy,vsx,nt,G) f64 of compute_dense_overlap (dense_overlap.py:4-75); test hook."""
     vsy, vsx = heatmap_size
@@ -243,13 +265,15 @@ def conv2d_nhwc(x, w_packed, Cout, KH, KW, stride, pad, mode=0, out_hw=None, ldy
     return (y, stats) if want_stats else y
 
 
-def conv2d_wgrad(x, dy, Cin, Cout, KH, KW, stride, pad, pro=None, splitk=0):
+def conv2d_wgrad(x, dy, Cin, Cout, KH, KW, stride, pad, pro=None, splitk=0, tile=0, out=None, packed=False):
     """x (N,H,W,ldx), dy (N,OH,OW,lddy) -> dW (Cout,Cin,KH,KW) fp32."""
     require_gpu(x, "conv2d_wgrad")
     N, H, W, ldx = x.shape
     _, OH, OW, lddy = dy.shape
-    dw = torch.zeros(Cout, Cin, KH, KW, dtype=torch.float32, device=x.device)
+    dw = torch.zeros(Cout, Cin, KH, KW, dtype=torch.float32, device=x.device) if out is None else out
     a = _hip.WgradArgs()
+    a.tile = tile
+    a.packed = int(packed)
     a.dtype = _hip.tf_dtype(x.dtype)
     a.N, a.H, a.W, a.Cin, a.OH, a.OW, a.Cout, a.KH, a.KW, a.stride, a.pad = N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad
     a.ldx, a.lddy, a.x, a.dy, a.dw_oihw, a.dw_ld, a.splitk = ldx, lddy, ptr(x), ptr(dy), ptr(dw), Cin * KH * KW, splitk
