@@ -208,6 +208,8 @@ int tf_bn_bwd_finalize(const float* partial, int nblk, int nk, int kidx, int ld,
                        float* cD, void* stream);
 int tf_bn_bwd_apply(int dtype, const void* g, const void* y, const void* x, const float* cA, const float* cB,
                     const float* cD, int64_t M, int C, void* out, void* stream);
+/* y = relu(x*scale + shift): BN + ReLU materialised for the 3x3 conv's LDS-DMA operand pipeline */
+int tf_bn_relu(int dtype, const void* x, const float* scale, const float* shift, int64_t M, int C, void* y, void* stream);
 /* Bottleneck output in training mode: y = relu(x*s1+h1 + (r*s2+h2 | r)) */
 int tf_bn_add_relu(int dtype, const void* x, const float* s1, const float* h1, const void* r, const float* s2,
                    const float* h2, int64_t M, int C, void* y, void* stream);

@@ -34,7 +34,7 @@ CONV_CASES = [
 
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("case", CONV_CASES)
-@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 11, 12, 13, 22, 23])
 def test_conv_forward_plain(dtype, case, tile):
     from tinyfaces import ops
     N, H, W, Cin, Cout, K, s, p = case
@@ -49,7 +49,8 @@ def test_conv_forward_plain(dtype, case, tile):
 
 
 @pytest.mark.parametrize("dtype", DT)
-def test_conv_forward_fused_eval_epilogue(dtype):
+@pytest.mark.parametrize("tile", [2, 0, 13])
+def test_conv_forward_fused_eval_epilogue(dtype, tile):
     """AFFINE (folded BN) + residual + ReLU, Cout=125 padded to 128 (the head shape)."""
     from tinyfaces import _hip, ops
     g = _g(3)
@@ -60,7 +61,7 @@ def test_conv_forward_fused_eval_epilogue(dtype):
     res = torch.randn(N, 128, H, W, generator=g)
     ref = torch.relu(F.conv2d(q(x, dtype), q(w, dtype)) * sc[:Cout].view(1, -1, 1, 1) + sh[:Cout].view(1, -1, 1, 1) + q(res, dtype)[:, :Cout])
     y = ops.conv2d_nhwc(to_nhwc(x, dtype), ops.pack_weight(w.cuda(), dtype), Cout, 1, 1, 1, 0, ldy=128,
-                        epi=_hip.EPI_AFFINE | _hip.EPI_RES | _hip.EPI_RELU, epi_scale=sc.cuda(), epi_shift=sh.cuda(), aux=to_nhwc(res, dtype))
+                        epi=_hip.EPI_AFFINE | _hip.EPI_RES | _hip.EPI_RELU, epi_scale=sc.cuda(), epi_shift=sh.cuda(), aux=to_nhwc(res, dtype), tile=tile)
     d = err(from_nhwc(y)[:, :Cout], ref)
     report(f"conv_epilogue_eval[{dtype}]", maxabs=d[0], rel=d[2])
     assert d[2] < TOL[dtype]
@@ -91,8 +92,29 @@ def test_conv_forward_prologue_and_stats(dtype, K, s):
 
 
 @pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("tile", [0, 11, 12, 13])
+def test_conv_forward_stats_no_prologue(dtype, tile):
+    """raw output + (sum, sumsq) partials without a prologue -> the LDS-DMA kernel's column-sum epilogue."""
+    from tinyfaces import _hip, ops
+    g = _g(41)
+    N, H, W, Cin, Cout = 2, 19, 23, 256, 128
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    ref = F.conv2d(q(x, dtype), q(w, dtype), padding=1)
+    y, st = ops.conv2d_nhwc(to_nhwc(x, dtype), ops.pack_weight(w.cuda(), dtype), Cout, 3, 3, 1, 1, epi=_hip.EPI_STATS, want_stats=True, tile=tile)
+    d = err(from_nhwc(y), ref)
+    ssum = st.sum(0).cpu()
+    n = ref.numel() / Cout
+    d1 = err(ssum[0] / n, ref.mean(dim=(0, 2, 3)))
+    d2 = err(ssum[1] / n, (ref ** 2).mean(dim=(0, 2, 3)))
+    report(f"conv_stats_dma[{dtype},t{tile}]", rel=d[2], mean_abs=d1[0], sq_rel=d2[2])
+    assert d[2] < TOL[dtype] and d1[0] < 2e-3 and d2[2] < 2e-3
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("tile", [0, 2, 13])
 @pytest.mark.parametrize("K,s,H", [(1, 1, 14), (3, 1, 14), (3, 2, 14), (3, 2, 15), (1, 2, 15)])
-def test_conv_dgrad_mode(dtype, K, s, H):
+def test_conv_dgrad_mode(dtype, K, s, H, tile):
     """mode 1 == data gradient of conv(stride, pad): compared with torch autograd."""
     from tinyfaces import ops
     g = _g(20 + K + s + H)
@@ -104,14 +126,15 @@ def test_conv_dgrad_mode(dtype, K, s, H):
     gy = torch.randn(yref.shape, generator=g)
     yref.backward(q(gy, dtype))
     wt = ops.pack_weight(w.cuda(), dtype, transpose=True)
-    gx = ops.conv2d_nhwc(to_nhwc(gy, dtype), wt, Cin, K, K, s, p, mode=1, out_hw=(H, W))
+    gx = ops.conv2d_nhwc(to_nhwc(gy, dtype), wt, Cin, K, K, s, p, mode=1, out_hw=(H, W), tile=tile)
     d = err(from_nhwc(gx), x.grad)
     report(f"conv_dgrad[{dtype},k{K}s{s}h{H}]", maxabs=d[0], rel=d[2])
     assert d[2] < TOL[dtype]
 
 
 @pytest.mark.parametrize("dtype", DT)
-def test_conv_dgrad_mask_stats2_and_join(dtype):
+@pytest.mark.parametrize("tile", [2, 0, 11])
+def test_conv_dgrad_mask_stats2_and_join(dtype, tile):
     from tinyfaces import _hip, ops
     g = _g(33)
     N, H, W, C1, C2 = 2, 16, 18, 256, 64          # dgrad of a 1x1 conv C2 -> C1 : input grad has C2 channels
@@ -123,7 +146,7 @@ def test_conv_dgrad_mask_stats2_and_join(dtype):
     mask = (q(craw, dtype) * ms.view(1, -1, 1, 1) + mh.view(1, -1, 1, 1)) > 0
     ref = base * mask
     y, st = ops.conv2d_nhwc(to_nhwc(gy, dtype), ops.pack_weight(w.cuda(), dtype, transpose=True), C2, 1, 1, 1, 0, mode=1, out_hw=(H, W),
-                            epi=_hip.EPI_MASK | _hip.EPI_STATS2, aux=to_nhwc(craw, dtype), mask=(ms.cuda(), mh.cuda()), want_stats=True)
+                            epi=_hip.EPI_MASK | _hip.EPI_STATS2, aux=to_nhwc(craw, dtype), mask=(ms.cuda(), mh.cuda()), want_stats=True, tile=tile)
     d = err(from_nhwc(y), ref)
     s = st.sum(0).cpu()
     d1 = err(s[0], ref.sum(dim=(0, 2, 3)))
@@ -133,7 +156,7 @@ def test_conv_dgrad_mask_stats2_and_join(dtype):
     g3 = torch.randn(N, C2, H, W, generator=g)
     refj = base + q(g3, dtype) * (q(y2, dtype) > 0)
     yj = ops.conv2d_nhwc(to_nhwc(gy, dtype), ops.pack_weight(w.cuda(), dtype, transpose=True), C2, 1, 1, 1, 0, mode=1, out_hw=(H, W),
-                         epi=_hip.EPI_JOIN, aux2=to_nhwc(y2, dtype), aux3=to_nhwc(g3, dtype))
+                         epi=_hip.EPI_JOIN, aux2=to_nhwc(y2, dtype), aux3=to_nhwc(g3, dtype), tile=tile)
     dj = err(from_nhwc(yj), refj)
     report(f"conv_dgrad_mask_join[{dtype}]", rel=d[2], s1=d1[2], s2=d2[2], join_rel=dj[2])
     assert d[2] < TOL[dtype] and dj[2] < TOL[dtype] and d1[2] < 5e-3 and d2[2] < 5e-3

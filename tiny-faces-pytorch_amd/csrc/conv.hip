@@ -23,6 +23,8 @@
 #include "common.h"
 #include "profile.h"
 
+int tf_conv_dma_launch(const tf_conv_args* a, int tile, int depth, hipStream_t stream);   // conv_dma.hip
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -346,15 +348,18 @@ int launch_conv(const tf_conv_args* A, hipStream_t stream) {
   return hipGetLastError() == hipSuccess ? TF_OK : TF_ERR_LAUNCH;
 }
 
+// tile codes: 1/2/3 = register-staged 128x128 / 128x64 / 64x64 (pixels x channels); 11/12/13 = LDS-DMA pipeline with a
+// 3-deep ring, 21/22/23 = 4-deep ring.  0 = auto.
 int pick_tile(const tf_conv_args* a) {
   if (a->tile) return a->tile;
   // measured on the bs=12 500x500 layer shapes (scripts/microbench.py): 128 pixels x 64 channels wins on every
   // layer (more, smaller tiles -> more blocks in flight per CU); 64x64 only when even that leaves CUs idle.
   const long M = (long)a->N * a->OH * a->OW;
   const long t2 = ((M + 127) / 128) * ((a->Cout + 63) / 64);
-  return t2 >= 256 ? 2 : 3;
+  if (!a->pro_scale) return 13;                   // LDS-DMA pipeline, 64x64 tiles, 3-deep ring: fastest on every layer shape
+  return t2 >= 256 ? 2 : 3;                       // producer-BN prologue needs the register-staged kernel
 }
-int tile_bm(int t) { return t == 3 ? 64 : 128; }
+int tile_bm(int t) { return (t % 10) == 3 ? 64 : 128; }
 
 }  // namespace
 
@@ -379,6 +384,10 @@ extern "C" int tf_conv2d(const tf_conv_args* a, void* stream_) {
   if ((a->epi & TF_EPI_MASK) && (!a->mask_scale || !a->mask_shift)) return TF_ERR_ARG;
   if (a->pro_scale && !a->pro_shift) return TF_ERR_ARG;
   const int t = pick_tile(a);
+  if (t >= 10) {
+    if (a->pro_scale) return TF_ERR_UNSUPPORTED;
+    return tf_conv_dma_launch(a, t % 10, t >= 20 ? 4 : 3, stream);
+  }
   if (a->dtype == TF_BF16) {
     if (t == 1) return launch_conv<tf::bf16_t, 128, 128>(a, stream);
     if (t == 2) return launch_conv<tf::bf16_t, 128, 64>(a, stream);

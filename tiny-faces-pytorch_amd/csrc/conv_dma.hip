@@ -1,0 +1,334 @@
+// conv_dma: the implicit-GEMM convolution with an LDS-DMA operand pipeline (gfx950).
+//
+// Same GEMM view, MFMA fragments and XOR-swizzled LDS image as conv.hip; what changes is how
+// operands reach LDS and how results leave:
+//   * global_load_lds_dwordx4: every lane DMAs 16 bytes straight into LDS (no VGPR round
+//     trip), a wave fills 1 KiB of the linear tile image per instruction.  The swizzle is
+//     applied on the SOURCE address (lane l fills LDS slot l%8 of row l/8 with logical slot
+//     (l%8)^h(row)); im2col padding / rows past M read a 128-byte zero page instead of branching.
+//   * NS-deep LDS ring, counted `s_waitcnt vmcnt(N)` + raw s_barrier: NS-1 K-stages stay in
+//     flight across barriers, so the ~1-2 us L2/HBM latency of a stage is overlapped with the
+//     MFMAs of the previous ones instead of being paid once per stage (the register-staged
+//     kernel is latency-bound at one stage in flight: profiles/r01a_microbench_layer_shapes.txt).
+//   * epilogue through LDS: accumulators are parked as an fp32 [pixels][channels] tile, then
+//     every thread handles 16 output bytes of one pixel row -> full 128-byte lines for the
+//     store AND for the residual / mask operands, all epilogue math on 8 consecutive channels.
+// Used whenever no producer-BN prologue has to be applied on the fly (eval forward, every
+// data-gradient, conv1 / downsample / heads in training); conv.hip keeps the prologue path.
+#include "common.h"
+#include "profile.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ uint4 g_zero_page[8];     // 128 zero bytes: source of padded / out-of-range rows
+
+struct DmaK {
+  const char* x; const char* w; char* y;
+  const float* epi_scale; const float* epi_shift;
+  const char* aux; const char* aux2; const char* aux3;
+  const float* mask_scale; const float* mask_shift;
+  float* stat_out;
+  int H, W, Cin, OH, OW, KW, stride, pad, sshift;
+  int M, OHW, ldy, Ktot, cpt, nstages, ntiles, mode, epi;
+};
+
+__device__ __forceinline__ int swz(int row) { return ((row >> 1) & 1) ^ (((row >> 2) & 1) << 2) ^ (((row >> 3) & 1) * 6); }
+__device__ __forceinline__ int lds_off(int row, int slot) { return row * 128 + ((slot ^ swz(row)) << 4); }
+
+template <typename T> struct MmaD;
+template <> struct MmaD<tf::bf16_t> {
+  static constexpr int KCH = 64;
+  template <int NF, int MF>
+  __device__ static __forceinline__ void stage(const char* xs, const char* ws, int xrow0, int wrow0, f32x4 (&acc)[NF][MF]) {
+    const int l = threadIdx.x & 63, r = l & 15, g = l >> 4;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 xf[MF], wf[NF];
+#pragma unroll
+      for (int m = 0; m < MF; ++m) xf[m] = *reinterpret_cast<const bf16x8*>(xs + lds_off(xrow0 + m * 16 + r, ks * 4 + g));
+#pragma unroll
+      for (int n = 0; n < NF; ++n) wf[n] = *reinterpret_cast<const bf16x8*>(ws + lds_off(wrow0 + n * 16 + r, ks * 4 + g));
+#pragma unroll
+      for (int n = 0; n < NF; ++n)
+#pragma unroll
+        for (int m = 0; m < MF; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[n], xf[m], acc[n][m], 0, 0, 0);
+    }
+  }
+};
+template <> struct MmaD<float> {
+  static constexpr int KCH = 32;
+  template <int NF, int MF>
+  __device__ static __forceinline__ void stage(const char* xs, const char* ws, int xrow0, int wrow0, f32x4 (&acc)[NF][MF]) {
+    const int l = threadIdx.x & 63, r = l & 15, g = l >> 4;
+    f32x4 xf[MF][2], wf[NF][2];
+#pragma unroll
+    for (int m = 0; m < MF; ++m)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) xf[m][h] = *reinterpret_cast<const f32x4*>(xs + lds_off(xrow0 + m * 16 + r, 2 * g + h));
+#pragma unroll
+    for (int n = 0; n < NF; ++n)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) wf[n][h] = *reinterpret_cast<const f32x4*>(ws + lds_off(wrow0 + n * 16 + r, 2 * g + h));
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int n = 0; n < NF; ++n)
+#pragma unroll
+        for (int m = 0; m < MF; ++m)
+          acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n][j >> 2][j & 3], xf[m][j >> 2][j & 3], acc[n][m], 0, 0, 0);
+  }
+};
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// 16-byte DMA: global (per-lane address) -> LDS (wave-uniform base + lane*16)
+__device__ __forceinline__ void dma16(const void* gsrc, void* lds_wave_base) {
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef __attribute__((address_space(1))) const void glb_void;
+  __builtin_amdgcn_global_load_lds((glb_void*)gsrc, (lds_void*)lds_wave_base, 16, 0, 0);
+}
+
+template <typename T, int BM, int BN, int NS>
+__global__ void __launch_bounds__(256) conv_dma_kernel(const DmaK a) {
+  constexpr int KCH = MmaD<T>::KCH;
+  constexpr int EPS = tf::Elem<T>::kPer16B;
+  constexpr int XR = BM / 32, WR = BN / 32;
+  constexpr int WM = BM / 2, WN = BN / 2, MF = WM / 16, NF = WN / 16;
+  constexpr int XBYTES = BM * 128, WBYTES = BN * 128, BUF = XBYTES + WBYTES;
+  constexpr int L = XR + WR;                        // DMA instructions per thread per stage
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  int logical;
+  {
+    const int nb = gridDim.x, b = blockIdx.x, q = nb >> 3, r = nb & 7, xcd = b & 7, idx = b >> 3;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int mt = logical / a.ntiles, nt = logical - mt * a.ntiles;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int tid = threadIdx.x, lrow = tid >> 3, pslot = tid & 7;
+  const int wave_byte = (tid & ~63) * 16;            // LDS byte offset of this wave's 1 KiB piece inside a 256-thread pass
+
+  // logical slot that must land in physical slot pslot of each of this thread's rows (swizzle on the source)
+  int rb_n[XR], rb_h[XR], rb_w[XR], xslot[XR];
+#pragma unroll
+  for (int i = 0; i < XR; ++i) {
+    const int row = lrow + i * 32;
+    xslot[i] = pslot ^ swz(row);
+    const int p = m0 + row;
+    if (p < a.M) {
+      const int n = p / a.OHW, rem = p - n * a.OHW, oh = rem / a.OW, ow = rem - oh * a.OW;
+      rb_n[i] = n * a.H * a.W;
+      if (a.mode == 0) { rb_h[i] = oh * a.stride - a.pad; rb_w[i] = ow * a.stride - a.pad; }
+      else             { rb_h[i] = oh + a.pad;            rb_w[i] = ow + a.pad; }
+    } else { rb_n[i] = 0; rb_h[i] = -(1 << 28); rb_w[i] = -(1 << 28); }
+  }
+  const char* wsrc[WR];
+#pragma unroll
+  for (int i = 0; i < WR; ++i) {
+    const int row = lrow + i * 32;
+    wsrc[i] = a.w + ((size_t)(n0 + row) * a.Ktot + (pslot ^ swz(row)) * EPS) * sizeof(T);
+  }
+  const char* zero = reinterpret_cast<const char*>(g_zero_page) + pslot * 16;
+
+  auto issue = [&](int st) {
+    char* xs = smem + (st % NS) * BUF;
+    char* ws = xs + XBYTES;
+    const int tap = st / a.cpt, cin0 = (st - tap * a.cpt) * KCH;
+    const int kh = tap / a.KW, kw = tap - kh * a.KW;
+#pragma unroll
+    for (int i = 0; i < XR; ++i) {
+      int ih, iw; bool ok;
+      if (a.mode == 0) {
+        ih = rb_h[i] + kh; iw = rb_w[i] + kw;
+        ok = (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+      } else {
+        const int th = rb_h[i] - kh, tw = rb_w[i] - kw, smask = (1 << a.sshift) - 1;
+        ih = th >> a.sshift; iw = tw >> a.sshift;
+        ok = th >= 0 && tw >= 0 && !(th & smask) && !(tw & smask) && ih < a.H && iw < a.W;
+      }
+      // branch-free: compute the (clamped) address unconditionally, then select against the zero page
+      const int ihc = ok ? ih : 0, iwc = ok ? iw : 0;
+      const uintptr_t real = reinterpret_cast<uintptr_t>(a.x) +
+                             (((size_t)(rb_n[i] + ihc * a.W + iwc)) * a.Cin + cin0 + xslot[i] * EPS) * sizeof(T);
+      const uintptr_t src = ok ? real : reinterpret_cast<uintptr_t>(zero);
+      dma16(reinterpret_cast<const void*>(src), xs + i * 4096 + wave_byte);
+    }
+#pragma unroll
+    for (int i = 0; i < WR; ++i) dma16(wsrc[i] + (size_t)st * KCH * sizeof(T), ws + i * 4096 + wave_byte);
+  };
+
+  f32x4 acc[NF][MF];
+#pragma unroll
+  for (int n = 0; n < NF; ++n)
+#pragma unroll
+    for (int m = 0; m < MF; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int wave = tid >> 6, wm = wave & 1, wn = wave >> 1;
+
+  const int nst = a.nstages;
+#pragma unroll
+  for (int j = 0; j < NS - 1; ++j)
+    if (j < nst) issue(j);
+  for (int st = 0; st < nst; ++st) {
+    // stage st has landed once at most min(NS-2, nst-1-st) younger stages are still in flight
+    const int younger = nst - 1 - st;
+    if (younger >= NS - 2) wait_vmcnt<L*(NS - 2)>();
+    else if (NS > 3 && younger == 1) wait_vmcnt<L>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();                   // everyone's pieces of stage st landed; ring slot (st-1)%NS is free
+    if (st + NS - 1 < nst) issue(st + NS - 1);
+    const char* xs = smem + (st % NS) * BUF;
+    MmaD<T>::template stage<NF, MF>(xs, xs + XBYTES, wm * WM, wn * WN, acc);
+  }
+  __builtin_amdgcn_s_barrier();                     // all waves done reading the ring -> reuse it as the staging tile
+
+  // ---------------- epilogue, phase 1: accumulators -> fp32 [BM][BN+4] tile in LDS
+  constexpr int PITCH = BN + 4;
+  float* stg = reinterpret_cast<float*>(smem);
+  {
+    const int l = tid & 63, pr = l & 15, g = l >> 4;
+#pragma unroll
+    for (int n = 0; n < NF; ++n)
+#pragma unroll
+      for (int m = 0; m < MF; ++m)
+        *reinterpret_cast<f32x4*>(stg + (wm * WM + m * 16 + pr) * PITCH + wn * WN + n * 16 + g * 4) = acc[n][m];
+  }
+  __syncthreads();
+
+  // ---------------- phase 2: one 16-byte output chunk (EPS consecutive channels) of one pixel row per thread
+  constexpr int CPR = BN / EPS, RPP = 256 / CPR, PASSES = BM / RPP;
+  const int chunk = tid % CPR, rlane = tid / CPR;
+  const int c0 = n0 + chunk * EPS;
+  const bool cok = c0 < a.ldy;
+  float es[EPS], eh[EPS], ms[EPS], mh[EPS], s1[EPS], s2[EPS];
+#pragma unroll
+  for (int j = 0; j < EPS; ++j) { es[j] = 1.f; eh[j] = 0.f; ms[j] = 0.f; mh[j] = 0.f; s1[j] = 0.f; s2[j] = 0.f; }
+  if (cok) {
+    if (a.epi & TF_EPI_AFFINE) {
+#pragma unroll
+      for (int j = 0; j < EPS; ++j) { es[j] = a.epi_scale[c0 + j]; eh[j] = a.epi_shift[c0 + j]; }
+    }
+    if (a.epi & TF_EPI_MASK) {
+#pragma unroll
+      for (int j = 0; j < EPS; ++j) { ms[j] = a.mask_scale[c0 + j]; mh[j] = a.mask_shift[c0 + j]; }
+    }
+  }
+#pragma unroll
+  for (int ps = 0; ps < PASSES; ++ps) {
+    const int row = rlane + ps * RPP;
+    const int p = m0 + row;
+    float v[EPS];
+#pragma unroll
+    for (int j = 0; j < EPS; j += 4) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(stg + row * PITCH + chunk * EPS + j);
+      v[j] = t[0]; v[j + 1] = t[1]; v[j + 2] = t[2]; v[j + 3] = t[3];
+    }
+    if (a.epi & TF_EPI_STATS) {
+#pragma unroll
+      for (int j = 0; j < EPS; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }      // rows >= M are exactly 0
+    }
+    if (p < a.M && cok) {
+      const size_t o = ((size_t)p * a.ldy + c0) * sizeof(T);
+      float ax[EPS];
+      if (a.epi & (TF_EPI_RES | TF_EPI_MASK | TF_EPI_STATS2)) tf::unpack16<T>(*reinterpret_cast<const uint4*>(a.aux + o), ax);
+      if (a.epi & TF_EPI_AFFINE) {
+#pragma unroll
+        for (int j = 0; j < EPS; ++j) v[j] = v[j] * es[j] + eh[j];
+      }
+      if (a.epi & TF_EPI_RES) {
+#pragma unroll
+        for (int j = 0; j < EPS; ++j) v[j] += ax[j];
+      }
+      if (a.epi & TF_EPI_MASK) {
+#pragma unroll
+        for (int j = 0; j < EPS; ++j) v[j] = (ax[j] * ms[j] + mh[j] > 0.f) ? v[j] : 0.f;
+      }
+      if (a.epi & TF_EPI_JOIN) {
+        float y2[EPS], g3[EPS];
+        tf::unpack16<T>(*reinterpret_cast<const uint4*>(a.aux2 + o), y2);
+        tf::unpack16<T>(*reinterpret_cast<const uint4*>(a.aux3 + o), g3);
+#pragma unroll
+        for (int j = 0; j < EPS; ++j) v[j] += (y2[j] > 0.f) ? g3[j] : 0.f;
+      }
+      if (a.epi & TF_EPI_RELU) {
+#pragma unroll
+        for (int j = 0; j < EPS; ++j) v[j] = fmaxf(v[j], 0.f);
+      }
+      if (a.epi & TF_EPI_STATS2) {
+#pragma unroll
+        for (int j = 0; j < EPS; ++j) { s1[j] += v[j]; s2[j] += v[j] * ax[j]; }
+      }
+      *reinterpret_cast<uint4*>(a.y + o) = tf::pack16<T>(v);
+    }
+  }
+  if (a.epi & (TF_EPI_STATS | TF_EPI_STATS2)) {       // block-uniform: deterministic column sums of the tile
+    // lanes sharing a chunk inside a wave differ in the lane bits >= log2(CPR)
+#pragma unroll
+    for (int o = CPR; o < 64; o <<= 1) {
+#pragma unroll
+      for (int j = 0; j < EPS; ++j) { s1[j] += __shfl_xor(s1[j], o, 64); s2[j] += __shfl_xor(s2[j], o, 64); }
+    }
+    __syncthreads();                                 // staging tile fully consumed
+    float* red = reinterpret_cast<float*>(smem);     // [4 waves][2][BN]
+    const int lane = tid & 63;
+    if (lane < CPR) {
+#pragma unroll
+      for (int j = 0; j < EPS; ++j) { red[(wave * 2 + 0) * BN + lane * EPS + j] = s1[j]; red[(wave * 2 + 1) * BN + lane * EPS + j] = s2[j]; }
+    }
+    __syncthreads();
+    for (int e = tid; e < 2 * BN; e += 256) {
+      const int k = e / BN, cl = e - k * BN, c = n0 + cl;
+      if (c < a.ldy) a.stat_out[((size_t)mt * 2 + k) * a.ldy + c] = red[(0 * 2 + k) * BN + cl] + red[(1 * 2 + k) * BN + cl] +
+                                                                   red[(2 * 2 + k) * BN + cl] + red[(3 * 2 + k) * BN + cl];
+    }
+  }
+}
+
+template <typename T, int BM, int BN, int NS>
+int launch(const tf_conv_args* A, hipStream_t stream) {
+  constexpr int KCH = MmaD<T>::KCH;
+  DmaK k;
+  k.x = (const char*)A->x; k.w = (const char*)A->w; k.y = (char*)A->y;
+  k.epi_scale = A->epi_scale; k.epi_shift = A->epi_shift;
+  k.aux = (const char*)A->aux; k.aux2 = (const char*)A->aux2; k.aux3 = (const char*)A->aux3;
+  k.mask_scale = A->mask_scale; k.mask_shift = A->mask_shift; k.stat_out = A->stat_out;
+  k.H = A->H; k.W = A->W; k.Cin = A->Cin; k.OH = A->OH; k.OW = A->OW; k.KW = A->KW; k.stride = A->stride; k.pad = A->pad;
+  k.sshift = A->stride == 2 ? 1 : 0;
+  k.M = A->N * A->OH * A->OW; k.OHW = A->OH * A->OW; k.ldy = A->ldy;
+  k.cpt = A->Cin / KCH; k.Ktot = A->KH * A->KW * A->Cin; k.nstages = A->KH * A->KW * k.cpt;
+  k.ntiles = (A->Cout + BN - 1) / BN; k.mode = A->mode; k.epi = A->epi;
+  const int mtiles = (k.M + BM - 1) / BM;
+  size_t lds = (size_t)NS * (BM + BN) * 128;
+  const size_t stg = (size_t)BM * (BN + 4) * 4;
+  if (stg > lds) lds = stg;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<T, BM, BN, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  {
+    const double es = sizeof(T), M = k.M, Kt = k.Ktot;
+    double bytes = ((double)A->N * A->H * A->W * A->Cin + (double)A->Cout * Kt + M * A->Cout) * es;
+    if (A->epi & (TF_EPI_RES | TF_EPI_MASK | TF_EPI_STATS2)) bytes += M * A->Cout * es;
+    if (A->epi & TF_EPI_JOIN) bytes += 2 * M * A->Cout * es;
+    tf::ProfScope prof((sizeof(T) == 2 ? 3 : 0) + (BM == 64 ? 2 : (BN == 64 ? 1 : 0)), 2.0 * M * A->Cout * Kt, bytes, stream);
+    hipLaunchKernelGGL((conv_dma_kernel<T, BM, BN, NS>), dim3(mtiles * k.ntiles), dim3(256), lds, stream, k);
+  }
+  return hipGetLastError() == hipSuccess ? TF_OK : TF_ERR_LAUNCH;
+}
+
+}  // namespace
+
+// tile: 1 = 128x128, 2 = 128x64, 3 = 64x64 (pixels x channels); depth: ring stages (3 or 4)
+int tf_conv_dma_launch(const tf_conv_args* a, int tile, int depth, hipStream_t stream) {
+  if (a->dtype == TF_BF16) {
+    if (tile == 1) return launch<tf::bf16_t, 128, 128, 3>(a, stream);
+    if (tile == 2) return depth == 4 ? launch<tf::bf16_t, 128, 64, 4>(a, stream) : launch<tf::bf16_t, 128, 64, 3>(a, stream);
+    return depth == 3 ? launch<tf::bf16_t, 64, 64, 3>(a, stream) : launch<tf::bf16_t, 64, 64, 4>(a, stream);
+  }
+  if (tile == 1) return launch<float, 128, 128, 3>(a, stream);
+  if (tile == 2) return launch<float, 128, 64, 3>(a, stream);
+  return launch<float, 64, 64, 4>(a, stream);
+}

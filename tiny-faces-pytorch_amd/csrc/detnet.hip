@@ -36,6 +36,7 @@ int tf_bn_bwd_finalize(const float*, int, int, int, int, int, float, const float
                        float*, void*);
 int tf_bn_bwd_apply(int, const void*, const void*, const void*, const float*, const float*, const float*, int64_t, int, void*, void*);
 int tf_bn_add_relu(int, const void*, const float*, const float*, const void*, const float*, const float*, int64_t, int, void*, void*);
+int tf_bn_relu(int, const void*, const float*, const float*, int64_t, int, void*, void*);
 int tf_upsample_add_crop(int, const void*, const void*, const float*, int, int, int, int, int, int, int, float*, void*);
 int tf_upsample_add_crop_bwd(int, const float*, const float*, int, int, int, int, int, int, int, void*, void*, void*);
 int tf_reduce_partials(const float*, int, int, int, int, int, float*, void*);
@@ -134,7 +135,7 @@ BnBuf bn_alloc(Arena& ar, int C) {
 struct Plan {                    // everything a forward carves; backward re-derives the same pointers
   int dtype, N, H, W, nout, training;
   int H1, W1, H2, W2;            // stem conv out, maxpool out
-  void *col, *cstem, *pool; uint8_t* pool_idx; BnBuf bn_stem;
+  void *col, *cstem, *pool, *a1tmp; uint8_t* pool_idx; BnBuf bn_stem;
   void *wstem;
   struct Blk {
     int Hin, Win, Hout, Wout;
@@ -198,6 +199,7 @@ void build_plan(Plan& P, Arena& ar, int dtype, int N, int H, int W, int nout, in
   const Plan::Blk& l3 = P.blk[A.layer_end[2]];
   P.H3 = l2.Hout; P.W3 = l2.Wout; P.H4 = l3.Hout; P.W4 = l3.Wout;
   const size_t M3 = (size_t)N * P.H3 * P.W3, M4 = (size_t)N * P.H4 * P.W4;
+  P.a1tmp = ar.get(training ? max_act : 0);       // relu(bn1(c1)) of the current block (3x3 conv operand, not kept)
   P.w_h3 = ar.get(packed_bytes(dtype, kHeadLd, 1, 512)); P.w_h4 = ar.get(packed_bytes(dtype, kHeadLd, 1, 1024));
   P.s3 = ar.get(M3 * kHeadLd * es); P.s4 = ar.get(M4 * kHeadLd * es);
   P.hbias3 = ar.f32(kHeadLd); P.hbias4 = ar.f32(kHeadLd); P.ones = ar.f32(kHeadLd);
@@ -346,8 +348,9 @@ extern "C" int tf_detnet_forward(int dtype, int training, const float* x, int N,
     c.chk(tf_conv2d(&a, c.stream));
     if (tr) bn_forward(c, B.c1, pl, b.b1, true, &a, P.partial, (float)Min, eps, mom);
     // conv2 3x3 (stride here)
-    conv_fill(a, dtype, 0, N, b.Hin, b.Win, pl, b.Hout, b.Wout, pl, 3, B.stride, 1, pl, b.c1, b.w2, b.c2);
-    if (tr) { a.pro_scale = b.b1.scale; a.pro_shift = b.b1.shift; a.pro_relu = 1; a.epi = TF_EPI_STATS; a.stat_out = P.partial; }
+    if (tr) c.chk(tf_bn_relu(dtype, b.c1, b.b1.scale, b.b1.shift, Min, pl, P.a1tmp, c.stream));   // un-fused on purpose: lets the 3x3 use the DMA pipeline
+    conv_fill(a, dtype, 0, N, b.Hin, b.Win, pl, b.Hout, b.Wout, pl, 3, B.stride, 1, pl, tr ? P.a1tmp : b.c1, b.w2, b.c2);
+    if (tr) { a.epi = TF_EPI_STATS; a.stat_out = P.partial; }
     else { bn_forward(c, B.c2, pl, b.b2, false, nullptr, nullptr, 0, eps, mom); a.epi = TF_EPI_AFFINE | TF_EPI_RELU; a.epi_scale = b.b2.scale; a.epi_shift = b.b2.shift; }
     c.chk(tf_conv2d(&a, c.stream));
     if (tr) bn_forward(c, B.c2, pl, b.b2, true, &a, P.partial, (float)Mout, eps, mom);

@@ -334,6 +334,23 @@ __global__ void __launch_bounds__(256) bn_add_relu_kernel(const T* __restrict__ 
   }
 }
 
+// y = relu(x*s+h): materialised BN+ReLU (input of the 3x3 conv, so that it can use the LDS-DMA pipeline)
+template <typename T>
+__global__ void __launch_bounds__(256) bn_relu_kernel(const T* __restrict__ x, const float* __restrict__ sc, const float* __restrict__ sh, size_t M,
+                                                      int C, T* __restrict__ y) {
+  constexpr int EPS = tf::Elem<T>::kPer16B;
+  const int spr = C / EPS;
+  const size_t total = M * spr;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int s = (int)(i % spr);
+    float f[EPS];
+    tf::unpack16<T>(*reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(x) + i * 16), f);
+#pragma unroll
+    for (int j = 0; j < EPS; ++j) f[j] = fmaxf(f[j] * sc[s * EPS + j] + sh[s * EPS + j], 0.f);
+    *reinterpret_cast<uint4*>(reinterpret_cast<char*>(y) + i * 16) = tf::pack16<T>(f);
+  }
+}
+
 // ---------------------------------------------------------------- head: bilinear ConvTranspose2d(k4,s2,p1) + crop + add
 // out NCHW fp32 [B][C][H3][W3] = s3[(b,y,x)][c] + sum_{ky,kx} s4[(b,i,j)][c] * wup[c][ky][kx],  y = 2i-1+ky, x = 2j-1+kx
 // (model.py:104-126; only the channel diagonal of score4_upsample.weight is non-zero, model.py:61-65)
@@ -556,6 +573,15 @@ extern "C" int tf_bn_add_relu(int dtype, const void* x, const float* s1, const f
   const size_t total = (size_t)M * (C / (dtype == TF_BF16 ? 8 : 4));
   DISPATCH_T(dtype, hipLaunchKernelGGL(bn_add_relu_kernel<T>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const T*)x, s1, h1,
                                        (const T*)r, s2, h2, (size_t)M, C, (T*)y));
+  TF_CHECK_LAUNCH();
+  return TF_OK;
+}
+
+extern "C" int tf_bn_relu(int dtype, const void* x, const float* scale, const float* shift, int64_t M, int C, void* y, void* stream) {
+  if (!x || !y || !scale || !shift || C % 8) return TF_ERR_ARG;
+  const size_t total = (size_t)M * (C / (dtype == TF_BF16 ? 8 : 4));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_relu_kernel<T>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const T*)x, scale, shift,
+                                       (size_t)M, C, (T*)y));
   TF_CHECK_LAUNCH();
   return TF_OK;
 }

@@ -72,6 +72,7 @@ _SIGNATURES = {
     "tf_bn_fold": (i32, [vp, vp, vp, vp, f32, i32, vp, vp, vp]),
     "tf_bn_bwd_finalize": (i32, [vp, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "tf_bn_bwd_apply": (i32, [i32, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp]),
+    "tf_bn_relu": (i32, [i32, vp, vp, vp, i64, i32, vp, vp]),
     "tf_bn_add_relu": (i32, [i32, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp]),
     "tf_upsample_add_crop": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
     "tf_upsample_add_crop_bwd": (i32, [i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
