@@ -159,6 +159,9 @@ int tf_conv2d(const tf_conv_args* a, void* stream);
  * operand [CinPad'][KH*KW][Cout] (roles swapped).  Pads are zero-filled. */
 int tf_pack_weight(const float* w_oihw, int Cout, int Cin, int KH, int KW, int transpose,
                    int dtype, void* out, int rows_pad, int cols_pad, void* stream);
+/* the same for many weights in one or two launches (job table passed as kernel arguments, no H2D copy) */
+typedef struct tf_pack_job { const float* src; void* dst; int cout, cin, taps, transpose, rows_pad, cols_pad; } tf_pack_job;
+int tf_pack_weights_batched(int dtype, const tf_pack_job* host_jobs, int njobs, void* stream);
 
 /* weight gradient: dW[co][ci][kh][kw] (+)= sum_p dY[p,co] * xhat[gather(p,tap),ci] (fp32 atomics
  * into dw_oihw, which the caller zeroes).  Same prologue semantics as tf_conv2d. */
@@ -236,8 +239,11 @@ int tf_detnet_out_shape(int H, int W, int* H3, int* W3);
 int tf_detnet_forward(int dtype, int training, const float* x_nchw, int N, int H, int W, int num_out,
                       void* const* params, float bn_eps, float bn_momentum,
                       float* out_nchw, void* ws, size_t ws_bytes, void* stream);
+/* grad_flat (optional): when every entry of `grads` lies inside [grad_flat, grad_flat + grad_flat_bytes) the whole
+ * range is zeroed with ONE memset instead of one per weight gradient. */
 int tf_detnet_backward(int dtype, const float* x_nchw, int N, int H, int W, int num_out,
                        void* const* params, void* const* grads, const float* gout_nchw,
+                       void* grad_flat, size_t grad_flat_bytes,
                        void* ws, size_t ws_bytes, void* stream);
 
 /* ---- measurement hooks (bench.py `roofline`) ------------------------------------------

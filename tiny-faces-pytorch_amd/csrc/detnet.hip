@@ -141,10 +141,11 @@ struct Plan {                    // everything a forward carves; backward re-der
     int Hin, Win, Hout, Wout;
     void *c1, *c2, *c3, *d, *y;
     void *w1, *w2, *w3, *wd;         // packed forward weights
+    void *w1t, *w2t, *w3t, *wdt;     // packed data-gradient (transposed) weights, training only
     BnBuf b1, b2, b3, bd;
   };
   std::vector<Blk> blk;
-  void *w_h3, *w_h4, *s3, *s4; float *hbias3, *hbias4, *ones, *wup_diag;
+  void *w_h3, *w_h4, *w_h3t, *w_h4t, *s3, *s4; float *hbias3, *hbias4, *ones, *wup_diag;
   float* partial; size_t partial_floats;
   // backward-only
   void *g3, *g4, *G0, *G1, *T1, *T2, *T3, *T4, *R3, *wt; float* dwp;   // gradient buffers (roles in tf_detnet_backward) + transposed-weight scratch
@@ -185,6 +186,10 @@ void build_plan(Plan& P, Arena& ar, int dtype, int N, int H, int W, int nout, in
     b.w1 = ar.get(packed_bytes(dtype, pl, 1, B.cin)); b.w2 = ar.get(packed_bytes(dtype, pl, 9, pl));
     b.w3 = ar.get(packed_bytes(dtype, c4, 1, pl));
     b.wd = B.has_ds ? ar.get(packed_bytes(dtype, c4, 1, B.cin)) : nullptr;
+    b.w1t = training ? ar.get(packed_bytes(dtype, B.cin, 1, pl)) : nullptr;
+    b.w2t = training ? ar.get(packed_bytes(dtype, pl, 9, pl)) : nullptr;
+    b.w3t = training ? ar.get(packed_bytes(dtype, pl, 1, c4)) : nullptr;
+    b.wdt = (training && B.has_ds) ? ar.get(packed_bytes(dtype, B.cin, 1, c4)) : nullptr;
     b.b1 = bn_alloc(ar, pl); b.b2 = bn_alloc(ar, pl); b.b3 = bn_alloc(ar, c4);
     if (B.has_ds) b.bd = bn_alloc(ar, c4);
     part(Min, pl); part(Mout, c4);
@@ -201,10 +206,13 @@ void build_plan(Plan& P, Arena& ar, int dtype, int N, int H, int W, int nout, in
   const size_t M3 = (size_t)N * P.H3 * P.W3, M4 = (size_t)N * P.H4 * P.W4;
   P.a1tmp = ar.get(training ? max_act : 0);       // relu(bn1(c1)) of the current block (3x3 conv operand, not kept)
   P.w_h3 = ar.get(packed_bytes(dtype, kHeadLd, 1, 512)); P.w_h4 = ar.get(packed_bytes(dtype, kHeadLd, 1, 1024));
+  P.w_h3t = training ? ar.get(packed_bytes(dtype, 512, 1, kHeadLd)) : nullptr;
+  P.w_h4t = training ? ar.get(packed_bytes(dtype, 1024, 1, kHeadLd)) : nullptr;
   P.s3 = ar.get(M3 * kHeadLd * es); P.s4 = ar.get(M4 * kHeadLd * es);
   P.hbias3 = ar.f32(kHeadLd); P.hbias4 = ar.f32(kHeadLd); P.ones = ar.f32(kHeadLd);
   P.wup_diag = ar.f32((size_t)nout * 16);
   part(M3, kHeadLd);
+  if (max_partial < (size_t)1100 * 3 * 1024) max_partial = (size_t)1100 * 3 * 1024;   // colstats: up to ~1024 blocks x 3 sums x 1024 channels
   P.partial_floats = max_partial + 4096;
   P.partial = ar.f32(P.partial_floats);
   if (training) {
@@ -229,6 +237,9 @@ __global__ void head_vectors_kernel(const float* b3, const float* b4, const floa
 
 struct Ctx {
   int dtype; hipStream_t stream; void* const* params; void* const* grads; int rc;
+  bool grads_zeroed = false;
+  std::vector<tf_pack_job> jobs;
+  void flush_packs() { if (!jobs.empty()) { chk(tf_pack_weights_batched(dtype, jobs.data(), (int)jobs.size(), stream)); jobs.clear(); } }
   const float* P(int i) const { return (const float*)params[i]; }
   float* G(int i) const { return grads ? (float*)grads[i] : nullptr; }
   void chk(int r) { if (r != TF_OK && rc == TF_OK) rc = r; }
@@ -244,14 +255,12 @@ void conv_fill(tf_conv_args& a, int dtype, int mode, int N, int H, int W, int Ci
 void pack(Ctx& c, const ConvUnit& u, int cout, void* out, bool transpose, int cin_override = 0, int cols_pad_override = 0,
           int k_override = 0) {
   const int cin = cin_override ? cin_override : u.cin;
-  const int taps = k_override ? k_override : u.k;
-  if (!transpose) {
-    const int cols = cols_pad_override ? cols_pad_override : cin;
-    c.chk(tf_pack_weight(c.P(u.w), cout, cin, taps, taps, 0, c.dtype, out, (cout + 127) / 128 * 128, cols, c.stream));
-  } else {
-    const int cols = cols_pad_override ? cols_pad_override : cout;
-    c.chk(tf_pack_weight(c.P(u.w), cout, cin, taps, taps, 1, c.dtype, out, (cin + 127) / 128 * 128, cols, c.stream));
-  }
+  const int k = k_override ? k_override : u.k;
+  tf_pack_job j;
+  j.src = c.P(u.w); j.dst = out; j.cout = cout; j.cin = cin; j.taps = k * k; j.transpose = transpose ? 1 : 0;
+  if (!transpose) { j.rows_pad = (cout + 127) / 128 * 128; j.cols_pad = cols_pad_override ? cols_pad_override : cin; }
+  else            { j.rows_pad = (cin + 127) / 128 * 128;  j.cols_pad = cols_pad_override ? cols_pad_override : cout; }
+  c.jobs.push_back(j);
 }
 
 // BN after a conv: eval -> fold running stats; train -> finalize batch partials (+ running update)
@@ -320,7 +329,22 @@ extern "C" int tf_detnet_forward(int dtype, int training, const float* x, int N,
   // ---- stem: im2col + GEMM (+BN+ReLU) + maxpool
   const int M1 = N * P.H1 * P.W1;
   c.chk(tf_stem_im2col(x, N, H, W, dtype, P.col, kStemK, c.stream));
+  // ---- every weight of the pass re-packed from the fp32 master copy in two launches
   pack(c, A.stem, 64, P.wstem, false, 147, kStemK, 1);     // conv1.weight flattened OIHW == im2col k order
+  for (size_t i = 0; i < A.blocks.size(); ++i) {
+    const Block& B = A.blocks[i];
+    Plan::Blk& b = P.blk[i];
+    pack(c, B.c1, B.planes, b.w1, false); pack(c, B.c2, B.planes, b.w2, false); pack(c, B.c3, B.planes * 4, b.w3, false);
+    if (B.has_ds) pack(c, B.ds, B.planes * 4, b.wd, false);
+  }
+  {
+    tf_pack_job j;
+    j.src = c.P(A.head3.w); j.dst = P.w_h3; j.cout = nout; j.cin = 512; j.taps = 1; j.transpose = 0; j.rows_pad = kHeadLd; j.cols_pad = 512;
+    c.jobs.push_back(j);
+    j.src = c.P(A.head4.w); j.dst = P.w_h4; j.cin = 1024; j.cols_pad = 1024;
+    c.jobs.push_back(j);
+  }
+  c.flush_packs();
   conv_fill(a, dtype, 0, 1, 1, M1, kStemK, 1, M1, 64, 1, 1, 0, 64, P.col, P.wstem, P.cstem);
   if (tr) { a.epi = TF_EPI_STATS; a.stat_out = P.partial; }
   else {
@@ -339,8 +363,6 @@ extern "C" int tf_detnet_forward(int dtype, int training, const float* x, int N,
     Plan::Blk& b = P.blk[i];
     const int pl = B.planes, c4 = pl * 4;
     const int Min = N * b.Hin * b.Win, Mout = N * b.Hout * b.Wout;
-    pack(c, B.c1, pl, b.w1, false); pack(c, B.c2, pl, b.w2, false); pack(c, B.c3, c4, b.w3, false);
-    if (B.has_ds) pack(c, B.ds, c4, b.wd, false);
     // conv1 1x1
     conv_fill(a, dtype, 0, N, b.Hin, b.Win, B.cin, b.Hin, b.Win, pl, 1, 1, 0, pl, yin, b.w1, b.c1);
     if (tr) { a.epi = TF_EPI_STATS; a.stat_out = P.partial; }
@@ -383,8 +405,6 @@ extern "C" int tf_detnet_forward(int dtype, int training, const float* x, int N,
   const void* res4 = P.blk[A.layer_end[2]].y;
   hipLaunchKernelGGL(head_vectors_kernel, dim3((nout * 16 + 255) / 256), dim3(256), 0, c.stream, c.P(A.head3.bias), c.P(A.head4.bias),
                      c.P(A.upsample_w), nout, P.hbias3, P.hbias4, P.ones, P.wup_diag);
-  c.chk(tf_pack_weight(c.P(A.head3.w), nout, 512, 1, 1, 0, dtype, P.w_h3, kHeadLd, 512, c.stream));
-  c.chk(tf_pack_weight(c.P(A.head4.w), nout, 1024, 1, 1, 0, dtype, P.w_h4, kHeadLd, 1024, c.stream));
   conv_fill(a, dtype, 0, N, P.H3, P.W3, 512, P.H3, P.W3, kHeadLd, 1, 1, 0, kHeadLd, res3, P.w_h3, P.s3);
   a.epi = TF_EPI_AFFINE; a.epi_scale = P.ones; a.epi_shift = P.hbias3;
   c.chk(tf_conv2d(&a, c.stream));
@@ -418,29 +438,49 @@ void wgrad(Ctx& c, const ConvUnit& u, int cout, int N, int H, int W, int OH, int
   if (k > 1 && packed_scratch) {          // 3x3: coalesced atomics into [Cout][tap][Cin], then one transposing copy to OIHW
     float* oihw = w.dw_oihw;
     w.dw_oihw = packed_scratch; w.packed = 1;
-    if (hipMemsetAsync(packed_scratch, 0, (size_t)cout * w.dw_ld * 4, c.stream) != hipSuccess) c.chk(TF_ERR_LAUNCH);
+    if (hipMemsetAsync(packed_scratch, 0, (size_t)cout * w.dw_ld * 4, c.stream) != hipSuccess) c.chk(TF_ERR_LAUNCH);   // scratch: always
     c.chk(tf_conv2d_wgrad(&w, c.stream));
     c.chk(tf_unpack_dw(packed_scratch, cout, cin, k * k, oihw, c.stream));
     return;
   }
-  if (hipMemsetAsync(w.dw_oihw, 0, (size_t)cout * w.dw_ld * 4, c.stream) != hipSuccess) c.chk(TF_ERR_LAUNCH);
+  if (!c.grads_zeroed && hipMemsetAsync(w.dw_oihw, 0, (size_t)cout * w.dw_ld * 4, c.stream) != hipSuccess) c.chk(TF_ERR_LAUNCH);
   c.chk(tf_conv2d_wgrad(&w, c.stream));
 }
 
 }  // namespace
 
 extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W, int nout, void* const* params, void* const* grads,
-                                  const float* gout, void* ws, size_t ws_bytes, void* stream_) {
+                                  const float* gout, void* grad_flat, size_t grad_flat_bytes, void* ws, size_t ws_bytes, void* stream_) {
   if (!x || !params || !grads || !gout || !ws) return TF_ERR_ARG;
   const Arch& A = arch();
   Plan P; Arena ar(ws, ws_bytes);
   build_plan(P, ar, dtype, N, H, W, nout, 1);
   if (!ar.ok) return TF_ERR_WORKSPACE;
-  Ctx c{dtype, (hipStream_t)stream_, params, grads, TF_OK};
+  Ctx c{dtype, (hipStream_t)stream_, params, grads, TF_OK};   // (grads_zeroed / jobs default-initialised)
   tf_conv_args a;
   const int M3 = N * P.H3 * P.W3, M4 = N * P.H4 * P.W4;
   const void* res3 = P.blk[A.layer_end[1]].y;
   const void* res4 = P.blk[A.layer_end[2]].y;
+
+  if (grad_flat && grad_flat_bytes) {                     // one memset for every weight gradient (atomics accumulate into them)
+    if (hipMemsetAsync(grad_flat, 0, grad_flat_bytes, c.stream) != hipSuccess) c.chk(TF_ERR_LAUNCH);
+    c.grads_zeroed = true;
+  }
+  // ---- every data-gradient (transposed) weight operand of the pass in two launches
+  for (size_t i = 0; i < A.blocks.size(); ++i) {
+    const Block& B = A.blocks[i];
+    Plan::Blk& b = P.blk[i];
+    pack(c, B.c1, B.planes, b.w1t, true); pack(c, B.c2, B.planes, b.w2t, true); pack(c, B.c3, B.planes * 4, b.w3t, true);
+    if (B.has_ds) pack(c, B.ds, B.planes * 4, b.wdt, true);
+  }
+  {
+    tf_pack_job j;
+    j.src = c.P(A.head3.w); j.dst = P.w_h3t; j.cout = nout; j.cin = 512; j.taps = 1; j.transpose = 1; j.rows_pad = 512; j.cols_pad = kHeadLd;
+    c.jobs.push_back(j);
+    j.src = c.P(A.head4.w); j.dst = P.w_h4t; j.cin = 1024; j.rows_pad = 1024;
+    c.jobs.push_back(j);
+  }
+  c.flush_packs();
 
   // ---- heads
   c.chk(tf_upsample_add_crop_bwd(dtype, gout, P.wup_diag, N, nout, kHeadLd, P.H3, P.W3, P.H4, P.W4, P.g3, P.g4, c.stream));
@@ -462,11 +502,9 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
   // Buffer roles: Gcur/Gnext ping-pong the gradient w.r.t. a block output / input; T1 = g_c3 then g_c1;
   // T2 = gz2 -> g_c2; T3 = g_d; T4 = downsample-branch input gradient; R3 = gradient w.r.t. res3 from the head.
   void *Gcur = P.G0, *Gnext = P.G1;
-  c.chk(tf_pack_weight(c.P(A.head4.w), nout, 1024, 1, 1, 1, dtype, P.wt, 1024, kHeadLd, c.stream));
-  conv_fill(a, dtype, 1, N, P.H4, P.W4, kHeadLd, P.H4, P.W4, 1024, 1, 1, 0, 1024, P.g4, P.wt, Gcur);
+  conv_fill(a, dtype, 1, N, P.H4, P.W4, kHeadLd, P.H4, P.W4, 1024, 1, 1, 0, 1024, P.g4, P.w_h4t, Gcur);
   c.chk(tf_conv2d(&a, c.stream));
-  c.chk(tf_pack_weight(c.P(A.head3.w), nout, 512, 1, 1, 1, dtype, P.wt, 512, kHeadLd, c.stream));
-  conv_fill(a, dtype, 1, N, P.H3, P.W3, kHeadLd, P.H3, P.W3, 512, 1, 1, 0, 512, P.g3, P.wt, P.R3);
+  conv_fill(a, dtype, 1, N, P.H3, P.W3, kHeadLd, P.H3, P.W3, 512, 1, 1, 0, 512, P.g3, P.w_h3t, P.R3);
   c.chk(tf_conv2d(&a, c.stream));
 
   // ---- bottlenecks in reverse
@@ -488,8 +526,7 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
     // (3) wgrad conv3 (its input is relu(bn2(c2)), re-materialised in the loader)
     wgrad(c, B.c3, c4, N, b.Hout, b.Wout, b.Hout, b.Wout, b.c2, pl, P.T1, c4, &b.b2);
     // (4) dgrad conv3 -> gz2 in T2 (masked by relu(bn2(c2))) + BN-backward sums
-    pack(c, B.c3, c4, P.wt, true);
-    conv_fill(a, dtype, 1, N, b.Hout, b.Wout, c4, b.Hout, b.Wout, pl, 1, 1, 0, pl, P.T1, P.wt, P.T2);
+    conv_fill(a, dtype, 1, N, b.Hout, b.Wout, c4, b.Hout, b.Wout, pl, 1, 1, 0, pl, P.T1, b.w3t, P.T2);
     a.epi = TF_EPI_MASK | TF_EPI_STATS2; a.aux = b.c2; a.mask_scale = b.b2.scale; a.mask_shift = b.b2.shift; a.stat_out = P.partial;
     c.chk(tf_conv2d(&a, c.stream));
     bn_backward_coefs(c, B.c2, pl, b.b2, P.partial, tf_conv_mtiles(&a), 2, 1, pl, (float)Mout);
@@ -498,8 +535,7 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
     // (6) wgrad conv2 (input relu(bn1(c1)))
     wgrad(c, B.c2, pl, N, b.Hin, b.Win, b.Hout, b.Wout, b.c1, pl, P.T2, pl, &b.b1, 0, 0, 0, P.dwp);
     // (7) dgrad conv2 -> gz1 in T1 (+ sums); output spatial = conv2's input
-    pack(c, B.c2, pl, P.wt, true);
-    conv_fill(a, dtype, 1, N, b.Hout, b.Wout, pl, b.Hin, b.Win, pl, 3, B.stride, 1, pl, P.T2, P.wt, P.T1);
+    conv_fill(a, dtype, 1, N, b.Hout, b.Wout, pl, b.Hin, b.Win, pl, 3, B.stride, 1, pl, P.T2, b.w2t, P.T1);
     a.epi = TF_EPI_MASK | TF_EPI_STATS2; a.aux = b.c1; a.mask_scale = b.b1.scale; a.mask_shift = b.b1.shift; a.stat_out = P.partial;
     c.chk(tf_conv2d(&a, c.stream));
     bn_backward_coefs(c, B.c1, pl, b.b1, P.partial, tf_conv_mtiles(&a), 2, 1, pl, (float)Min);
@@ -511,17 +547,14 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
     if (B.has_ds) {
       c.chk(tf_bn_bwd_apply(dtype, Gcur, b.y, b.d, b.bd.cA, b.bd.cB, b.bd.cD, Mout, c4, P.T3, c.stream));
       wgrad(c, B.ds, c4, N, b.Hin, b.Win, b.Hout, b.Wout, yin, B.cin, P.T3, c4, nullptr);
-      pack(c, B.ds, c4, P.wt, true);
-      conv_fill(a, dtype, 1, N, b.Hout, b.Wout, c4, b.Hin, b.Win, B.cin, 1, B.stride, 0, B.cin, P.T3, P.wt, P.T4);
+      conv_fill(a, dtype, 1, N, b.Hout, b.Wout, c4, b.Hin, b.Win, B.cin, 1, B.stride, 0, B.cin, P.T3, b.wdt, P.T4);
       if (extra) { a.epi = TF_EPI_RES; a.aux = extra; }
       c.chk(tf_conv2d(&a, c.stream));
-      pack(c, B.c1, pl, P.wt, true);
-      conv_fill(a, dtype, 1, N, b.Hin, b.Win, pl, b.Hin, b.Win, B.cin, 1, 1, 0, B.cin, P.T1, P.wt, Gnext);
+      conv_fill(a, dtype, 1, N, b.Hin, b.Win, pl, b.Hin, b.Win, B.cin, 1, 1, 0, B.cin, P.T1, b.w1t, Gnext);
       a.epi = TF_EPI_RES; a.aux = P.T4;
       c.chk(tf_conv2d(&a, c.stream));
     } else {
-      pack(c, B.c1, pl, P.wt, true);
-      conv_fill(a, dtype, 1, N, b.Hin, b.Win, pl, b.Hin, b.Win, B.cin, 1, 1, 0, B.cin, P.T1, P.wt, Gnext);
+      conv_fill(a, dtype, 1, N, b.Hin, b.Win, pl, b.Hin, b.Win, B.cin, 1, 1, 0, B.cin, P.T1, b.w1t, Gnext);
       a.epi = TF_EPI_JOIN; a.aux2 = b.y; a.aux3 = Gcur;       // identity branch: + g_y * (y > 0)
       c.chk(tf_conv2d(&a, c.stream));
     }

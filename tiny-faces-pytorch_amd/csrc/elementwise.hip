@@ -27,6 +27,24 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int Cout, int Ci
   }
 }
 
+struct PackJobs { tf_pack_job j[64]; };
+template <typename T>
+__global__ void __launch_bounds__(256) pack_batched_kernel(const PackJobs jobs) {
+  const tf_pack_job& J = jobs.j[blockIdx.y];
+  const int taps = J.taps;
+  const size_t total = (size_t)J.rows_pad * taps * J.cols_pad;
+  T* out = reinterpret_cast<T*>(J.dst);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int inner = (int)(i % J.cols_pad);
+    const int tap = (int)((i / J.cols_pad) % taps);
+    const int row = (int)(i / ((size_t)J.cols_pad * taps));
+    const int co = J.transpose ? inner : row, ci = J.transpose ? row : inner;
+    float v = 0.f;
+    if (co < J.cout && ci < J.cin) v = J.src[((size_t)co * J.cin + ci) * taps + tap];
+    tf::Elem<T>::store(out + i, v);
+  }
+}
+
 // ---------------------------------------------------------------- stem im2col
 // x NCHW fp32 [N][3][H][W] -> col [M][ldc], k = c*49 + kh*7 + kw (== OIHW order of conv1.weight), zero padded
 template <typename T>
@@ -288,6 +306,8 @@ __global__ void __launch_bounds__(kFinCh* kFinLanes) bn_bwd_finalize_kernel(cons
 }
 
 // out = A*g' + B*x + D   (g' = g*(y>0) when y given).  BN input gradient, materialised for dgrad / wgrad.
+// The grid stride (gridDim*256) is a multiple of the 16-byte slots per row, so a thread keeps ONE channel chunk:
+// its per-channel coefficients are loaded once, the loop body is 3 loads + 1 store of 16 bytes.
 template <typename T>
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__ g, const T* __restrict__ y, const T* __restrict__ x,
                                                            const float* __restrict__ cA, const float* __restrict__ cB,
@@ -295,8 +315,12 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__
   constexpr int EPS = tf::Elem<T>::kPer16B;
   const int spr = C / EPS;
   const size_t total = M * spr;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int s = (int)(i % spr);
+  const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int s = (int)(i0 % spr);
+  float A[EPS], B[EPS], D[EPS];
+#pragma unroll
+  for (int j = 0; j < EPS; ++j) { A[j] = cA[s * EPS + j]; B[j] = cB[s * EPS + j]; D[j] = cD[s * EPS + j]; }
+  for (size_t i = i0; i < total; i += (size_t)gridDim.x * 256) {
     float gf[EPS], xf[EPS], yf[EPS];
     tf::unpack16<T>(*reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(g) + i * 16), gf);
     tf::unpack16<T>(*reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(x) + i * 16), xf);
@@ -306,7 +330,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__
       for (int j = 0; j < EPS; ++j) if (!(yf[j] > 0.f)) gf[j] = 0.f;
     }
 #pragma unroll
-    for (int j = 0; j < EPS; ++j) { const int c = s * EPS + j; gf[j] = cA[c] * gf[j] + cB[c] * xf[j] + cD[c]; }
+    for (int j = 0; j < EPS; ++j) gf[j] = A[j] * gf[j] + B[j] * xf[j] + D[j];
     *reinterpret_cast<uint4*>(reinterpret_cast<char*>(out) + i * 16) = tf::pack16<T>(gf);
   }
 }
@@ -319,17 +343,20 @@ __global__ void __launch_bounds__(256) bn_add_relu_kernel(const T* __restrict__ 
   constexpr int EPS = tf::Elem<T>::kPer16B;
   const int spr = C / EPS;
   const size_t total = M * spr;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int s = (int)(i % spr);
+  const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int s = (int)(i0 % spr);
+  float a1[EPS], b1[EPS], a2[EPS], b2[EPS];
+#pragma unroll
+  for (int j = 0; j < EPS; ++j) {
+    a1[j] = s1[s * EPS + j]; b1[j] = h1[s * EPS + j];
+    a2[j] = s2 ? s2[s * EPS + j] : 1.f; b2[j] = s2 ? h2[s * EPS + j] : 0.f;
+  }
+  for (size_t i = i0; i < total; i += (size_t)gridDim.x * 256) {
     float xf[EPS], rf[EPS];
     tf::unpack16<T>(*reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(x) + i * 16), xf);
     tf::unpack16<T>(*reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(r) + i * 16), rf);
 #pragma unroll
-    for (int j = 0; j < EPS; ++j) {
-      const int c = s * EPS + j;
-      const float res = s2 ? rf[j] * s2[c] + h2[c] : rf[j];
-      xf[j] = fmaxf(xf[j] * s1[c] + h1[c] + res, 0.f);
-    }
+    for (int j = 0; j < EPS; ++j) xf[j] = fmaxf(xf[j] * a1[j] + b1[j] + (rf[j] * a2[j] + b2[j]), 0.f);
     *reinterpret_cast<uint4*>(reinterpret_cast<char*>(y) + i * 16) = tf::pack16<T>(xf);
   }
 }
@@ -341,12 +368,16 @@ __global__ void __launch_bounds__(256) bn_relu_kernel(const T* __restrict__ x, c
   constexpr int EPS = tf::Elem<T>::kPer16B;
   const int spr = C / EPS;
   const size_t total = M * spr;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int s = (int)(i % spr);
+  const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int s = (int)(i0 % spr);
+  float a[EPS], b[EPS];
+#pragma unroll
+  for (int j = 0; j < EPS; ++j) { a[j] = sc[s * EPS + j]; b[j] = sh[s * EPS + j]; }
+  for (size_t i = i0; i < total; i += (size_t)gridDim.x * 256) {
     float f[EPS];
     tf::unpack16<T>(*reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(x) + i * 16), f);
 #pragma unroll
-    for (int j = 0; j < EPS; ++j) f[j] = fmaxf(f[j] * sc[s * EPS + j] + sh[s * EPS + j], 0.f);
+    for (int j = 0; j < EPS; ++j) f[j] = fmaxf(f[j] * a[j] + b[j], 0.f);
     *reinterpret_cast<uint4*>(reinterpret_cast<char*>(y) + i * 16) = tf::pack16<T>(f);
   }
 }
@@ -475,6 +506,18 @@ extern "C" int tf_pack_weight(const float* w_oihw, int Cout, int Cin, int KH, in
   return TF_OK;
 }
 
+extern "C" int tf_pack_weights_batched(int dtype, const tf_pack_job* host_jobs, int njobs, void* stream) {
+  if (njobs < 0 || (njobs > 0 && !host_jobs)) return TF_ERR_ARG;
+  for (int j0 = 0; j0 < njobs; j0 += 64) {
+    PackJobs pj;
+    const int n = njobs - j0 < 64 ? njobs - j0 : 64;
+    for (int k = 0; k < n; ++k) pj.j[k] = host_jobs[j0 + k];
+    DISPATCH_T(dtype, hipLaunchKernelGGL(pack_batched_kernel<T>, dim3(48, n), dim3(256), 0, (hipStream_t)stream, pj));
+  }
+  TF_CHECK_LAUNCH();
+  return TF_OK;
+}
+
 extern "C" int tf_stem_im2col(const float* x_nchw, int N, int H, int W, int dtype, void* col, int ldc, void* stream) {
   if (!x_nchw || !col || ldc < 147 || ldc % 8) return TF_ERR_ARG;
   const int OH = (H + 6 - 7) / 2 + 1, OW = (W + 6 - 7) / 2 + 1;
@@ -507,10 +550,17 @@ extern "C" int tf_maxpool_bwd(int dtype, const void* g, const uint8_t* argmax, c
   return TF_OK;
 }
 
-extern "C" int tf_colstats_blocks(int M, int C, int dtype) {
+// rows handled by one colstats block: aim at ~1024 blocks (chip-filling), multiple of the rows in flight
+static int colstats_rows(int M, int C, int dtype) {
   const int eps = dtype == TF_BF16 ? 8 : 4;
-  const int rt = 256 / (C / eps);
-  int rows = 64 * (rt > 0 ? rt : 1);              // 64 row-iterations per thread
+  int rt = 256 / (C / eps);
+  if (rt < 1) rt = 1;
+  int rows = (M + 1023) / 1024;
+  rows = (rows + rt - 1) / rt * rt;
+  return rows < rt ? rt : rows;
+}
+extern "C" int tf_colstats_blocks(int M, int C, int dtype) {
+  const int rows = colstats_rows(M, C, dtype);
   return (M + rows - 1) / rows;
 }
 
@@ -520,7 +570,7 @@ extern "C" int tf_colstats(int dtype, const void* g, const void* y, const void* 
   if (!g || !partial || C % eps || C / eps > 256 || 256 % (C / eps)) return TF_ERR_ARG;
   const int nk = b ? 3 : (a ? 2 : 1);
   const int rt = 256 / (C / eps);
-  const int rows = 64 * rt;
+  const int rows = colstats_rows(M, C, dtype);
   const int nblk = (M + rows - 1) / rows;
   const size_t lds = (size_t)rt * nk * C * 4;
   if (lds > 64 * 1024) return TF_ERR_UNSUPPORTED;

@@ -285,7 +285,7 @@ class DetectionModel(nn.Module):
             table = cache[1]
         with torch.cuda.device(x.device):
             check(lib().tf_detnet_backward(self.compute_dtype, ptr(x), N, H, W, self.num_out, self._param_ptrs, table, ptr(gout),
-                                           ptr(self._ws), self._ws.numel(), stream()), "tf_detnet_backward")
+                                           ptr(gflat), gflat.numel() * 4, ptr(self._ws), self._ws.numel(), stream()), "tf_detnet_backward")
         self._last_grad_flat = gflat
         if persistent:
             return gflat
