@@ -1,0 +1,49 @@
+"""Evaluation entry point with the reference's flags (evaluate_model.py:17-31) on the MI355X hot path.
+`dataset == "synthetic"` evaluates seeded random images (no WIDER files needed); results are written in the WIDER
+submission format by write_results exactly like evaluate_model.py:47-68."""
+import argparse
+
+import torch
+
+from tinyfaces import ops, transforms
+from tinyfaces.datasets.templates import load_templates
+from tinyfaces.evaluation import get_detections, get_model, write_results
+
+
+def arguments():
+    parser = argparse.ArgumentParser("Model Evaluator")
+    parser.add_argument("dataset")
+    parser.add_argument("--split", default="val")
+    parser.add_argument("--dataset-root")
+    parser.add_argument("--checkpoint", help="The path to the model checkpoint", default="")
+    parser.add_argument("--prob_thresh", type=float, default=0.03)
+    parser.add_argument("--nms_thresh", type=float, default=0.3)
+    parser.add_argument("--workers", default=8, type=int)
+    parser.add_argument("--batch_size", default=1, type=int)
+    parser.add_argument("--results_dir", default=None)
+    parser.add_argument("--debug", action="store_true")
+    parser.add_argument("--num-images", default=4, type=int, help="synthetic dataset only")
+    return parser.parse_args()
+
+
+def main():
+    args = arguments()
+    if not torch.cuda.is_available():
+        raise SystemExit("this build of the tiny-faces hot path runs on MI355X only (no CPU fallback)")
+    device = torch.device("cuda:0")
+    templates = load_templates()
+    model = get_model(args.checkpoint, num_templates=templates.shape[0])
+    tf = transforms.Compose([transforms.ToTensor(), transforms.Normalize([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])])
+    if args.dataset != "synthetic":
+        raise SystemExit("WIDER FACE file loading is out of scope this round: use `synthetic` or call get_detections on your own images")
+    g = torch.Generator().manual_seed(0)
+    with torch.no_grad():
+        for i in range(args.num_images):
+            img = torch.rand(3, 480, 640, generator=g)
+            dets = get_detections(model, img, templates, ops.RF, tf, args.prob_thresh, args.nms_thresh, device=device)
+            write_results(dets, f"synthetic/img_{i}.jpg", args.split, args.results_dir)
+            print(f"img_{i}: {dets.shape[0]} detections")
+
+
+if __name__ == "__main__":
+    main()
