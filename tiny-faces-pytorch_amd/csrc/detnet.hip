@@ -148,7 +148,8 @@ struct Plan {                    // everything a forward carves; backward re-der
   void *w_h3, *w_h4, *w_h3t, *w_h4t, *s3, *s4; float *hbias3, *hbias4, *ones, *wup_diag;
   float* partial; size_t partial_floats;
   // backward-only
-  void *g3, *g4, *G0, *G1, *T1, *T2, *T3, *T4, *R3, *wt; float* dwp;   // gradient buffers (roles in tf_detnet_backward) + transposed-weight scratch
+  void *g3, *g4, *G0, *G1, *T4, *R3, *wt; float* dwp;
+  void *S1[2], *S2[2], *S3[2], *SD[2];   // per block parity: g_c3, g_c2, g_c1, g_d (read by the weight-gradient stream)   // gradient buffers (roles in tf_detnet_backward) + transposed-weight scratch
   int H3, W3, H4, W4;
   size_t total;
 };
@@ -217,13 +218,14 @@ void build_plan(Plan& P, Arena& ar, int dtype, int N, int H, int W, int nout, in
   P.partial = ar.f32(P.partial_floats);
   if (training) {
     P.g3 = ar.get(M3 * kHeadLd * es); P.g4 = ar.get(M4 * kHeadLd * es);
-    P.G0 = ar.get(max_act); P.G1 = ar.get(max_act); P.T1 = ar.get(max_act); P.T2 = ar.get(max_act);
-    P.T3 = ar.get(max_act); P.T4 = ar.get(max_act); P.R3 = ar.get(max_act);
+    P.G0 = ar.get(max_act); P.G1 = ar.get(max_act); P.T4 = ar.get(max_act); P.R3 = ar.get(max_act);
+    for (int k = 0; k < 2; ++k) { P.S1[k] = ar.get(max_act); P.S2[k] = ar.get(max_act); P.S3[k] = ar.get(max_act); P.SD[k] = ar.get(max_act); }
     if (packed_bytes(dtype, 1024, 1, kHeadLd) > max_wt) max_wt = packed_bytes(dtype, 1024, 1, kHeadLd);
     P.wt = ar.get(max_wt);
     P.dwp = ar.f32((size_t)256 * 9 * 256);      // packed [Cout][tap][Cin] scratch of the 3x3 weight gradients
   } else {
-    P.g3 = P.g4 = P.G0 = P.G1 = P.T1 = P.T2 = P.T3 = P.T4 = P.R3 = P.wt = nullptr; P.dwp = nullptr;
+    P.g3 = P.g4 = P.G0 = P.G1 = P.T4 = P.R3 = P.wt = nullptr; P.dwp = nullptr;
+    for (int k = 0; k < 2; ++k) P.S1[k] = P.S2[k] = P.S3[k] = P.SD[k] = nullptr;
   }
   P.total = ar.off;
 }
@@ -239,6 +241,17 @@ struct Ctx {
   int dtype; hipStream_t stream; void* const* params; void* const* grads; int rc;
   bool grads_zeroed = false;
   std::vector<tf_pack_job> jobs;
+  hipStream_t side = nullptr;                 // weight gradients run here, concurrently with the data-gradient chain
+  std::vector<hipEvent_t>* events = nullptr; size_t ev_next = 0;
+  hipEvent_t next_event() {
+    if (ev_next == events->size()) { hipEvent_t e; if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { chk(TF_ERR_LAUNCH); return nullptr; } events->push_back(e); }
+    return (*events)[ev_next++];
+  }
+  // everything enqueued on `stream` so far becomes a dependency of what is enqueued on `side` next
+  void fork() { if (!side) return; hipEvent_t e = next_event(); if (e) { (void)hipEventRecord(e, stream); (void)hipStreamWaitEvent(side, e, 0); } }
+  hipEvent_t mark_side() { if (!side) return nullptr; hipEvent_t e = next_event(); if (e) (void)hipEventRecord(e, side); return e; }
+  void wait_on_main(hipEvent_t e) { if (e) (void)hipStreamWaitEvent(stream, e, 0); }
+  hipStream_t wstream() const { return side ? side : stream; }
   void flush_packs() { if (!jobs.empty()) { chk(tf_pack_weights_batched(dtype, jobs.data(), (int)jobs.size(), stream)); jobs.clear(); } }
   const float* P(int i) const { return (const float*)params[i]; }
   float* G(int i) const { return grads ? (float*)grads[i] : nullptr; }
@@ -438,13 +451,13 @@ void wgrad(Ctx& c, const ConvUnit& u, int cout, int N, int H, int W, int OH, int
   if (k > 1 && packed_scratch) {          // 3x3: coalesced atomics into [Cout][tap][Cin], then one transposing copy to OIHW
     float* oihw = w.dw_oihw;
     w.dw_oihw = packed_scratch; w.packed = 1;
-    if (hipMemsetAsync(packed_scratch, 0, (size_t)cout * w.dw_ld * 4, c.stream) != hipSuccess) c.chk(TF_ERR_LAUNCH);   // scratch: always
-    c.chk(tf_conv2d_wgrad(&w, c.stream));
-    c.chk(tf_unpack_dw(packed_scratch, cout, cin, k * k, oihw, c.stream));
+    if (hipMemsetAsync(packed_scratch, 0, (size_t)cout * w.dw_ld * 4, c.wstream()) != hipSuccess) c.chk(TF_ERR_LAUNCH);   // scratch: always
+    c.chk(tf_conv2d_wgrad(&w, c.wstream()));
+    c.chk(tf_unpack_dw(packed_scratch, cout, cin, k * k, oihw, c.wstream()));
     return;
   }
-  if (!c.grads_zeroed && hipMemsetAsync(w.dw_oihw, 0, (size_t)cout * w.dw_ld * 4, c.stream) != hipSuccess) c.chk(TF_ERR_LAUNCH);
-  c.chk(tf_conv2d_wgrad(&w, c.stream));
+  if (!c.grads_zeroed && hipMemsetAsync(w.dw_oihw, 0, (size_t)cout * w.dw_ld * 4, c.wstream()) != hipSuccess) c.chk(TF_ERR_LAUNCH);
+  c.chk(tf_conv2d_wgrad(&w, c.wstream()));
 }
 
 }  // namespace
@@ -457,6 +470,13 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
   build_plan(P, ar, dtype, N, H, W, nout, 1);
   if (!ar.ok) return TF_ERR_WORKSPACE;
   Ctx c{dtype, (hipStream_t)stream_, params, grads, TF_OK};   // (grads_zeroed / jobs default-initialised)
+  static hipStream_t g_side = nullptr;
+  static std::vector<hipEvent_t> g_events;
+  static const bool g_single = getenv("TINYFACES_SINGLE_STREAM") != nullptr;
+  if (!g_single) {
+    if (!g_side && hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) != hipSuccess) g_side = nullptr;
+    c.side = g_side; c.events = &g_events;
+  }
   tf_conv_args a;
   const int M3 = N * P.H3 * P.W3, M4 = N * P.H4 * P.W4;
   const void* res3 = P.blk[A.layer_end[1]].y;
@@ -493,6 +513,7 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
   }
   {
     ConvUnit h3 = A.head3, h4 = A.head4;
+    c.fork();
     wgrad(c, h3, nout, N, P.H3, P.W3, P.H3, P.W3, res3, 512, P.g3, kHeadLd, nullptr);
     wgrad(c, h4, nout, N, P.H4, P.W4, P.H4, P.W4, res4, 1024, P.g4, kHeadLd, nullptr);
   }
@@ -508,6 +529,7 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
   c.chk(tf_conv2d(&a, c.stream));
 
   // ---- bottlenecks in reverse
+  std::vector<hipEvent_t> block_done(A.blocks.size(), nullptr);
   for (int i = (int)A.blocks.size() - 1; i >= 0; --i) {
     const Block& B = A.blocks[i];
     Plan::Blk& b = P.blk[i];
@@ -515,6 +537,10 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
     const int Min = N * b.Hin * b.Win, Mout = N * b.Hout * b.Wout;
     const void* yin = i == 0 ? P.pool : P.blk[i - 1].y;
     const void* extra = (i == A.layer_end[1] + 1) ? P.R3 : nullptr;     // the block whose INPUT is res3
+    const int par = i & 1;
+    void *T1 = P.S1[par], *T2 = P.S2[par], *U1 = P.S3[par], *T3 = P.SD[par];
+    // this parity's buffers were last read by the weight gradients of block i+2: wait for them
+    if (i + 2 < (int)A.blocks.size()) c.wait_on_main(block_done[i + 2]);
     // (1) per-channel sums for bn3 (and the downsample BN) with gz = g_y * (y > 0)
     const int nb = tf_colstats_blocks(Mout, c4, dtype);
     c.chk(tf_colstats(dtype, Gcur, b.y, b.c3, B.has_ds ? b.d : nullptr, Mout, c4, c4, P.partial, c.stream));
@@ -522,48 +548,53 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
     bn_backward_coefs(c, B.c3, c4, b.b3, P.partial, nb, nk, 1, c4, (float)Mout);
     if (B.has_ds) bn_backward_coefs(c, B.ds, c4, b.bd, P.partial, nb, nk, 2, c4, (float)Mout);
     // (2) g_c3 -> T1
-    c.chk(tf_bn_bwd_apply(dtype, Gcur, b.y, b.c3, b.b3.cA, b.b3.cB, b.b3.cD, Mout, c4, P.T1, c.stream));
+    c.chk(tf_bn_bwd_apply(dtype, Gcur, b.y, b.c3, b.b3.cA, b.b3.cB, b.b3.cD, Mout, c4, T1, c.stream));
+    c.fork();
     // (3) wgrad conv3 (its input is relu(bn2(c2)), re-materialised in the loader)
-    wgrad(c, B.c3, c4, N, b.Hout, b.Wout, b.Hout, b.Wout, b.c2, pl, P.T1, c4, &b.b2);
+    wgrad(c, B.c3, c4, N, b.Hout, b.Wout, b.Hout, b.Wout, b.c2, pl, T1, c4, &b.b2);
     // (4) dgrad conv3 -> gz2 in T2 (masked by relu(bn2(c2))) + BN-backward sums
-    conv_fill(a, dtype, 1, N, b.Hout, b.Wout, c4, b.Hout, b.Wout, pl, 1, 1, 0, pl, P.T1, b.w3t, P.T2);
+    conv_fill(a, dtype, 1, N, b.Hout, b.Wout, c4, b.Hout, b.Wout, pl, 1, 1, 0, pl, T1, b.w3t, T2);
     a.epi = TF_EPI_MASK | TF_EPI_STATS2; a.aux = b.c2; a.mask_scale = b.b2.scale; a.mask_shift = b.b2.shift; a.stat_out = P.partial;
     c.chk(tf_conv2d(&a, c.stream));
     bn_backward_coefs(c, B.c2, pl, b.b2, P.partial, tf_conv_mtiles(&a), 2, 1, pl, (float)Mout);
     // (5) g_c2 in place
-    c.chk(tf_bn_bwd_apply(dtype, P.T2, nullptr, b.c2, b.b2.cA, b.b2.cB, b.b2.cD, Mout, pl, P.T2, c.stream));
+    c.chk(tf_bn_bwd_apply(dtype, T2, nullptr, b.c2, b.b2.cA, b.b2.cB, b.b2.cD, Mout, pl, T2, c.stream));
+    c.fork();
     // (6) wgrad conv2 (input relu(bn1(c1)))
-    wgrad(c, B.c2, pl, N, b.Hin, b.Win, b.Hout, b.Wout, b.c1, pl, P.T2, pl, &b.b1, 0, 0, 0, P.dwp);
+    wgrad(c, B.c2, pl, N, b.Hin, b.Win, b.Hout, b.Wout, b.c1, pl, T2, pl, &b.b1, 0, 0, 0, P.dwp);
     // (7) dgrad conv2 -> gz1 in T1 (+ sums); output spatial = conv2's input
-    conv_fill(a, dtype, 1, N, b.Hout, b.Wout, pl, b.Hin, b.Win, pl, 3, B.stride, 1, pl, P.T2, b.w2t, P.T1);
+    conv_fill(a, dtype, 1, N, b.Hout, b.Wout, pl, b.Hin, b.Win, pl, 3, B.stride, 1, pl, T2, b.w2t, U1);
     a.epi = TF_EPI_MASK | TF_EPI_STATS2; a.aux = b.c1; a.mask_scale = b.b1.scale; a.mask_shift = b.b1.shift; a.stat_out = P.partial;
     c.chk(tf_conv2d(&a, c.stream));
     bn_backward_coefs(c, B.c1, pl, b.b1, P.partial, tf_conv_mtiles(&a), 2, 1, pl, (float)Min);
     // (8) g_c1 in place
-    c.chk(tf_bn_bwd_apply(dtype, P.T1, nullptr, b.c1, b.b1.cA, b.b1.cB, b.b1.cD, Min, pl, P.T1, c.stream));
+    c.chk(tf_bn_bwd_apply(dtype, U1, nullptr, b.c1, b.b1.cA, b.b1.cB, b.b1.cD, Min, pl, U1, c.stream));
+    c.fork();
     // (9) wgrad conv1 (input = block input, already activated)
-    wgrad(c, B.c1, pl, N, b.Hin, b.Win, b.Hin, b.Win, yin, B.cin, P.T1, pl, nullptr);
+    wgrad(c, B.c1, pl, N, b.Hin, b.Win, b.Hin, b.Win, yin, B.cin, U1, pl, nullptr);
     // (10) gradient w.r.t. the block input -> Gnext
     if (B.has_ds) {
-      c.chk(tf_bn_bwd_apply(dtype, Gcur, b.y, b.d, b.bd.cA, b.bd.cB, b.bd.cD, Mout, c4, P.T3, c.stream));
-      wgrad(c, B.ds, c4, N, b.Hin, b.Win, b.Hout, b.Wout, yin, B.cin, P.T3, c4, nullptr);
-      conv_fill(a, dtype, 1, N, b.Hout, b.Wout, c4, b.Hin, b.Win, B.cin, 1, B.stride, 0, B.cin, P.T3, b.wdt, P.T4);
+      c.chk(tf_bn_bwd_apply(dtype, Gcur, b.y, b.d, b.bd.cA, b.bd.cB, b.bd.cD, Mout, c4, T3, c.stream));
+      c.fork();
+      wgrad(c, B.ds, c4, N, b.Hin, b.Win, b.Hout, b.Wout, yin, B.cin, T3, c4, nullptr);
+      conv_fill(a, dtype, 1, N, b.Hout, b.Wout, c4, b.Hin, b.Win, B.cin, 1, B.stride, 0, B.cin, T3, b.wdt, P.T4);
       if (extra) { a.epi = TF_EPI_RES; a.aux = extra; }
       c.chk(tf_conv2d(&a, c.stream));
-      conv_fill(a, dtype, 1, N, b.Hin, b.Win, pl, b.Hin, b.Win, B.cin, 1, 1, 0, B.cin, P.T1, b.w1t, Gnext);
+      conv_fill(a, dtype, 1, N, b.Hin, b.Win, pl, b.Hin, b.Win, B.cin, 1, 1, 0, B.cin, U1, b.w1t, Gnext);
       a.epi = TF_EPI_RES; a.aux = P.T4;
       c.chk(tf_conv2d(&a, c.stream));
     } else {
-      conv_fill(a, dtype, 1, N, b.Hin, b.Win, pl, b.Hin, b.Win, B.cin, 1, 1, 0, B.cin, P.T1, b.w1t, Gnext);
+      conv_fill(a, dtype, 1, N, b.Hin, b.Win, pl, b.Hin, b.Win, B.cin, 1, 1, 0, B.cin, U1, b.w1t, Gnext);
       a.epi = TF_EPI_JOIN; a.aux2 = b.y; a.aux3 = Gcur;       // identity branch: + g_y * (y > 0)
       c.chk(tf_conv2d(&a, c.stream));
     }
+    block_done[i] = c.mark_side();
     void* t = Gcur; Gcur = Gnext; Gnext = t;
   }
 
   // ---- stem
   const int M1 = N * P.H1 * P.W1;
-  void* gz = P.T1;
+  void* gz = P.T4;                          // main-stream scratch (its last reader, block 0's conv1 dgrad, is ahead on this stream)
   c.chk(tf_maxpool_bwd(dtype, Gcur, P.pool_idx, P.cstem, P.bn_stem.scale, P.bn_stem.shift, N, P.H1, P.W1, 64, gz, c.stream));
   const int nb = tf_colstats_blocks(M1, 64, dtype);
   c.chk(tf_colstats(dtype, gz, nullptr, P.cstem, nullptr, M1, 64, 64, P.partial, c.stream));
@@ -572,8 +603,10 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
   c.chk(tf_stem_im2col(x, N, H, W, dtype, P.col, kStemK, c.stream));
   {
     ConvUnit s = A.stem; s.stride = 1; s.pad = 0;
+    c.fork();
     wgrad(c, s, 64, 1, 1, M1, 1, M1, P.col, kStemK, gz, 64, nullptr, 147, 1, 147);
   }
+  c.wait_on_main(c.mark_side());           // join: the caller's stream sees every weight gradient
   if (hipGetLastError() != hipSuccess && c.rc == TF_OK) c.rc = TF_ERR_LAUNCH;
   return c.rc;
 }
