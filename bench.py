@@ -160,10 +160,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    share = os.environ.get("TINYFACES_BENCH_SHARE_GPU") == "1"      # functional test of the N>1 path on a 1-GPU box (gloo, shared device)
     if world > 1:
-        parallel.init_from_env("nccl")
+        parallel.init_from_env("gloo" if share else "nccl")
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    device = torch.device(f"cuda:{local}")
+    device = torch.device(f"cuda:{local % torch.cuda.device_count() if share else local}")
     torch.cuda.set_device(device)
     _hip.lib()                                           # fail loudly if the HIP library is missing
 

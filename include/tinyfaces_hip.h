@@ -239,6 +239,8 @@ int tf_detnet_out_shape(int H, int W, int* H3, int* W3);
 int tf_detnet_forward(int dtype, int training, const float* x_nchw, int N, int H, int W, int num_out,
                       void* const* params, float bn_eps, float bn_momentum,
                       float* out_nchw, void* ws, size_t ws_bytes, void* stream);
+/* 1 (default): weight gradients run on an internal second stream concurrently with the data-gradient chain; 0: single stream */
+int tf_detnet_set_dual_stream(int on);
 /* grad_flat (optional): when every entry of `grads` lies inside [grad_flat, grad_flat + grad_flat_bytes) the whole
  * range is zeroed with ONE memset instead of one per weight gradient. */
 int tf_detnet_backward(int dtype, const float* x_nchw, int N, int H, int W, int num_out,

@@ -34,7 +34,7 @@ CONV_CASES = [
 
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("case", CONV_CASES)
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 11, 12, 13, 22, 23])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 11, 12, 13, 22, 23, 14, 15, 16, 17])
 def test_conv_forward_plain(dtype, case, tile):
     from tinyfaces import ops
     N, H, W, Cin, Cout, K, s, p = case

@@ -359,7 +359,7 @@ int pick_tile(const tf_conv_args* a) {
   if (!a->pro_scale) return 13;                   // LDS-DMA pipeline, 64x64 tiles, 3-deep ring: fastest on every layer shape
   return t2 >= 256 ? 2 : 3;                       // producer-BN prologue needs the register-staged kernel
 }
-int tile_bm(int t) { return (t % 10) == 3 ? 64 : 128; }
+int tile_bm(int t) { const int k = t % 10; return (k == 3 || k == 4 || k == 5) ? 64 : 128; }
 
 }  // namespace
 

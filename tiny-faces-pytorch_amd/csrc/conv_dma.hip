@@ -323,6 +323,12 @@ int launch(const tf_conv_args* A, hipStream_t stream) {
 
 // tile: 1 = 128x128, 2 = 128x64, 3 = 64x64 (pixels x channels); depth: ring stages (3 or 4)
 int tf_conv_dma_launch(const tf_conv_args* a, int tile, int depth, hipStream_t stream) {
+  if (a->dtype == TF_BF16 && tile >= 4) {          // experimental wide tiles (bf16 only): 4 = 64x128/3, 5 = 64x256/2, 6 = 128x128/4, 7 = 128x256/2
+    if (tile == 4) return launch<tf::bf16_t, 64, 128, 3>(a, stream);
+    if (tile == 5) return launch<tf::bf16_t, 64, 256, 2>(a, stream);
+    if (tile == 6) return launch<tf::bf16_t, 128, 128, 4>(a, stream);
+    return launch<tf::bf16_t, 128, 256, 2>(a, stream);
+  }
   if (a->dtype == TF_BF16) {
     if (tile == 1) return launch<tf::bf16_t, 128, 128, 3>(a, stream);
     if (tile == 2) return depth == 4 ? launch<tf::bf16_t, 128, 64, 4>(a, stream) : launch<tf::bf16_t, 128, 64, 3>(a, stream);

@@ -462,6 +462,10 @@ void wgrad(Ctx& c, const ConvUnit& u, int cout, int N, int H, int W, int OH, int
 
 }  // namespace
 
+static bool g_force_single = false;
+// 1 = weight gradients on a second stream (default), 0 = everything on the caller's stream (A/B + race tests)
+extern "C" int tf_detnet_set_dual_stream(int on) { g_force_single = !on; return TF_OK; }
+
 extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W, int nout, void* const* params, void* const* grads,
                                   const float* gout, void* grad_flat, size_t grad_flat_bytes, void* ws, size_t ws_bytes, void* stream_) {
   if (!x || !params || !grads || !gout || !ws) return TF_ERR_ARG;
@@ -472,8 +476,8 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
   Ctx c{dtype, (hipStream_t)stream_, params, grads, TF_OK};   // (grads_zeroed / jobs default-initialised)
   static hipStream_t g_side = nullptr;
   static std::vector<hipEvent_t> g_events;
-  static const bool g_single = getenv("TINYFACES_SINGLE_STREAM") != nullptr;
-  if (!g_single) {
+  static const bool g_single_env = getenv("TINYFACES_SINGLE_STREAM") != nullptr;
+  if (!g_single_env && !g_force_single) {
     if (!g_side && hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) != hipSuccess) g_side = nullptr;
     c.side = g_side; c.events = &g_events;
   }

@@ -85,6 +85,7 @@ _SIGNATURES = {
     "tf_detnet_forward": (i32, [i32, i32, vp, i32, i32, i32, i32, vp, f32, f32, vp, vp, sz, vp]),
     "tf_detnet_backward": (i32, [i32, vp, i32, i32, i32, i32, vp, vp, vp, vp, sz, vp, sz, vp]),
     "tf_pack_weights_batched": (i32, [i32, vp, i32, vp]),
+    "tf_detnet_set_dual_stream": (i32, [i32]),
     "tf_probe_tr16": (i32, [vp, vp]),
     "tf_profile_enable": (i32, [i32]),
     "tf_profile_collect": (i32, [C.POINTER(C.c_double), i32]),
