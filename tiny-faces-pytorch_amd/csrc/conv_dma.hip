@@ -91,7 +91,9 @@ __device__ __forceinline__ void dma16(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((glb_void*)gsrc, (lds_void*)lds_wave_base, 16, 0, 0);
 }
 
-template <typename T, int BM, int BN, int NS>
+// KIND: 1 = pointwise GEMM (1x1, stride 1, pad 0: forward or data-gradient, no per-stage address logic at all),
+//       0 = generic forward gather, 2 = generic transposed gather (data gradient of a KxK / strided conv)
+template <typename T, int BM, int BN, int NS, int KIND>
 __global__ void __launch_bounds__(256) conv_dma_kernel(const DmaK a) {
   constexpr int KCH = MmaD<T>::KCH;
   constexpr int EPS = tf::Elem<T>::kPer16B;
@@ -111,19 +113,29 @@ __global__ void __launch_bounds__(256) conv_dma_kernel(const DmaK a) {
   const int tid = threadIdx.x, lrow = tid >> 3, pslot = tid & 7;
   const int wave_byte = (tid & ~63) * 16;            // LDS byte offset of this wave's 1 KiB piece inside a 256-thread pass
 
-  // logical slot that must land in physical slot pslot of each of this thread's rows (swizzle on the source)
-  int rb_n[XR], rb_h[XR], rb_w[XR], xslot[XR];
+  // Per-row gather state, fixed for the whole K loop.  Physical LDS slot pslot of row r must receive logical slot
+  // pslot^h(r) (swizzle on the SOURCE).  Padded taps / rows past M read the zero page.
+  const char* zero = reinterpret_cast<const char*>(g_zero_page) + pslot * 16;
+  const char* rowptr[XR];       // KIND 1: running source pointer;  else: pointer of tap (0,0) / channel chunk 0
+  int rstep[XR];                // KIND 1: bytes to advance per stage (0 for rows on the zero page)
+  int rb_h[XR], rb_w[XR];
 #pragma unroll
   for (int i = 0; i < XR; ++i) {
     const int row = lrow + i * 32;
-    xslot[i] = pslot ^ swz(row);
+    const int xs_ = (pslot ^ swz(row)) * 16;
     const int p = m0 + row;
+    rowptr[i] = zero; rstep[i] = 0; rb_h[i] = -(1 << 28); rb_w[i] = -(1 << 28);
     if (p < a.M) {
-      const int n = p / a.OHW, rem = p - n * a.OHW, oh = rem / a.OW, ow = rem - oh * a.OW;
-      rb_n[i] = n * a.H * a.W;
-      if (a.mode == 0) { rb_h[i] = oh * a.stride - a.pad; rb_w[i] = ow * a.stride - a.pad; }
-      else             { rb_h[i] = oh + a.pad;            rb_w[i] = ow + a.pad; }
-    } else { rb_n[i] = 0; rb_h[i] = -(1 << 28); rb_w[i] = -(1 << 28); }
+      if (KIND == 1) {
+        rowptr[i] = a.x + (size_t)p * a.Cin * sizeof(T) + xs_;
+        rstep[i] = KCH * (int)sizeof(T);
+      } else {
+        const int n = p / a.OHW, rem = p - n * a.OHW, oh = rem / a.OW, ow = rem - oh * a.OW;
+        if (KIND == 0) { rb_h[i] = oh * a.stride - a.pad; rb_w[i] = ow * a.stride - a.pad; }
+        else           { rb_h[i] = oh + a.pad;            rb_w[i] = ow + a.pad; }
+        rowptr[i] = a.x + (size_t)n * a.H * a.W * a.Cin * sizeof(T) + xs_;
+      }
+    }
   }
   const char* wsrc[WR];
 #pragma unroll
@@ -131,33 +143,38 @@ __global__ void __launch_bounds__(256) conv_dma_kernel(const DmaK a) {
     const int row = lrow + i * 32;
     wsrc[i] = a.w + ((size_t)(n0 + row) * a.Ktot + (pslot ^ swz(row)) * EPS) * sizeof(T);
   }
-  const char* zero = reinterpret_cast<const char*>(g_zero_page) + pslot * 16;
 
-  auto issue = [&](int st) {
-    char* xs = smem + (st % NS) * BUF;
+  // stage iterator (scalar): stages are issued in order, so (slot, chunk, kw, kh) advance incrementally
+  int is_slot = 0, is_c = 0, is_kw = 0, is_kh = 0;
+  auto issue = [&]() {
+    char* xs = smem + is_slot * BUF;
     char* ws = xs + XBYTES;
-    const int tap = st / a.cpt, cin0 = (st - tap * a.cpt) * KCH;
-    const int kh = tap / a.KW, kw = tap - kh * a.KW;
+    if (KIND == 1) {
 #pragma unroll
-    for (int i = 0; i < XR; ++i) {
-      int ih, iw; bool ok;
-      if (a.mode == 0) {
-        ih = rb_h[i] + kh; iw = rb_w[i] + kw;
-        ok = (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
-      } else {
-        const int th = rb_h[i] - kh, tw = rb_w[i] - kw, smask = (1 << a.sshift) - 1;
-        ih = th >> a.sshift; iw = tw >> a.sshift;
-        ok = th >= 0 && tw >= 0 && !(th & smask) && !(tw & smask) && ih < a.H && iw < a.W;
+      for (int i = 0; i < XR; ++i) { dma16(rowptr[i], xs + i * 4096 + wave_byte); rowptr[i] += rstep[i]; }
+    } else {
+      const int cin_b = is_c * KCH * (int)sizeof(T);
+#pragma unroll
+      for (int i = 0; i < XR; ++i) {
+        int ih, iw; bool ok;
+        if (KIND == 0) {
+          ih = rb_h[i] + is_kh; iw = rb_w[i] + is_kw;
+          ok = (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+        } else {
+          const int th = rb_h[i] - is_kh, tw = rb_w[i] - is_kw, smask = (1 << a.sshift) - 1;
+          ih = th >> a.sshift; iw = tw >> a.sshift;
+          ok = (th | tw) >= 0 && !((th | tw) & smask) && ih < a.H && iw < a.W;
+        }
+        const int pix = ok ? ih * a.W + iw : 0;
+        const uintptr_t real = reinterpret_cast<uintptr_t>(rowptr[i]) + (size_t)pix * a.Cin * sizeof(T) + cin_b;
+        const uintptr_t src = ok ? real : reinterpret_cast<uintptr_t>(zero);
+        dma16(reinterpret_cast<const void*>(src), xs + i * 4096 + wave_byte);
       }
-      // branch-free: compute the (clamped) address unconditionally, then select against the zero page
-      const int ihc = ok ? ih : 0, iwc = ok ? iw : 0;
-      const uintptr_t real = reinterpret_cast<uintptr_t>(a.x) +
-                             (((size_t)(rb_n[i] + ihc * a.W + iwc)) * a.Cin + cin0 + xslot[i] * EPS) * sizeof(T);
-      const uintptr_t src = ok ? real : reinterpret_cast<uintptr_t>(zero);
-      dma16(reinterpret_cast<const void*>(src), xs + i * 4096 + wave_byte);
     }
 #pragma unroll
-    for (int i = 0; i < WR; ++i) dma16(wsrc[i] + (size_t)st * KCH * sizeof(T), ws + i * 4096 + wave_byte);
+    for (int i = 0; i < WR; ++i) { dma16(wsrc[i], ws + i * 4096 + wave_byte); wsrc[i] += KCH * sizeof(T); }
+    if (++is_slot == NS) is_slot = 0;
+    if (KIND != 1 && ++is_c == a.cpt) { is_c = 0; if (++is_kw == a.KW) { is_kw = 0; ++is_kh; } }
   };
 
   f32x4 acc[NF][MF];
@@ -170,7 +187,8 @@ __global__ void __launch_bounds__(256) conv_dma_kernel(const DmaK a) {
   const int nst = a.nstages;
 #pragma unroll
   for (int j = 0; j < NS - 1; ++j)
-    if (j < nst) issue(j);
+    if (j < nst) issue();
+  int cs = 0;                                        // ring slot being computed
   for (int st = 0; st < nst; ++st) {
     // stage st has landed once at most min(NS-2, nst-1-st) younger stages are still in flight
     const int younger = nst - 1 - st;
@@ -178,9 +196,10 @@ __global__ void __launch_bounds__(256) conv_dma_kernel(const DmaK a) {
     else if (NS > 3 && younger == 1) wait_vmcnt<L>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();                   // everyone's pieces of stage st landed; ring slot (st-1)%NS is free
-    if (st + NS - 1 < nst) issue(st + NS - 1);
-    const char* xs = smem + (st % NS) * BUF;
+    if (st + NS - 1 < nst) issue();
+    const char* xs = smem + cs * BUF;
     MmaD<T>::template stage<NF, MF>(xs, xs + XBYTES, wm * WM, wn * WN, acc);
+    if (++cs == NS) cs = 0;
   }
   __builtin_amdgcn_s_barrier();                     // all waves done reading the ring -> reuse it as the staging tile
 
@@ -286,8 +305,8 @@ __global__ void __launch_bounds__(256) conv_dma_kernel(const DmaK a) {
   }
 }
 
-template <typename T, int BM, int BN, int NS>
-int launch(const tf_conv_args* A, hipStream_t stream) {
+template <typename T, int BM, int BN, int NS, int KIND>
+int launch_kind(const tf_conv_args* A, hipStream_t stream) {
   constexpr int KCH = MmaD<T>::KCH;
   DmaK k;
   k.x = (const char*)A->x; k.w = (const char*)A->w; k.y = (char*)A->y;
@@ -305,7 +324,7 @@ int launch(const tf_conv_args* A, hipStream_t stream) {
   if (stg > lds) lds = stg;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<T, BM, BN, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<T, BM, BN, NS, KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   {
@@ -314,9 +333,16 @@ int launch(const tf_conv_args* A, hipStream_t stream) {
     if (A->epi & (TF_EPI_RES | TF_EPI_MASK | TF_EPI_STATS2)) bytes += M * A->Cout * es;
     if (A->epi & TF_EPI_JOIN) bytes += 2 * M * A->Cout * es;
     tf::ProfScope prof((sizeof(T) == 2 ? 3 : 0) + (BM == 64 ? 2 : (BN == 64 ? 1 : 0)), 2.0 * M * A->Cout * Kt, bytes, stream);
-    hipLaunchKernelGGL((conv_dma_kernel<T, BM, BN, NS>), dim3(mtiles * k.ntiles), dim3(256), lds, stream, k);
+    hipLaunchKernelGGL((conv_dma_kernel<T, BM, BN, NS, KIND>), dim3(mtiles * k.ntiles), dim3(256), lds, stream, k);
   }
   return hipGetLastError() == hipSuccess ? TF_OK : TF_ERR_LAUNCH;
+}
+
+template <typename T, int BM, int BN, int NS>
+int launch(const tf_conv_args* A, hipStream_t stream) {
+  const bool pointwise = A->KH == 1 && A->KW == 1 && A->stride == 1 && A->pad == 0 && A->H == A->OH && A->W == A->OW;
+  if (pointwise) return launch_kind<T, BM, BN, NS, 1>(A, stream);
+  return A->mode == 0 ? launch_kind<T, BM, BN, NS, 0>(A, stream) : launch_kind<T, BM, BN, NS, 2>(A, stream);
 }
 
 }  // namespace
