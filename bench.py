@@ -33,7 +33,8 @@ PEAK_HBM_GBS = 8000.0
 FWD_GFLOP_PER_IMG = 73.559                           # BASELINE.md section 3 (2*MACs of all 97 convs @500x500)
 KIND_NAMES = {0: "conv_igemm<f32,128x128>", 1: "conv_igemm<f32,128x64>", 2: "conv_igemm<f32,64x64>",
               3: "conv_igemm<bf16,128x128>", 4: "conv_igemm<bf16,128x64>", 5: "conv_igemm<bf16,64x64>",
-              8: "wgrad<f32,64>", 9: "wgrad<f32,128>", 10: "wgrad<bf16,64>", 11: "wgrad<bf16,128>"}
+              8: "wgrad<f32,64>", 9: "wgrad<f32,128>", 10: "wgrad<bf16,64>", 11: "wgrad<bf16,128>",
+              12: "conv_dma<f32,64x64x3>", 13: "conv_dma<bf16,64x64x3>", 14: "wgrad_dma<bf16,64x64x3>"}
 
 
 def tame_init_(model, seed=0):
@@ -224,7 +225,7 @@ def main():
            "step_tflops": round(3 * FWD_GFLOP_PER_IMG * args.batch / ms_per_step, 2)}
     if prof:
         dom = max(prof, key=lambda r: r["ms"])
-        peak = PEAK_TFLOPS["bf16" if dom["kind"] in (3, 4, 5, 10, 11) else "fp32"]
+        peak = PEAK_TFLOPS["bf16" if dom["kind"] in (3, 4, 5, 10, 11, 13, 14) else "fp32"]
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         out["roofline"] = {"kernel": KIND_NAMES.get(dom["kind"], str(dom["kind"])), "bound": "mfma", "achieved": round(ach, 2), "peak": peak,
                            "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None, "launches": dom["launches"],

@@ -252,7 +252,8 @@ int tf_detnet_backward(int dtype, const float* x_nchw, int N, int H, int W, int 
  * While enabled, every MFMA kernel launch (conv_igemm / wgrad) is bracketed by HIP events on
  * the stream it is launched on.  tf_profile_collect blocks until they completed and writes
  * rows of 5 doubles to HOST memory: kind, launches, total_ms, algorithmic flops, algorithmic
- * bytes.  kind 0..5 = conv (dtype*3 + tile-1), 8..11 = wgrad (8 + dtype*2 + (tile==128)). */
+ * bytes.  kind 0..5 = conv_igemm (dtype*3 + tile-1), 8..11 = wgrad (8 + dtype*2 + (tile==128)),
+ * 12/13 = conv_dma f32/bf16, 14 = wgrad_dma bf16. */
 int tf_profile_enable(int on);
 int tf_profile_collect(double* host_out, int max_rows);
 /* test hook: raw lane mapping of ds_read_b64_tr_b16 (see tests/test_gpu_small_ops.py) */

@@ -42,9 +42,9 @@ for name, H, W, Cin, Cout, K, s in LAYERS:
         print(line, flush=True)
     if which in ("wgrad", "all"):
         out = torch.zeros(Cout, Cin, K, K, device="cuda")
-        for tile in (64, 128):
+        for tile in (64, 1):
             line = f"{name:6s} wgrad tile{tile:3d}"
-            for sk in (0, 1, 2, 4, 8, 16, 32, 64):
-                us = timeit(lambda: ops.conv2d_wgrad(x, gy, Cin, Cout, K, K, s, p, splitk=sk, tile=tile, out=out))
+            for sk in (0, 4, 8, 16, 32):
+                us = timeit(lambda: ops.conv2d_wgrad(x, gy, Cin, Cout, K, K, s, p, splitk=sk, tile=tile, out=out, packed=(K > 1)))
                 line += f" | sk{sk}: {us:6.1f}us {flops/us/1e6:5.0f}TF"
             print(line, flush=True)

@@ -164,6 +164,8 @@ def test_conv_dgrad_mask_stats2_and_join(dtype, tile):
 
 WG_CASES = [
     # N, H, W, Cin, Cout, K, stride
+    (1, 9, 7, 64, 64, 1, 1),
+    (2, 33, 35, 128, 64, 3, 1),
     (2, 20, 22, 64, 64, 3, 1),
     (2, 21, 19, 128, 128, 3, 2),
     (3, 30, 30, 256, 1024, 1, 1),
@@ -173,9 +175,10 @@ WG_CASES = [
 ]
 
 
+@pytest.mark.parametrize("tile", [0, 64, 128])
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("case", WG_CASES)
-def test_wgrad(dtype, case):
+def test_wgrad(dtype, case, tile):
     from tinyfaces import ops
     N, H, W, Cin, Cout, K, s = case
     p = K // 2
@@ -185,9 +188,9 @@ def test_wgrad(dtype, case):
     y = F.conv2d(q(x, dtype), w, stride=s, padding=p)
     gy = torch.randn(y.shape, generator=g)
     y.backward(q(gy, dtype))
-    dw = ops.conv2d_wgrad(to_nhwc(x, dtype), to_nhwc(gy, dtype), Cin, Cout, K, K, s, p)
+    dw = ops.conv2d_wgrad(to_nhwc(x, dtype), to_nhwc(gy, dtype), Cin, Cout, K, K, s, p, tile=tile)
     d = err(dw.cpu(), w.grad)
-    report(f"wgrad[{dtype},{case}]", maxabs=d[0], rel=d[2])
+    report(f"wgrad[{dtype},{case},t{tile}]", maxabs=d[0], rel=d[2])
     assert d[2] < (5e-5 if dtype == torch.float32 else 2e-3)
 
 
@@ -213,6 +216,14 @@ def test_wgrad_with_prologue_and_padded_head(dtype):
     y2.backward(q(gy2, dtype))
     gy2p = torch.cat([gy2, torch.zeros(N, 3, H, W)], 1)
     dw2 = ops.conv2d_wgrad(to_nhwc(x2, dtype), to_nhwc(gy2p, dtype), 512, 125, 1, 1, 1, 0)
+    x3 = torch.randn(N, 192, H, W, generator=g); x3[:, 147:] = 0          # stem im2col shape: Cin 147 stored with ldx 192
+    w3 = (torch.randn(64, 147, 1, 1, generator=g) * 0.05).requires_grad_(True)
+    y3 = F.conv2d(q(x3[:, :147], dtype), w3)
+    gy3 = torch.randn(y3.shape, generator=g)
+    y3.backward(q(gy3, dtype))
+    dw3 = ops.conv2d_wgrad(to_nhwc(x3, dtype), to_nhwc(gy3, dtype), 147, 64, 1, 1, 1, 0)
+    d3 = err(dw3.cpu(), w3.grad)
+    assert d3[2] < (5e-5 if dtype == torch.float32 else 3e-3)
     d2 = err(dw2.cpu(), w2.grad)
     report(f"wgrad_pro_head[{dtype}]", rel=d[2], head_rel=d2[2])
     tol = 5e-5 if dtype == torch.float32 else 3e-3

@@ -332,7 +332,7 @@ int launch_kind(const tf_conv_args* A, hipStream_t stream) {
     double bytes = ((double)A->N * A->H * A->W * A->Cin + (double)A->Cout * Kt + M * A->Cout) * es;
     if (A->epi & (TF_EPI_RES | TF_EPI_MASK | TF_EPI_STATS2)) bytes += M * A->Cout * es;
     if (A->epi & TF_EPI_JOIN) bytes += 2 * M * A->Cout * es;
-    tf::ProfScope prof((sizeof(T) == 2 ? 3 : 0) + (BM == 64 ? 2 : (BN == 64 ? 1 : 0)), 2.0 * M * A->Cout * Kt, bytes, stream);
+    tf::ProfScope prof(sizeof(T) == 2 ? 13 : 12, 2.0 * M * A->Cout * Kt, bytes, stream);   // 12 = conv_dma f32, 13 = conv_dma bf16
     hipLaunchKernelGGL((conv_dma_kernel<T, BM, BN, NS, KIND>), dim3(mtiles * k.ntiles), dim3(256), lds, stream, k);
   }
   return hipGetLastError() == hipSuccess ? TF_OK : TF_ERR_LAUNCH;

@@ -140,6 +140,7 @@ struct Plan {                    // everything a forward carves; backward re-der
   struct Blk {
     int Hin, Win, Hout, Wout;
     void *c1, *c2, *c3, *d, *y;
+    void *a1, *a2;                   // relu(bn1(c1)), relu(bn2(c2)) materialised in training (operands of conv2/conv3 and of their weight gradients)
     void *w1, *w2, *w3, *wd;         // packed forward weights
     void *w1t, *w2t, *w3t, *wdt;     // packed data-gradient (transposed) weights, training only
     BnBuf b1, b2, b3, bd;
@@ -181,6 +182,7 @@ void build_plan(Plan& P, Arena& ar, int dtype, int N, int H, int W, int nout, in
     const size_t Min = (size_t)N * h * w, Mout = (size_t)N * b.Hout * b.Wout;
     const int pl = B.planes, c4 = pl * 4;
     b.c1 = ar.get(Min * pl * es); b.c2 = ar.get(Mout * pl * es);
+    b.a1 = training ? ar.get(Min * pl * es) : nullptr; b.a2 = training ? ar.get(Mout * pl * es) : nullptr;
     b.c3 = training ? ar.get(Mout * c4 * es) : nullptr;
     b.d = B.has_ds ? ar.get(Mout * c4 * es) : nullptr;
     b.y = ar.get(Mout * c4 * es);
@@ -205,7 +207,7 @@ void build_plan(Plan& P, Arena& ar, int dtype, int N, int H, int W, int nout, in
   const Plan::Blk& l3 = P.blk[A.layer_end[2]];
   P.H3 = l2.Hout; P.W3 = l2.Wout; P.H4 = l3.Hout; P.W4 = l3.Wout;
   const size_t M3 = (size_t)N * P.H3 * P.W3, M4 = (size_t)N * P.H4 * P.W4;
-  P.a1tmp = ar.get(training ? max_act : 0);       // relu(bn1(c1)) of the current block (3x3 conv operand, not kept)
+  P.a1tmp = nullptr;
   P.w_h3 = ar.get(packed_bytes(dtype, kHeadLd, 1, 512)); P.w_h4 = ar.get(packed_bytes(dtype, kHeadLd, 1, 1024));
   P.w_h3t = training ? ar.get(packed_bytes(dtype, 512, 1, kHeadLd)) : nullptr;
   P.w_h4t = training ? ar.get(packed_bytes(dtype, 1024, 1, kHeadLd)) : nullptr;
@@ -383,8 +385,8 @@ extern "C" int tf_detnet_forward(int dtype, int training, const float* x, int N,
     c.chk(tf_conv2d(&a, c.stream));
     if (tr) bn_forward(c, B.c1, pl, b.b1, true, &a, P.partial, (float)Min, eps, mom);
     // conv2 3x3 (stride here)
-    if (tr) c.chk(tf_bn_relu(dtype, b.c1, b.b1.scale, b.b1.shift, Min, pl, P.a1tmp, c.stream));   // un-fused on purpose: lets the 3x3 use the DMA pipeline
-    conv_fill(a, dtype, 0, N, b.Hin, b.Win, pl, b.Hout, b.Wout, pl, 3, B.stride, 1, pl, tr ? P.a1tmp : b.c1, b.w2, b.c2);
+    if (tr) c.chk(tf_bn_relu(dtype, b.c1, b.b1.scale, b.b1.shift, Min, pl, b.a1, c.stream));   // un-fused on purpose: every consumer uses the DMA pipeline
+    conv_fill(a, dtype, 0, N, b.Hin, b.Win, pl, b.Hout, b.Wout, pl, 3, B.stride, 1, pl, tr ? b.a1 : b.c1, b.w2, b.c2);
     if (tr) { a.epi = TF_EPI_STATS; a.stat_out = P.partial; }
     else { bn_forward(c, B.c2, pl, b.b2, false, nullptr, nullptr, 0, eps, mom); a.epi = TF_EPI_AFFINE | TF_EPI_RELU; a.epi_scale = b.b2.scale; a.epi_shift = b.b2.shift; }
     c.chk(tf_conv2d(&a, c.stream));
@@ -398,8 +400,9 @@ extern "C" int tf_detnet_forward(int dtype, int training, const float* x, int N,
       if (tr) bn_forward(c, B.ds, c4, b.bd, true, &a, P.partial, (float)Mout, eps, mom);
     }
     // conv3 1x1 (+ BN + residual + ReLU)
-    conv_fill(a, dtype, 0, N, b.Hout, b.Wout, pl, b.Hout, b.Wout, c4, 1, 1, 0, c4, b.c2, b.w3, tr ? b.c3 : b.y);
-    if (tr) { a.pro_scale = b.b2.scale; a.pro_shift = b.b2.shift; a.pro_relu = 1; a.epi = TF_EPI_STATS; a.stat_out = P.partial; }
+    if (tr) c.chk(tf_bn_relu(dtype, b.c2, b.b2.scale, b.b2.shift, Mout, pl, b.a2, c.stream));
+    conv_fill(a, dtype, 0, N, b.Hout, b.Wout, pl, b.Hout, b.Wout, c4, 1, 1, 0, c4, tr ? b.a2 : b.c2, b.w3, tr ? b.c3 : b.y);
+    if (tr) { a.epi = TF_EPI_STATS; a.stat_out = P.partial; }
     else {
       bn_forward(c, B.c3, c4, b.b3, false, nullptr, nullptr, 0, eps, mom);
       a.epi = TF_EPI_AFFINE | TF_EPI_RES | TF_EPI_RELU; a.epi_scale = b.b3.scale; a.epi_shift = b.b3.shift; a.aux = B.has_ds ? b.d : yin;
@@ -555,7 +558,7 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
     c.chk(tf_bn_bwd_apply(dtype, Gcur, b.y, b.c3, b.b3.cA, b.b3.cB, b.b3.cD, Mout, c4, T1, c.stream));
     c.fork();
     // (3) wgrad conv3 (its input is relu(bn2(c2)), re-materialised in the loader)
-    wgrad(c, B.c3, c4, N, b.Hout, b.Wout, b.Hout, b.Wout, b.c2, pl, T1, c4, &b.b2);
+    wgrad(c, B.c3, c4, N, b.Hout, b.Wout, b.Hout, b.Wout, b.a2, pl, T1, c4, nullptr);
     // (4) dgrad conv3 -> gz2 in T2 (masked by relu(bn2(c2))) + BN-backward sums
     conv_fill(a, dtype, 1, N, b.Hout, b.Wout, c4, b.Hout, b.Wout, pl, 1, 1, 0, pl, T1, b.w3t, T2);
     a.epi = TF_EPI_MASK | TF_EPI_STATS2; a.aux = b.c2; a.mask_scale = b.b2.scale; a.mask_shift = b.b2.shift; a.stat_out = P.partial;
@@ -565,7 +568,7 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
     c.chk(tf_bn_bwd_apply(dtype, T2, nullptr, b.c2, b.b2.cA, b.b2.cB, b.b2.cD, Mout, pl, T2, c.stream));
     c.fork();
     // (6) wgrad conv2 (input relu(bn1(c1)))
-    wgrad(c, B.c2, pl, N, b.Hin, b.Win, b.Hout, b.Wout, b.c1, pl, T2, pl, &b.b1, 0, 0, 0, P.dwp);
+    wgrad(c, B.c2, pl, N, b.Hin, b.Win, b.Hout, b.Wout, b.a1, pl, T2, pl, nullptr, 0, 0, 0, P.dwp);
     // (7) dgrad conv2 -> gz1 in T1 (+ sums); output spatial = conv2's input
     conv_fill(a, dtype, 1, N, b.Hout, b.Wout, pl, b.Hin, b.Win, pl, 3, B.stride, 1, pl, T2, b.w2t, U1);
     a.epi = TF_EPI_MASK | TF_EPI_STATS2; a.aux = b.c1; a.mask_scale = b.b1.scale; a.mask_shift = b.b1.shift; a.stat_out = P.partial;
