@@ -136,6 +136,12 @@ int tf_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n,
 #define TF_EPI_MASK 16
 #define TF_EPI_STATS2 32
 #define TF_EPI_JOIN 64
+/* partial-sum rows of one launch are folded (atomics) into at most this many rows; consumers pass clear=1 to the
+ * last finalize that reads them so that the buffer is zero again for the next producer */
+#define TF_STAT_ROWS 64
+/* rows <= 0: do not fold (one partial row per tile / block, plain stores: bit-reproducible statistics); default TF_STAT_ROWS */
+int tf_set_stat_rows(int rows);
+int tf_get_stat_rows(void);
 
 typedef struct tf_conv_args {
   int dtype, mode;
@@ -152,7 +158,7 @@ typedef struct tf_conv_args {
   int tile;           /* 0 = auto; else 1:(128x128) 2:(128x64) 3:(64x64) pixels x channels */
 } tf_conv_args;
 
-int tf_conv_mtiles(const tf_conv_args* a);
+int tf_conv_mtiles(const tf_conv_args* a);   /* rows of stat_out this launch writes (<= TF_STAT_ROWS for the DMA kernel) */
 int tf_conv2d(const tf_conv_args* a, void* stream);
 
 /* OIHW fp32 -> packed [CoutPad][KH*KW][CinPad] (dtype); transpose=1 packs the data-gradient
@@ -201,14 +207,14 @@ int tf_colstats(int dtype, const void* g, const void* y, const void* a, const vo
  * -> y = x*scale + shift, saved mean / invstd, running statistics (momentum, unbiased var). */
 int tf_bn_finalize(const float* partial, int nblk, int ld, int C, float count, const float* gamma, const float* beta,
                    float eps, float momentum, float* scale, float* shift, float* mean, float* invstd,
-                   float* running_mean, float* running_var, void* stream);
+                   float* running_mean, float* running_var, int clear, void* stream);
 /* eval-mode BN as a per-channel affine (folded into the conv epilogue) */
 int tf_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
                int C, float* scale, float* shift, void* stream);
 /* BN backward: partial sums (k0 = sum gz, kidx = sum gz*x) -> dgamma, dbeta and g_x = A*gz + B*x + D */
 int tf_bn_bwd_finalize(const float* partial, int nblk, int nk, int kidx, int ld, int C, float count, const float* gamma,
                        const float* mean, const float* invstd, float* dgamma, float* dbeta, float* cA, float* cB,
-                       float* cD, void* stream);
+                       float* cD, int clear, void* stream);
 int tf_bn_bwd_apply(int dtype, const void* g, const void* y, const void* x, const float* cA, const float* cB,
                     const float* cD, int64_t M, int C, void* out, void* stream);
 /* y = relu(x*scale + shift): BN + ReLU materialised for the 3x3 conv's LDS-DMA operand pipeline */
@@ -222,7 +228,7 @@ int tf_upsample_add_crop(int dtype, const void* s3, const void* s4, const float*
                          int H3, int W3, int H4, int W4, float* out_nchw, void* stream);
 int tf_upsample_add_crop_bwd(int dtype, const float* g_nchw, const float* wup_diag, int B, int C, int ldc,
                              int H3, int W3, int H4, int W4, void* g3, void* g4, void* stream);
-int tf_reduce_partials(const float* partial, int nblk, int nk, int k, int ld, int C, float* out, void* stream);
+int tf_reduce_partials(const float* partial, int nblk, int nk, int k, int ld, int C, float* out, int clear, void* stream);
 
 /* ---- the detector network as one native graph executor -----------------------------
  * Replaces DetectionModel.forward (tinyfaces/models/model.py:89-128) and its autograd

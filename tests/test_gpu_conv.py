@@ -34,7 +34,7 @@ CONV_CASES = [
 
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("case", CONV_CASES)
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 11, 12, 13, 22, 23, 14, 15, 16, 17])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 11, 12, 13, 22, 23])
 def test_conv_forward_plain(dtype, case, tile):
     from tinyfaces import ops
     N, H, W, Cin, Cout, K, s, p = case
@@ -297,7 +297,7 @@ def test_bn_train_forward_backward_chain(dtype):
     scale, shift, mean, invstd, dga, dbe, cA, cB, cD = bufs
     gd, bd = gamma.cuda(), beta.cuda()
     assert lib().tf_bn_finalize(ptr(part), nb, C, C, float(M), ptr(gd), ptr(bd), 1e-5, 0.1, ptr(scale), ptr(shift), ptr(mean), ptr(invstd),
-                                ptr(rmd), ptr(rvd), stream()) == 0
+                                ptr(rmd), ptr(rvd), 0, stream()) == 0
     y_d = torch.empty_like(x_d)
     assert lib().tf_bn_add_relu(tfd, ptr(x_d), ptr(scale), ptr(shift), ptr(id_d), None, None, M, C, ptr(y_d), stream()) == 0
     dy = err(from_nhwc(y_d), yref.detach())
@@ -306,7 +306,7 @@ def test_bn_train_forward_backward_chain(dtype):
     part3 = torch.zeros(nb, 2, C, device="cuda")
     assert lib().tf_colstats(tfd, ptr(gy_d), ptr(y_d), ptr(x_d), None, M, C, C, ptr(part3), stream()) == 0
     assert lib().tf_bn_bwd_finalize(ptr(part3), nb, 2, 1, C, C, float(M), ptr(gd), ptr(mean), ptr(invstd), ptr(dga), ptr(dbe), ptr(cA),
-                                    ptr(cB), ptr(cD), stream()) == 0
+                                    ptr(cB), ptr(cD), 0, stream()) == 0
     gx_d = torch.empty_like(x_d)
     assert lib().tf_bn_bwd_apply(tfd, ptr(gy_d), ptr(y_d), ptr(x_d), ptr(cA), ptr(cB), ptr(cD), M, C, ptr(gx_d), stream()) == 0
     dgx = err(from_nhwc(gx_d), xq.grad)

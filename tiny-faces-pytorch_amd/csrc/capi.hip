@@ -14,10 +14,13 @@ static const char* const kSymbols[] = {
     "tf_upsample_add_crop", "tf_upsample_add_crop_bwd", "tf_reduce_partials",
     "tf_detnet_num_params", "tf_detnet_param_name", "tf_detnet_param_numel", "tf_detnet_workspace_bytes",
     "tf_detnet_out_shape", "tf_detnet_forward", "tf_detnet_backward", "tf_detnet_set_dual_stream",
-    "tf_probe_tr16", "tf_profile_enable", "tf_profile_collect",
+    "tf_probe_tr16", "tf_set_stat_rows", "tf_get_stat_rows", "tf_profile_enable", "tf_profile_collect",
 };
 
 extern "C" int tf_version(void) { return 100; }
+static int g_stat_rows = TF_STAT_ROWS;
+extern "C" int tf_set_stat_rows(int rows) { g_stat_rows = rows <= 0 ? (1 << 30) : rows; return TF_OK; }
+extern "C" int tf_get_stat_rows(void) { return g_stat_rows; }
 extern "C" int tf_symbol_count(void) { return (int)(sizeof(kSymbols) / sizeof(kSymbols[0])); }
 extern "C" const char* tf_symbol_name(int i) { return (i >= 0 && i < tf_symbol_count()) ? kSymbols[i] : nullptr; }
 

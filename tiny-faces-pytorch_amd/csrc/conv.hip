@@ -359,14 +359,16 @@ int pick_tile(const tf_conv_args* a) {
   if (!a->pro_scale) return 13;                   // LDS-DMA pipeline, 64x64 tiles, 3-deep ring: fastest on every layer shape
   return t2 >= 256 ? 2 : 3;                       // producer-BN prologue needs the register-staged kernel
 }
-int tile_bm(int t) { const int k = t % 10; return (k == 3 || k == 4 || k == 5) ? 64 : 128; }
+int tile_bm(int t) { return (t % 10) == 3 ? 64 : 128; }
 
 }  // namespace
 
 extern "C" int tf_conv_mtiles(const tf_conv_args* a) {
   const long M = (long)a->N * a->OH * a->OW;
-  const int bm = tile_bm(pick_tile(a));
-  return (int)((M + bm - 1) / bm);
+  const int t = pick_tile(a);
+  const int bm = tile_bm(t);
+  const int mt = (int)((M + bm - 1) / bm);
+  return (t >= 10 && mt > tf_get_stat_rows()) ? tf_get_stat_rows() : mt;     // the DMA kernel folds its tiles into <= TF_STAT_ROWS rows
 }
 
 extern "C" int tf_conv2d(const tf_conv_args* a, void* stream_) {

@@ -32,7 +32,7 @@ struct DmaK {
   const float* mask_scale; const float* mask_shift;
   float* stat_out;
   int H, W, Cin, OH, OW, KW, stride, pad, sshift;
-  int M, OHW, ldy, Ktot, cpt, nstages, ntiles, mode, epi;
+  int M, OHW, ldy, Ktot, cpt, nstages, ntiles, mode, epi, srows, mtiles;
 };
 
 __device__ __forceinline__ int swz(int row) { return ((row >> 1) & 1) ^ (((row >> 2) & 1) << 2) ^ (((row >> 3) & 1) * 6); }
@@ -299,8 +299,13 @@ __global__ void __launch_bounds__(256) conv_dma_kernel(const DmaK a) {
     __syncthreads();
     for (int e = tid; e < 2 * BN; e += 256) {
       const int k = e / BN, cl = e - k * BN, c = n0 + cl;
-      if (c < a.ldy) a.stat_out[((size_t)mt * 2 + k) * a.ldy + c] = red[(0 * 2 + k) * BN + cl] + red[(1 * 2 + k) * BN + cl] +
-                                                                   red[(2 * 2 + k) * BN + cl] + red[(3 * 2 + k) * BN + cl];
+      if (c < a.ldy) {
+        // at most TF_STAT_ROWS partial rows per launch: tile mt accumulates into row mt % TF_STAT_ROWS (fp32 atomics;
+        // rows start at zero: the finalize kernels clear what they consumed), so the finalize reads 64 rows, not thousands
+        const float v = red[(0 * 2 + k) * BN + cl] + red[(1 * 2 + k) * BN + cl] + red[(2 * 2 + k) * BN + cl] + red[(3 * 2 + k) * BN + cl];
+        if (a.mtiles > a.srows) atomicAdd(&a.stat_out[((size_t)(mt % a.srows) * 2 + k) * a.ldy + c], v);
+        else a.stat_out[((size_t)mt * 2 + k) * a.ldy + c] = v;
+      }
     }
   }
 }
@@ -319,6 +324,7 @@ int launch_kind(const tf_conv_args* A, hipStream_t stream) {
   k.cpt = A->Cin / KCH; k.Ktot = A->KH * A->KW * A->Cin; k.nstages = A->KH * A->KW * k.cpt;
   k.ntiles = (A->Cout + BN - 1) / BN; k.mode = A->mode; k.epi = A->epi;
   const int mtiles = (k.M + BM - 1) / BM;
+  k.mtiles = mtiles; k.srows = tf_get_stat_rows();
   size_t lds = (size_t)NS * (BM + BN) * 128;
   const size_t stg = (size_t)BM * (BN + 4) * 4;
   if (stg > lds) lds = stg;
@@ -349,12 +355,9 @@ int launch(const tf_conv_args* A, hipStream_t stream) {
 
 // tile: 1 = 128x128, 2 = 128x64, 3 = 64x64 (pixels x channels); depth: ring stages (3 or 4)
 int tf_conv_dma_launch(const tf_conv_args* a, int tile, int depth, hipStream_t stream) {
-  if (a->dtype == TF_BF16 && tile >= 4) {          // experimental wide tiles (bf16 only): 4 = 64x128/3, 5 = 64x256/2, 6 = 128x128/4, 7 = 128x256/2
-    if (tile == 4) return launch<tf::bf16_t, 64, 128, 3>(a, stream);
-    if (tile == 5) return launch<tf::bf16_t, 64, 256, 2>(a, stream);
-    if (tile == 6) return launch<tf::bf16_t, 128, 128, 4>(a, stream);
-    return launch<tf::bf16_t, 128, 256, 2>(a, stream);
-  }
+  // (64x128, 64x256, 128x128x4 and 128x256 tiles were measured and lost to 64x64x3 on every layer shape:
+  //  profiles/r01c_microbench_wide_tiles.txt; they were removed again.)
+  if (tile > 3) return TF_ERR_UNSUPPORTED;
   if (a->dtype == TF_BF16) {
     if (tile == 1) return launch<tf::bf16_t, 128, 128, 3>(a, stream);
     if (tile == 2) return depth == 4 ? launch<tf::bf16_t, 128, 64, 4>(a, stream) : launch<tf::bf16_t, 128, 64, 3>(a, stream);

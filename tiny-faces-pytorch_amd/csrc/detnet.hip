@@ -30,16 +30,16 @@ int tf_maxpool_bwd(int, const void*, const uint8_t*, const void*, const float*, 
 int tf_colstats_blocks(int, int, int);
 int tf_colstats(int, const void*, const void*, const void*, const void*, int, int, int, float*, void*);
 int tf_bn_finalize(const float*, int, int, int, float, const float*, const float*, float, float, float*, float*, float*, float*, float*,
-                   float*, void*);
+                   float*, int, void*);
 int tf_bn_fold(const float*, const float*, const float*, const float*, float, int, float*, float*, void*);
 int tf_bn_bwd_finalize(const float*, int, int, int, int, int, float, const float*, const float*, const float*, float*, float*, float*, float*,
-                       float*, void*);
+                       float*, int, void*);
 int tf_bn_bwd_apply(int, const void*, const void*, const void*, const float*, const float*, const float*, int64_t, int, void*, void*);
 int tf_bn_add_relu(int, const void*, const float*, const float*, const void*, const float*, const float*, int64_t, int, void*, void*);
 int tf_bn_relu(int, const void*, const float*, const float*, int64_t, int, void*, void*);
 int tf_upsample_add_crop(int, const void*, const void*, const float*, int, int, int, int, int, int, int, float*, void*);
 int tf_upsample_add_crop_bwd(int, const float*, const float*, int, int, int, int, int, int, int, void*, void*, void*);
-int tf_reduce_partials(const float*, int, int, int, int, int, float*, void*);
+int tf_reduce_partials(const float*, int, int, int, int, int, float*, int, void*);
 }
 
 namespace {
@@ -285,7 +285,7 @@ void bn_forward(Ctx& c, const ConvUnit& u, int C, BnBuf& b, bool training, const
     c.chk(tf_bn_fold(c.P(u.gamma), c.P(u.beta), c.P(u.rmean), c.P(u.rvar), eps, C, b.scale, b.shift, c.stream));
   } else {
     c.chk(tf_bn_finalize(partial, tf_conv_mtiles(conv), conv->ldy, C, count, c.P(u.gamma), c.P(u.beta), eps, mom, b.scale, b.shift, b.mean,
-                         b.invstd, (float*)c.params[u.rmean], (float*)c.params[u.rvar], c.stream));
+                         b.invstd, (float*)c.params[u.rmean], (float*)c.params[u.rvar], 1, c.stream));
   }
 }
 
@@ -341,6 +341,7 @@ extern "C" int tf_detnet_forward(int dtype, int training, const float* x, int N,
   tf_conv_args a;
   const bool tr = training != 0;
 
+  if (tr && hipMemsetAsync(P.partial, 0, (size_t)TF_STAT_ROWS * 3 * 1024 * 4, c.stream) != hipSuccess) c.chk(TF_ERR_LAUNCH);   // statistic rows start at zero
   // ---- stem: im2col + GEMM (+BN+ReLU) + maxpool
   const int M1 = N * P.H1 * P.W1;
   c.chk(tf_stem_im2col(x, N, H, W, dtype, P.col, kStemK, c.stream));
@@ -437,9 +438,10 @@ extern "C" int tf_detnet_forward(int dtype, int training, const float* x, int N,
 namespace {
 
 // g_x for a BN whose output-gradient sums are in `partial`: finalize (dgamma, dbeta, coefficients)
-void bn_backward_coefs(Ctx& c, const ConvUnit& u, int C, BnBuf& b, const float* partial, int nblk, int nk, int kidx, int ld, float count) {
+void bn_backward_coefs(Ctx& c, const ConvUnit& u, int C, BnBuf& b, const float* partial, int nblk, int nk, int kidx, int ld, float count,
+                       int clear = 1) {
   c.chk(tf_bn_bwd_finalize(partial, nblk, nk, kidx, ld, C, count, c.P(u.gamma), b.mean, b.invstd, c.G(u.gamma), c.G(u.beta), b.cA, b.cB,
-                           b.cD, c.stream));
+                           b.cD, clear, c.stream));
 }
 
 void wgrad(Ctx& c, const ConvUnit& u, int cout, int N, int H, int W, int OH, int OW, const void* x, int ldx, const void* dy, int lddy,
@@ -489,6 +491,7 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
   const void* res3 = P.blk[A.layer_end[1]].y;
   const void* res4 = P.blk[A.layer_end[2]].y;
 
+  if (hipMemsetAsync(P.partial, 0, (size_t)TF_STAT_ROWS * 3 * 1024 * 4, c.stream) != hipSuccess) c.chk(TF_ERR_LAUNCH);   // statistic rows start at zero
   if (grad_flat && grad_flat_bytes) {                     // one memset for every weight gradient (atomics accumulate into them)
     if (hipMemsetAsync(grad_flat, 0, grad_flat_bytes, c.stream) != hipSuccess) c.chk(TF_ERR_LAUNCH);
     c.grads_zeroed = true;
@@ -514,9 +517,9 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
   {
     const int nb3 = tf_colstats_blocks(M3, kHeadLd, dtype), nb4 = tf_colstats_blocks(M4, kHeadLd, dtype);
     c.chk(tf_colstats(dtype, P.g3, nullptr, nullptr, nullptr, M3, kHeadLd, kHeadLd, P.partial, c.stream));
-    c.chk(tf_reduce_partials(P.partial, nb3, 1, 0, kHeadLd, nout, c.G(A.head3.bias), c.stream));
+    c.chk(tf_reduce_partials(P.partial, nb3, 1, 0, kHeadLd, nout, c.G(A.head3.bias), 1, c.stream));
     c.chk(tf_colstats(dtype, P.g4, nullptr, nullptr, nullptr, M4, kHeadLd, kHeadLd, P.partial, c.stream));
-    c.chk(tf_reduce_partials(P.partial, nb4, 1, 0, kHeadLd, nout, c.G(A.head4.bias), c.stream));
+    c.chk(tf_reduce_partials(P.partial, nb4, 1, 0, kHeadLd, nout, c.G(A.head4.bias), 1, c.stream));
   }
   {
     ConvUnit h3 = A.head3, h4 = A.head4;
@@ -552,8 +555,8 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
     const int nb = tf_colstats_blocks(Mout, c4, dtype);
     c.chk(tf_colstats(dtype, Gcur, b.y, b.c3, B.has_ds ? b.d : nullptr, Mout, c4, c4, P.partial, c.stream));
     const int nk = B.has_ds ? 3 : 2;
-    bn_backward_coefs(c, B.c3, c4, b.b3, P.partial, nb, nk, 1, c4, (float)Mout);
-    if (B.has_ds) bn_backward_coefs(c, B.ds, c4, b.bd, P.partial, nb, nk, 2, c4, (float)Mout);
+    bn_backward_coefs(c, B.c3, c4, b.b3, P.partial, nb, nk, 1, c4, (float)Mout, B.has_ds ? 0 : 1);   // the last reader clears the partial rows
+    if (B.has_ds) bn_backward_coefs(c, B.ds, c4, b.bd, P.partial, nb, nk, 2, c4, (float)Mout, 1);
     // (2) g_c3 -> T1
     c.chk(tf_bn_bwd_apply(dtype, Gcur, b.y, b.c3, b.b3.cA, b.b3.cB, b.b3.cD, Mout, c4, T1, c.stream));
     c.fork();

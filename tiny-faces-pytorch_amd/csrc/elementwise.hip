@@ -170,7 +170,7 @@ __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const T* __restrict__ 
 template <typename T>
 __global__ void __launch_bounds__(256) colstats_kernel(const T* __restrict__ g, const T* __restrict__ y, const T* __restrict__ a,
                                                        const T* __restrict__ b, int M, int C, int ld, int rows_per_block,
-                                                       float* __restrict__ out, int nk) {
+                                                       float* __restrict__ out, int nk, int srows) {
   constexpr int EPS = tf::Elem<T>::kPer16B;
   const int ct = C / EPS;                         // threads across channels (<= 256)
   const int rt = 256 / ct;                        // rows in flight
@@ -214,7 +214,8 @@ __global__ void __launch_bounds__(256) colstats_kernel(const T* __restrict__ g, 
   for (int e = threadIdx.x; e < nk * C; e += 256) {
     float t = 0.f;
     for (int r = 0; r < rt; ++r) t += red[r * nk * C + e];
-    out[(size_t)blockIdx.x * nk * C + e] = t;
+    if ((int)gridDim.x <= srows) out[(size_t)blockIdx.x * nk * C + e] = t;
+    else atomicAdd(&out[(size_t)(blockIdx.x % srows) * nk * C + e], t);      // rows are zero on entry (finalize clears)
   }
 }
 
@@ -223,8 +224,8 @@ __global__ void __launch_bounds__(256) colstats_kernel(const T* __restrict__ g, 
 // sums the nblk rows with 32 row-lanes per channel (coalesced 128-byte reads), then 32 threads finalize.
 constexpr int kFinCh = 32, kFinLanes = 32;
 template <int NK>
-__device__ __forceinline__ void reduce_partial_rows(const float* __restrict__ partial, int nblk, int nk, const int* kidx, int ld, int C,
-                                                    double (*out)[kFinCh]) {
+__device__ __forceinline__ void reduce_partial_rows(float* __restrict__ partial, int nblk, int nk, const int* kidx, int ld, int C,
+                                                    double (*out)[kFinCh], int clear) {
   __shared__ double red[NK][kFinLanes][kFinCh];
   const int tc = threadIdx.x % kFinCh, tr = threadIdx.x / kFinCh;
   const int c = blockIdx.x * kFinCh + tc;
@@ -236,6 +237,10 @@ __device__ __forceinline__ void reduce_partial_rows(const float* __restrict__ pa
 #pragma unroll
       for (int k = 0; k < NK; ++k) acc[k] += (double)partial[((size_t)b * nk + kidx[k]) * ld + c];
     }
+  }
+  if (clear && c < C) {                 // leave the buffer zeroed for the next producer (own channels only: race-free)
+    for (int b = tr; b < nblk; b += kFinLanes)
+      for (int k = 0; k < nk; ++k) partial[((size_t)b * nk + k) * ld + c] = 0.f;
   }
 #pragma unroll
   for (int k = 0; k < NK; ++k) red[k][tr][tc] = acc[k];
@@ -249,14 +254,14 @@ __device__ __forceinline__ void reduce_partial_rows(const float* __restrict__ pa
 }
 
 // partial[blk][2][ld] (sum, sumsq) -> scale/shift for y = x*scale+shift, saved mean/invstd, running stats
-__global__ void __launch_bounds__(kFinCh* kFinLanes) bn_finalize_kernel(const float* __restrict__ partial, int nblk, int ld, int C, float count,
+__global__ void __launch_bounds__(kFinCh* kFinLanes) bn_finalize_kernel(float* __restrict__ partial, int nblk, int ld, int C, float count, int clear,
                                                                         const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                                         float momentum, float* __restrict__ scale, float* __restrict__ shift,
                                                                         float* __restrict__ mean_out, float* __restrict__ invstd_out,
                                                                         float* __restrict__ running_mean, float* __restrict__ running_var) {
   __shared__ double sums[2][kFinCh];
   const int kidx[2] = {0, 1};
-  reduce_partial_rows<2>(partial, nblk, 2, kidx, ld, C, sums);
+  reduce_partial_rows<2>(partial, nblk, 2, kidx, ld, C, sums, clear);
   const int c = blockIdx.x * kFinCh + threadIdx.x;
   if (threadIdx.x >= kFinCh || c >= C) return;
   const double s = sums[0][threadIdx.x], q = sums[1][threadIdx.x];
@@ -285,14 +290,14 @@ __global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __r
 
 // BN backward finalize: partial[blk][nk][ld] with k0 = sum gz, kidx = sum gz*x  ->
 //   dgamma, dbeta and the affine form  g_x = A*gz + B*x + D
-__global__ void __launch_bounds__(kFinCh* kFinLanes) bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int nk, int kidx_, int ld, int C,
-                                                                            float count, const float* __restrict__ gamma, const float* __restrict__ mean,
+__global__ void __launch_bounds__(kFinCh* kFinLanes) bn_bwd_finalize_kernel(float* __restrict__ partial, int nblk, int nk, int kidx_, int ld, int C,
+                                                                            int clear, float count, const float* __restrict__ gamma, const float* __restrict__ mean,
                                                                             const float* __restrict__ invstd, float* __restrict__ dgamma,
                                                                             float* __restrict__ dbeta, float* __restrict__ cA, float* __restrict__ cB,
                                                                             float* __restrict__ cD) {
   __shared__ double sums[2][kFinCh];
   const int kidx[2] = {0, kidx_};
-  reduce_partial_rows<2>(partial, nblk, nk, kidx, ld, C, sums);
+  reduce_partial_rows<2>(partial, nblk, nk, kidx, ld, C, sums, clear);
   const int c = blockIdx.x * kFinCh + threadIdx.x;
   if (threadIdx.x >= kFinCh || c >= C) return;
   const double s1 = sums[0][threadIdx.x], s2 = sums[1][threadIdx.x];
@@ -471,11 +476,11 @@ __global__ void __launch_bounds__(256) upsample_add_bwd_kernel(const float* __re
 }
 
 // sum over blocks of partial[blk][nk][ld] row k -> out[c]  (bias gradients)
-__global__ void __launch_bounds__(kFinCh* kFinLanes) reduce_partials_kernel(const float* __restrict__ partial, int nblk, int nk, int k, int ld, int C,
-                                                                            float* __restrict__ out) {
+__global__ void __launch_bounds__(kFinCh* kFinLanes) reduce_partials_kernel(float* __restrict__ partial, int nblk, int nk, int k, int ld, int C,
+                                                                            float* __restrict__ out, int clear) {
   __shared__ double sums[1][kFinCh];
   const int kidx[1] = {k};
-  reduce_partial_rows<1>(partial, nblk, nk, kidx, ld, C, sums);
+  reduce_partial_rows<1>(partial, nblk, nk, kidx, ld, C, sums, clear);
   const int c = blockIdx.x * kFinCh + threadIdx.x;
   if (threadIdx.x < kFinCh && c < C) out[c] = (float)sums[0][threadIdx.x];
 }
@@ -559,9 +564,10 @@ static int colstats_rows(int M, int C, int dtype) {
   rows = (rows + rt - 1) / rt * rt;
   return rows < rt ? rt : rows;
 }
-extern "C" int tf_colstats_blocks(int M, int C, int dtype) {
+extern "C" int tf_colstats_blocks(int M, int C, int dtype) {       // partial ROWS written (blocks are folded into <= TF_STAT_ROWS)
   const int rows = colstats_rows(M, C, dtype);
-  return (M + rows - 1) / rows;
+  const int nblk = (M + rows - 1) / rows;
+  return nblk > tf_get_stat_rows() ? tf_get_stat_rows() : nblk;
 }
 
 extern "C" int tf_colstats(int dtype, const void* g, const void* y, const void* a, const void* b, int M, int C, int ld, float* partial,
@@ -575,17 +581,17 @@ extern "C" int tf_colstats(int dtype, const void* g, const void* y, const void* 
   const size_t lds = (size_t)rt * nk * C * 4;
   if (lds > 64 * 1024) return TF_ERR_UNSUPPORTED;
   DISPATCH_T(dtype, hipLaunchKernelGGL(colstats_kernel<T>, dim3(nblk), dim3(256), lds, (hipStream_t)stream, (const T*)g, (const T*)y,
-                                       (const T*)a, (const T*)b, M, C, ld, rows, partial, nk));
+                                       (const T*)a, (const T*)b, M, C, ld, rows, partial, nk, tf_get_stat_rows()));
   TF_CHECK_LAUNCH();
   return TF_OK;
 }
 
 extern "C" int tf_bn_finalize(const float* partial, int nblk, int ld, int C, float count, const float* gamma, const float* beta, float eps,
                               float momentum, float* scale, float* shift, float* mean, float* invstd, float* running_mean,
-                              float* running_var, void* stream) {
+                              float* running_var, int clear, void* stream) {
   if (!partial || !gamma || !beta || !scale || !shift || !mean || !invstd) return TF_ERR_ARG;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinCh * kFinLanes), 0, (hipStream_t)stream, partial, nblk, ld, C, count, gamma, beta, eps,
-                     momentum, scale, shift, mean, invstd, running_mean, running_var);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinCh * kFinLanes), 0, (hipStream_t)stream, const_cast<float*>(partial), nblk, ld, C, count, clear,
+                     gamma, beta, eps, momentum, scale, shift, mean, invstd, running_mean, running_var);
   TF_CHECK_LAUNCH();
   return TF_OK;
 }
@@ -600,8 +606,8 @@ extern "C" int tf_bn_fold(const float* gamma, const float* beta, const float* ru
 
 extern "C" int tf_bn_bwd_finalize(const float* partial, int nblk, int nk, int kidx, int ld, int C, float count, const float* gamma,
                                   const float* mean, const float* invstd, float* dgamma, float* dbeta, float* cA, float* cB, float* cD,
-                                  void* stream) {
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinCh * kFinLanes), 0, (hipStream_t)stream, partial, nblk, nk, kidx, ld, C, count,
+                                  int clear, void* stream) {
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinCh * kFinLanes), 0, (hipStream_t)stream, const_cast<float*>(partial), nblk, nk, kidx, ld, C, clear, count,
                      gamma, mean, invstd, dgamma, dbeta, cA, cB, cD);
   TF_CHECK_LAUNCH();
   return TF_OK;
@@ -657,8 +663,8 @@ extern "C" int tf_upsample_add_crop_bwd(int dtype, const float* g_nchw, const fl
   return TF_OK;
 }
 
-extern "C" int tf_reduce_partials(const float* partial, int nblk, int nk, int k, int ld, int C, float* out, void* stream) {
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinCh * kFinLanes), 0, (hipStream_t)stream, partial, nblk, nk, k, ld, C, out);
+extern "C" int tf_reduce_partials(const float* partial, int nblk, int nk, int k, int ld, int C, float* out, int clear, void* stream) {
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinCh * kFinLanes), 0, (hipStream_t)stream, const_cast<float*>(partial), nblk, nk, k, ld, C, out, clear);
   TF_CHECK_LAUNCH();
   return TF_OK;
 }

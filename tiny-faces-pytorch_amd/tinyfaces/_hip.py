@@ -68,15 +68,15 @@ _SIGNATURES = {
     "tf_maxpool_bwd": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
     "tf_colstats_blocks": (i32, [i32, i32, i32]),
     "tf_colstats": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, vp, vp]),
-    "tf_bn_finalize": (i32, [vp, i32, i32, i32, f32, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp]),
+    "tf_bn_finalize": (i32, [vp, i32, i32, i32, f32, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, i32, vp]),
     "tf_bn_fold": (i32, [vp, vp, vp, vp, f32, i32, vp, vp, vp]),
-    "tf_bn_bwd_finalize": (i32, [vp, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "tf_bn_bwd_finalize": (i32, [vp, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
     "tf_bn_bwd_apply": (i32, [i32, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp]),
     "tf_bn_relu": (i32, [i32, vp, vp, vp, i64, i32, vp, vp]),
     "tf_bn_add_relu": (i32, [i32, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp]),
     "tf_upsample_add_crop": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
     "tf_upsample_add_crop_bwd": (i32, [i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
-    "tf_reduce_partials": (i32, [vp, i32, i32, i32, i32, i32, vp, vp]),
+    "tf_reduce_partials": (i32, [vp, i32, i32, i32, i32, i32, vp, i32, vp]),
     "tf_detnet_num_params": (i32, []),
     "tf_detnet_param_name": (C.c_char_p, [i32]),
     "tf_detnet_param_numel": (i64, [i32, i32]),
@@ -87,6 +87,8 @@ _SIGNATURES = {
     "tf_pack_weights_batched": (i32, [i32, vp, i32, vp]),
     "tf_detnet_set_dual_stream": (i32, [i32]),
     "tf_probe_tr16": (i32, [vp, vp]),
+    "tf_set_stat_rows": (i32, [i32]),
+    "tf_get_stat_rows": (i32, []),
     "tf_profile_enable": (i32, [i32]),
     "tf_profile_collect": (i32, [C.POINTER(C.c_double), i32]),
 }
