@@ -112,7 +112,7 @@ def bench_eval(model, templates, device, runs=5):
     masks = {s: [torch.from_numpy(a).to(device) for a in ops.template_masks(templates, s, (x.shape[3] + 7) // 8, "w")] for s, x in levels}
     thr = None
     times, n_cand, n_keep = [], 0, 0
-    with torch.no_grad():
+    with torch.no_grad(), model.constant_weights(reserve=(1, 1920, 2560)):       # what evaluate_model.py's image loop does
         for it in range(runs + 2):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -150,6 +150,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-eval", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--eval-only", action="store_true", help="only the configs[1] pyramid leg (for rocprofv3 runs of the eval path)")
     args = ap.parse_args()
 
     from tinyfaces import _hip, ops, parallel
@@ -173,6 +174,9 @@ def main():
     t_d = torch.as_tensor(templates, dtype=torch.float64).to(device)
     torch.manual_seed(0)
     model = tame_init_(DetectionModel(num_objects=1, num_templates=25)).set_compute_dtype(args.dtype)
+    if args.eval_only:
+        print(json.dumps({"eval": bench_eval(model.to(device), templates, device, runs=10)}))
+        return
     crit = DetectionCriterion(25, seed=rank, lazy_meters=True)
     eng = TrainEngine(model, crit, lr=1e-4, momentum=0.9, weight_decay=5e-4, device=device)
 

@@ -242,9 +242,15 @@ const char* tf_detnet_param_name(int i);      /* state_dict key, e.g. "model.lay
 int64_t tf_detnet_param_numel(int i, int num_out);
 size_t tf_detnet_workspace_bytes(int dtype, int N, int H, int W, int num_out, int training);
 int tf_detnet_out_shape(int H, int W, int* H3, int* W3);
+/* flags: TF_DETNET_WEIGHTS_READY (eval only) = the front of `ws` (tf_detnet_param_region_bytes bytes, whose layout depends on
+ * dtype/num_out/training but not on N,H,W) still holds the packed weights + folded BN of an earlier eval forward with the
+ * SAME parameter values: skip re-packing.  The image pyramid of evaluation.py:49-82 runs 3-5 forwards per image on
+ * constant weights; the caller owns the guarantee.                                                                       */
+#define TF_DETNET_WEIGHTS_READY 1
+size_t tf_detnet_param_region_bytes(int dtype, int num_out, int training);
 int tf_detnet_forward(int dtype, int training, const float* x_nchw, int N, int H, int W, int num_out,
                       void* const* params, float bn_eps, float bn_momentum,
-                      float* out_nchw, void* ws, size_t ws_bytes, void* stream);
+                      float* out_nchw, void* ws, size_t ws_bytes, int flags, void* stream);
 /* 1 (default): weight gradients run on an internal second stream concurrently with the data-gradient chain; 0: single stream */
 int tf_detnet_set_dual_stream(int on);
 /* grad_flat (optional): when every entry of `grads` lies inside [grad_flat, grad_flat + grad_flat_bytes) the whole

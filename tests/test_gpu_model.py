@@ -291,3 +291,31 @@ def test_dual_stream_backward_equals_single_stream(dtype):
         _hip.lib().tf_set_stat_rows(64)
     report(f"dual_stream[{dtype}]", worst_rel=worst)
     assert worst < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_constant_weights_session_is_bit_identical(models, dtype):
+    """Inside model.constant_weights() the packed weights / folded BN of the first forward are reused for every later
+    image size (TF_DETNET_WEIGHTS_READY); outputs must equal the re-packing path bit for bit, and the cache must drop
+    when the session closes (a weight edit afterwards has to be visible)."""
+    m, _ = models
+    m.set_compute_dtype(dtype).eval()
+    g = torch.Generator().manual_seed(3)
+    xs = [torch.randn(1, 3, h, w, generator=g).cuda() for h, w in [(96, 128), (200, 168), (64, 64), (200, 168)]]
+    with torch.no_grad():
+        ref = [m(x).clone() for x in xs]
+        with m.constant_weights(reserve=(1, 200, 168)):
+            got = [m(x).clone() for x in xs]
+            assert m._ready_key is not None
+        assert m._ready_key is None
+        for a, b in zip(ref, got):
+            assert torch.equal(a, b)
+        # after the session: edits are honoured again
+        w = m.score_res3.bias
+        old = w.detach().clone()
+        try:
+            w.data.add_(1.0)
+            y2 = m(xs[0])
+            assert float((y2 - ref[0]).abs().max()) > 0.5
+        finally:
+            w.data.copy_(old)

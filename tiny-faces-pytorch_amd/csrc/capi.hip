@@ -13,7 +13,7 @@ static const char* const kSymbols[] = {
     "tf_bn_finalize", "tf_bn_fold", "tf_bn_bwd_finalize", "tf_bn_bwd_apply", "tf_bn_relu", "tf_bn_add_relu",
     "tf_upsample_add_crop", "tf_upsample_add_crop_bwd", "tf_reduce_partials",
     "tf_detnet_num_params", "tf_detnet_param_name", "tf_detnet_param_numel", "tf_detnet_workspace_bytes",
-    "tf_detnet_out_shape", "tf_detnet_forward", "tf_detnet_backward", "tf_detnet_set_dual_stream",
+    "tf_detnet_out_shape", "tf_detnet_param_region_bytes", "tf_detnet_forward", "tf_detnet_backward", "tf_detnet_set_dual_stream",
     "tf_probe_tr16", "tf_set_stat_rows", "tf_get_stat_rows", "tf_profile_enable", "tf_profile_collect",
 };
 

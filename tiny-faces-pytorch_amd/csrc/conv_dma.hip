@@ -15,6 +15,7 @@
 //     store AND for the residual / mask operands, all epilogue math on 8 consecutive channels.
 // Used whenever no producer-BN prologue has to be applied on the fly (eval forward, every
 // data-gradient, conv1 / downsample / heads in training); conv.hip keeps the prologue path.
+#include <cstdlib>
 #include "common.h"
 #include "profile.h"
 
@@ -32,7 +33,7 @@ struct DmaK {
   const float* mask_scale; const float* mask_shift;
   float* stat_out;
   int H, W, Cin, OH, OW, KW, stride, pad, sshift;
-  int M, OHW, ldy, Ktot, cpt, nstages, ntiles, mode, epi, srows, mtiles;
+  int M, OHW, ldy, Ktot, cpt, nstages, ntiles, mode, epi, srows, mtiles, dbg;
 };
 
 __device__ __forceinline__ int swz(int row) { return ((row >> 1) & 1) ^ (((row >> 2) & 1) << 2) ^ (((row >> 3) & 1) * 6); }
@@ -187,7 +188,7 @@ __global__ void __launch_bounds__(256) conv_dma_kernel(const DmaK a) {
   const int nst = a.nstages;
 #pragma unroll
   for (int j = 0; j < NS - 1; ++j)
-    if (j < nst) issue();
+    if (j < nst && !(a.dbg & 8)) issue();
   int cs = 0;                                        // ring slot being computed
   for (int st = 0; st < nst; ++st) {
     // stage st has landed once at most min(NS-2, nst-1-st) younger stages are still in flight
@@ -196,12 +197,13 @@ __global__ void __launch_bounds__(256) conv_dma_kernel(const DmaK a) {
     else if (NS > 3 && younger == 1) wait_vmcnt<L>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();                   // everyone's pieces of stage st landed; ring slot (st-1)%NS is free
-    if (st + NS - 1 < nst) issue();
+    if (st + NS - 1 < nst && !(a.dbg & 1)) issue();
     const char* xs = smem + cs * BUF;
-    MmaD<T>::template stage<NF, MF>(xs, xs + XBYTES, wm * WM, wn * WN, acc);
+    if (!(a.dbg & 2)) MmaD<T>::template stage<NF, MF>(xs, xs + XBYTES, wm * WM, wn * WN, acc);
     if (++cs == NS) cs = 0;
   }
   __builtin_amdgcn_s_barrier();                     // all waves done reading the ring -> reuse it as the staging tile
+  if (a.dbg & 4) { if (acc[0][0][0] == 123.456f) a.y[0] = 1; return; }
 
   // ---------------- epilogue, phase 1: accumulators -> fp32 [BM][BN+4] tile in LDS
   constexpr int PITCH = BN + 4;
@@ -325,6 +327,7 @@ int launch_kind(const tf_conv_args* A, hipStream_t stream) {
   k.ntiles = (A->Cout + BN - 1) / BN; k.mode = A->mode; k.epi = A->epi;
   const int mtiles = (k.M + BM - 1) / BM;
   k.mtiles = mtiles; k.srows = tf_get_stat_rows();
+  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("TF_CONV_DBG"); dbg = e ? atoi(e) : 0; } k.dbg = dbg; }
   size_t lds = (size_t)NS * (BM + BN) * 128;
   const size_t stg = (size_t)BM * (BN + 4) * 4;
   if (stg > lds) lds = stg;

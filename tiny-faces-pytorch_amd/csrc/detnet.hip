@@ -152,7 +152,7 @@ struct Plan {                    // everything a forward carves; backward re-der
   void *g3, *g4, *G0, *G1, *T4, *R3, *wt; float* dwp;
   void *S1[2], *S2[2], *S3[2], *SD[2];   // per block parity: g_c3, g_c2, g_c1, g_d (read by the weight-gradient stream)   // gradient buffers (roles in tf_detnet_backward) + transposed-weight scratch
   int H3, W3, H4, W4;
-  size_t total;
+  size_t total, param_bytes;
 };
 
 size_t packed_bytes(int dtype, int rows, int taps, int cols) { return (size_t)((rows + 127) / 128 * 128) * taps * cols * esize(dtype); }
@@ -165,16 +165,43 @@ void build_plan(Plan& P, Arena& ar, int dtype, int N, int H, int W, int nout, in
   const size_t M1 = (size_t)N * P.H1 * P.W1, M2 = (size_t)N * P.H2 * P.W2;
   size_t max_partial = 0;
   auto part = [&](size_t M, int C) { size_t t = ((M + 63) / 64) * 2 * (size_t)C; if (t > max_partial) max_partial = t; };
+  // ---- parameter-derived buffers first: their offsets depend on (dtype, nout, training) only, never on the image size, so an
+  //      eval-mode caller may keep them across forwards of different sizes (TF_DETNET_WEIGHTS_READY)
+  P.bn_stem = bn_alloc(ar, 64);
+  P.wstem = ar.get(packed_bytes(dtype, 64, 1, kStemK));
+  P.blk.resize(A.blocks.size());
+  size_t max_wt = 0;
+  for (size_t i = 0; i < A.blocks.size(); ++i) {
+    const Block& B = A.blocks[i];
+    Plan::Blk& b = P.blk[i];
+    const int pl = B.planes, c4 = pl * 4;
+    b.w1 = ar.get(packed_bytes(dtype, pl, 1, B.cin)); b.w2 = ar.get(packed_bytes(dtype, pl, 9, pl));
+    b.w3 = ar.get(packed_bytes(dtype, c4, 1, pl));
+    b.wd = B.has_ds ? ar.get(packed_bytes(dtype, c4, 1, B.cin)) : nullptr;
+    b.w1t = training ? ar.get(packed_bytes(dtype, B.cin, 1, pl)) : nullptr;
+    b.w2t = training ? ar.get(packed_bytes(dtype, pl, 9, pl)) : nullptr;
+    b.w3t = training ? ar.get(packed_bytes(dtype, pl, 1, c4)) : nullptr;
+    b.wdt = (training && B.has_ds) ? ar.get(packed_bytes(dtype, B.cin, 1, c4)) : nullptr;
+    b.b1 = bn_alloc(ar, pl); b.b2 = bn_alloc(ar, pl); b.b3 = bn_alloc(ar, c4);
+    if (B.has_ds) b.bd = bn_alloc(ar, c4);
+    const size_t wtb = packed_bytes(dtype, pl, 9, pl);
+    if (wtb > max_wt) max_wt = wtb;
+    if (packed_bytes(dtype, B.cin, 1, c4) > max_wt) max_wt = packed_bytes(dtype, B.cin, 1, c4);
+  }
+  P.w_h3 = ar.get(packed_bytes(dtype, kHeadLd, 1, 512)); P.w_h4 = ar.get(packed_bytes(dtype, kHeadLd, 1, 1024));
+  P.w_h3t = training ? ar.get(packed_bytes(dtype, 512, 1, kHeadLd)) : nullptr;
+  P.w_h4t = training ? ar.get(packed_bytes(dtype, 1024, 1, kHeadLd)) : nullptr;
+  P.hbias3 = ar.f32(kHeadLd); P.hbias4 = ar.f32(kHeadLd); P.ones = ar.f32(kHeadLd);
+  P.wup_diag = ar.f32((size_t)nout * 16);
+  P.param_bytes = ar.off;
+  // ---- activations
   P.col = ar.get(M1 * kStemK * es);
   P.cstem = ar.get(M1 * 64 * es);
   P.pool = ar.get(M2 * 64 * es);
   P.pool_idx = (uint8_t*)ar.get(training ? M2 * 64 : 0);
-  P.bn_stem = bn_alloc(ar, 64);
-  P.wstem = ar.get(packed_bytes(dtype, 64, 1, kStemK));
   part(M1, 64);
   int h = P.H2, w = P.W2;
-  P.blk.resize(A.blocks.size());
-  size_t max_act = M1 * 64 * es, max_wt = 0;
+  size_t max_act = M1 * 64 * es;
   for (size_t i = 0; i < A.blocks.size(); ++i) {
     const Block& B = A.blocks[i];
     Plan::Blk& b = P.blk[i];
@@ -186,21 +213,9 @@ void build_plan(Plan& P, Arena& ar, int dtype, int N, int H, int W, int nout, in
     b.c3 = training ? ar.get(Mout * c4 * es) : nullptr;
     b.d = B.has_ds ? ar.get(Mout * c4 * es) : nullptr;
     b.y = ar.get(Mout * c4 * es);
-    b.w1 = ar.get(packed_bytes(dtype, pl, 1, B.cin)); b.w2 = ar.get(packed_bytes(dtype, pl, 9, pl));
-    b.w3 = ar.get(packed_bytes(dtype, c4, 1, pl));
-    b.wd = B.has_ds ? ar.get(packed_bytes(dtype, c4, 1, B.cin)) : nullptr;
-    b.w1t = training ? ar.get(packed_bytes(dtype, B.cin, 1, pl)) : nullptr;
-    b.w2t = training ? ar.get(packed_bytes(dtype, pl, 9, pl)) : nullptr;
-    b.w3t = training ? ar.get(packed_bytes(dtype, pl, 1, c4)) : nullptr;
-    b.wdt = (training && B.has_ds) ? ar.get(packed_bytes(dtype, B.cin, 1, c4)) : nullptr;
-    b.b1 = bn_alloc(ar, pl); b.b2 = bn_alloc(ar, pl); b.b3 = bn_alloc(ar, c4);
-    if (B.has_ds) b.bd = bn_alloc(ar, c4);
     part(Min, pl); part(Mout, c4);
     if (Min * (size_t)B.cin * es > max_act) max_act = Min * B.cin * es;
     if (Mout * c4 * es > max_act) max_act = Mout * c4 * es;
-    const size_t wtb = packed_bytes(dtype, pl, 9, pl);
-    if (wtb > max_wt) max_wt = wtb;
-    if (packed_bytes(dtype, B.cin, 1, c4) > max_wt) max_wt = packed_bytes(dtype, B.cin, 1, c4);
     h = b.Hout; w = b.Wout;
   }
   const Plan::Blk& l2 = P.blk[A.layer_end[1]];
@@ -208,12 +223,7 @@ void build_plan(Plan& P, Arena& ar, int dtype, int N, int H, int W, int nout, in
   P.H3 = l2.Hout; P.W3 = l2.Wout; P.H4 = l3.Hout; P.W4 = l3.Wout;
   const size_t M3 = (size_t)N * P.H3 * P.W3, M4 = (size_t)N * P.H4 * P.W4;
   P.a1tmp = nullptr;
-  P.w_h3 = ar.get(packed_bytes(dtype, kHeadLd, 1, 512)); P.w_h4 = ar.get(packed_bytes(dtype, kHeadLd, 1, 1024));
-  P.w_h3t = training ? ar.get(packed_bytes(dtype, 512, 1, kHeadLd)) : nullptr;
-  P.w_h4t = training ? ar.get(packed_bytes(dtype, 1024, 1, kHeadLd)) : nullptr;
   P.s3 = ar.get(M3 * kHeadLd * es); P.s4 = ar.get(M4 * kHeadLd * es);
-  P.hbias3 = ar.f32(kHeadLd); P.hbias4 = ar.f32(kHeadLd); P.ones = ar.f32(kHeadLd);
-  P.wup_diag = ar.f32((size_t)nout * 16);
   part(M3, kHeadLd);
   if (max_partial < (size_t)1100 * 3 * 1024) max_partial = (size_t)1100 * 3 * 1024;   // colstats: up to ~1024 blocks x 3 sums x 1024 channels
   P.partial_floats = max_partial + 4096;
@@ -242,6 +252,7 @@ __global__ void head_vectors_kernel(const float* b3, const float* b4, const floa
 struct Ctx {
   int dtype; hipStream_t stream; void* const* params; void* const* grads; int rc;
   bool grads_zeroed = false;
+  bool skip_fold = false;
   std::vector<tf_pack_job> jobs;
   hipStream_t side = nullptr;                 // weight gradients run here, concurrently with the data-gradient chain
   std::vector<hipEvent_t>* events = nullptr; size_t ev_next = 0;
@@ -282,7 +293,7 @@ void pack(Ctx& c, const ConvUnit& u, int cout, void* out, bool transpose, int ci
 void bn_forward(Ctx& c, const ConvUnit& u, int C, BnBuf& b, bool training, const tf_conv_args* conv, float* partial, float count, float eps,
                 float mom) {
   if (!training) {
-    c.chk(tf_bn_fold(c.P(u.gamma), c.P(u.beta), c.P(u.rmean), c.P(u.rvar), eps, C, b.scale, b.shift, c.stream));
+    if (!c.skip_fold) c.chk(tf_bn_fold(c.P(u.gamma), c.P(u.beta), c.P(u.rmean), c.P(u.rvar), eps, C, b.scale, b.shift, c.stream));
   } else {
     c.chk(tf_bn_finalize(partial, tf_conv_mtiles(conv), conv->ldy, C, count, c.P(u.gamma), c.P(u.beta), eps, mom, b.scale, b.shift, b.mean,
                          b.invstd, (float*)c.params[u.rmean], (float*)c.params[u.rvar], 1, c.stream));
@@ -329,8 +340,14 @@ extern "C" size_t tf_detnet_workspace_bytes(int dtype, int N, int H, int W, int 
   return P.total + 4096;
 }
 
+extern "C" size_t tf_detnet_param_region_bytes(int dtype, int nout, int training) {
+  Plan P; Arena ar(nullptr, 0);
+  build_plan(P, ar, dtype, 1, 32, 32, nout, training);
+  return P.param_bytes;
+}
+
 extern "C" int tf_detnet_forward(int dtype, int training, const float* x, int N, int H, int W, int nout, void* const* params, float eps,
-                                 float mom, float* out, void* ws, size_t ws_bytes, void* stream_) {
+                                 float mom, float* out, void* ws, size_t ws_bytes, int flags, void* stream_) {
   if (!x || !params || !out || !ws || nout <= 0 || nout > kHeadLd) return TF_ERR_ARG;
   if (dtype != TF_BF16 && dtype != TF_F32) return TF_ERR_UNSUPPORTED;
   const Arch& A = arch();
@@ -340,12 +357,16 @@ extern "C" int tf_detnet_forward(int dtype, int training, const float* x, int N,
   Ctx c{dtype, (hipStream_t)stream_, params, nullptr, TF_OK};
   tf_conv_args a;
   const bool tr = training != 0;
+  // eval only: the packed weights, folded BN affines and head vectors at the front of `ws` are already those of `params`
+  const bool ready = !tr && (flags & TF_DETNET_WEIGHTS_READY);
 
+  c.skip_fold = ready;
   if (tr && hipMemsetAsync(P.partial, 0, (size_t)TF_STAT_ROWS * 3 * 1024 * 4, c.stream) != hipSuccess) c.chk(TF_ERR_LAUNCH);   // statistic rows start at zero
   // ---- stem: im2col + GEMM (+BN+ReLU) + maxpool
   const int M1 = N * P.H1 * P.W1;
   c.chk(tf_stem_im2col(x, N, H, W, dtype, P.col, kStemK, c.stream));
   // ---- every weight of the pass re-packed from the fp32 master copy in two launches
+  if (!ready) {
   pack(c, A.stem, 64, P.wstem, false, 147, kStemK, 1);     // conv1.weight flattened OIHW == im2col k order
   for (size_t i = 0; i < A.blocks.size(); ++i) {
     const Block& B = A.blocks[i];
@@ -361,6 +382,7 @@ extern "C" int tf_detnet_forward(int dtype, int training, const float* x, int N,
     c.jobs.push_back(j);
   }
   c.flush_packs();
+  }
   conv_fill(a, dtype, 0, 1, 1, M1, kStemK, 1, M1, 64, 1, 1, 0, 64, P.col, P.wstem, P.cstem);
   if (tr) { a.epi = TF_EPI_STATS; a.stat_out = P.partial; }
   else {
@@ -420,8 +442,9 @@ extern "C" int tf_detnet_forward(int dtype, int training, const float* x, int N,
   // ---- heads + bilinear upsample + crop + add
   const void* res3 = P.blk[A.layer_end[1]].y;
   const void* res4 = P.blk[A.layer_end[2]].y;
-  hipLaunchKernelGGL(head_vectors_kernel, dim3((nout * 16 + 255) / 256), dim3(256), 0, c.stream, c.P(A.head3.bias), c.P(A.head4.bias),
-                     c.P(A.upsample_w), nout, P.hbias3, P.hbias4, P.ones, P.wup_diag);
+  if (!ready)
+    hipLaunchKernelGGL(head_vectors_kernel, dim3((nout * 16 + 255) / 256), dim3(256), 0, c.stream, c.P(A.head3.bias), c.P(A.head4.bias),
+                       c.P(A.upsample_w), nout, P.hbias3, P.hbias4, P.ones, P.wup_diag);
   conv_fill(a, dtype, 0, N, P.H3, P.W3, 512, P.H3, P.W3, kHeadLd, 1, 1, 0, kHeadLd, res3, P.w_h3, P.s3);
   a.epi = TF_EPI_AFFINE; a.epi_scale = P.ones; a.epi_shift = P.hbias3;
   c.chk(tf_conv2d(&a, c.stream));
@@ -610,7 +633,7 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
   c.chk(tf_colstats(dtype, gz, nullptr, P.cstem, nullptr, M1, 64, 64, P.partial, c.stream));
   bn_backward_coefs(c, A.stem, 64, P.bn_stem, P.partial, nb, 2, 1, 64, (float)M1);
   c.chk(tf_bn_bwd_apply(dtype, gz, nullptr, P.cstem, P.bn_stem.cA, P.bn_stem.cB, P.bn_stem.cD, M1, 64, gz, c.stream));
-  c.chk(tf_stem_im2col(x, N, H, W, dtype, P.col, kStemK, c.stream));
+  // P.col still holds the im2col matrix of this forward (nothing else is carved from that range)
   {
     ConvUnit s = A.stem; s.stride = 1; s.pad = 0;
     c.fork();

@@ -167,55 +167,72 @@ __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const T* __restrict__ 
 // ---------------------------------------------------------------- column statistics  (M x C matrix)
 // out[blk][k][c]:  k=0: sum g'   k=1: sum g'*a   k=2: sum g'*b      with g' = g * (y > 0) if y given
 // (a == nullptr -> only k=0;  "sum x, sum x^2" is obtained with g = a = x)
-template <typename T>
+// Specialised on (mask present, number of sums) and unrolled over two row groups so that all 2..8 16-byte loads of an
+// iteration are in flight together (the runtime-flag form issued them one dependent group at a time: 2x slower).
+template <typename T, bool HASY, int NK>
 __global__ void __launch_bounds__(256) colstats_kernel(const T* __restrict__ g, const T* __restrict__ y, const T* __restrict__ a,
                                                        const T* __restrict__ b, int M, int C, int ld, int rows_per_block,
-                                                       float* __restrict__ out, int nk, int srows) {
+                                                       float* __restrict__ out, int srows) {
   constexpr int EPS = tf::Elem<T>::kPer16B;
   const int ct = C / EPS;                         // threads across channels (<= 256)
   const int rt = 256 / ct;                        // rows in flight
   const int tc = threadIdx.x % ct, tr = threadIdx.x / ct;
-  extern __shared__ float red[];                  // [rt][nk][C]
+  extern __shared__ float red[];                  // [rt][NK][C]
   float s0[EPS], s1[EPS], s2[EPS];
 #pragma unroll
   for (int j = 0; j < EPS; ++j) { s0[j] = 0.f; s1[j] = 0.f; s2[j] = 0.f; }
   const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  auto ld16 = [&](const T* p, size_t o) { return *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p) + o); };
+  auto accum = [&](const uint4& gq, const uint4& yq, const uint4& aq, const uint4& bq) {
+    float gf[EPS], f[EPS];
+    tf::unpack16<T>(gq, gf);
+    if (HASY) {
+      tf::unpack16<T>(yq, f);
+#pragma unroll
+      for (int j = 0; j < EPS; ++j) if (!(f[j] > 0.f)) gf[j] = 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < EPS; ++j) s0[j] += gf[j];
+    if (NK > 1) {
+      tf::unpack16<T>(aq, f);
+#pragma unroll
+      for (int j = 0; j < EPS; ++j) s1[j] += gf[j] * f[j];
+    }
+    if (NK > 2) {
+      tf::unpack16<T>(bq, f);
+#pragma unroll
+      for (int j = 0; j < EPS; ++j) s2[j] += gf[j] * f[j];
+    }
+  };
   if (tr < rt) {
-    for (int r = r0 + tr; r < r1; r += rt) {
-      const size_t o = ((size_t)r * ld + tc * EPS) * sizeof(T);
-      float gf[EPS], f[EPS];
-      tf::unpack16<T>(*reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(g) + o), gf);
-      if (y) {
-        tf::unpack16<T>(*reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(y) + o), f);
-#pragma unroll
-        for (int j = 0; j < EPS; ++j) if (!(f[j] > 0.f)) gf[j] = 0.f;
-      }
-#pragma unroll
-      for (int j = 0; j < EPS; ++j) s0[j] += gf[j];
-      if (a) {
-        tf::unpack16<T>(*reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a) + o), f);
-#pragma unroll
-        for (int j = 0; j < EPS; ++j) s1[j] += gf[j] * f[j];
-      }
-      if (b) {
-        tf::unpack16<T>(*reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(b) + o), f);
-#pragma unroll
-        for (int j = 0; j < EPS; ++j) s2[j] += gf[j] * f[j];
-      }
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    int r = r0 + tr;
+    for (; r + rt < r1; r += 2 * rt) {
+      const size_t o0 = ((size_t)r * ld + tc * EPS) * sizeof(T), o1 = ((size_t)(r + rt) * ld + tc * EPS) * sizeof(T);
+      const uint4 g0 = ld16(g, o0), g1 = ld16(g, o1);
+      const uint4 y0 = HASY ? ld16(y, o0) : z, y1 = HASY ? ld16(y, o1) : z;
+      const uint4 a0 = NK > 1 ? ld16(a, o0) : z, a1 = NK > 1 ? ld16(a, o1) : z;
+      const uint4 b0 = NK > 2 ? ld16(b, o0) : z, b1 = NK > 2 ? ld16(b, o1) : z;
+      accum(g0, y0, a0, b0);
+      accum(g1, y1, a1, b1);
+    }
+    if (r < r1) {
+      const size_t o0 = ((size_t)r * ld + tc * EPS) * sizeof(T);
+      accum(ld16(g, o0), HASY ? ld16(y, o0) : z, NK > 1 ? ld16(a, o0) : z, NK > 2 ? ld16(b, o0) : z);
     }
 #pragma unroll
     for (int j = 0; j < EPS; ++j) {
-      red[(tr * nk + 0) * C + tc * EPS + j] = s0[j];
-      if (nk > 1) red[(tr * nk + 1) * C + tc * EPS + j] = s1[j];
-      if (nk > 2) red[(tr * nk + 2) * C + tc * EPS + j] = s2[j];
+      red[(tr * NK + 0) * C + tc * EPS + j] = s0[j];
+      if (NK > 1) red[(tr * NK + 1) * C + tc * EPS + j] = s1[j];
+      if (NK > 2) red[(tr * NK + 2) * C + tc * EPS + j] = s2[j];
     }
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < nk * C; e += 256) {
+  for (int e = threadIdx.x; e < NK * C; e += 256) {
     float t = 0.f;
-    for (int r = 0; r < rt; ++r) t += red[r * nk * C + e];
-    if ((int)gridDim.x <= srows) out[(size_t)blockIdx.x * nk * C + e] = t;
-    else atomicAdd(&out[(size_t)(blockIdx.x % srows) * nk * C + e], t);      // rows are zero on entry (finalize clears)
+    for (int r = 0; r < rt; ++r) t += red[r * NK * C + e];
+    if ((int)gridDim.x <= srows) out[(size_t)blockIdx.x * NK * C + e] = t;
+    else atomicAdd(&out[(size_t)(blockIdx.x % srows) * NK * C + e], t);      // rows are zero on entry (finalize clears)
   }
 }
 
@@ -340,8 +357,18 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__
   }
 }
 
+// EPS consecutive per-channel coefficients as 16-byte loads (a conditional per-element form does not vectorise: 3x slower kernel)
+template <int EPS>
+__device__ __forceinline__ void load_coef(const float* __restrict__ p, float (&out)[EPS]) {
+#pragma unroll
+  for (int j = 0; j < EPS; j += 4) {
+    const float4 v = *reinterpret_cast<const float4*>(p + j);
+    out[j] = v.x; out[j + 1] = v.y; out[j + 2] = v.z; out[j + 3] = v.w;
+  }
+}
+
 // y = relu(x*s1+h1 + (r*s2+h2  |  r))      block output of a Bottleneck in training mode
-template <typename T>
+template <typename T, bool DS>
 __global__ void __launch_bounds__(256) bn_add_relu_kernel(const T* __restrict__ x, const float* __restrict__ s1, const float* __restrict__ h1,
                                                           const T* __restrict__ r, const float* __restrict__ s2, const float* __restrict__ h2,
                                                           size_t M, int C, T* __restrict__ y) {
@@ -351,17 +378,16 @@ __global__ void __launch_bounds__(256) bn_add_relu_kernel(const T* __restrict__ 
   const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x;
   const int s = (int)(i0 % spr);
   float a1[EPS], b1[EPS], a2[EPS], b2[EPS];
-#pragma unroll
-  for (int j = 0; j < EPS; ++j) {
-    a1[j] = s1[s * EPS + j]; b1[j] = h1[s * EPS + j];
-    a2[j] = s2 ? s2[s * EPS + j] : 1.f; b2[j] = s2 ? h2[s * EPS + j] : 0.f;
+  load_coef<EPS>(s1 + s * EPS, a1); load_coef<EPS>(h1 + s * EPS, b1);
+  if (DS) {
+    load_coef<EPS>(s2 + s * EPS, a2); load_coef<EPS>(h2 + s * EPS, b2);
   }
   for (size_t i = i0; i < total; i += (size_t)gridDim.x * 256) {
     float xf[EPS], rf[EPS];
     tf::unpack16<T>(*reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(x) + i * 16), xf);
     tf::unpack16<T>(*reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(r) + i * 16), rf);
 #pragma unroll
-    for (int j = 0; j < EPS; ++j) xf[j] = fmaxf(xf[j] * a1[j] + b1[j] + (rf[j] * a2[j] + b2[j]), 0.f);
+    for (int j = 0; j < EPS; ++j) xf[j] = fmaxf(xf[j] * a1[j] + b1[j] + (DS ? rf[j] * a2[j] + b2[j] : rf[j]), 0.f);
     *reinterpret_cast<uint4*>(reinterpret_cast<char*>(y) + i * 16) = tf::pack16<T>(xf);
   }
 }
@@ -580,8 +606,12 @@ extern "C" int tf_colstats(int dtype, const void* g, const void* y, const void* 
   const int nblk = (M + rows - 1) / rows;
   const size_t lds = (size_t)rt * nk * C * 4;
   if (lds > 64 * 1024) return TF_ERR_UNSUPPORTED;
-  DISPATCH_T(dtype, hipLaunchKernelGGL(colstats_kernel<T>, dim3(nblk), dim3(256), lds, (hipStream_t)stream, (const T*)g, (const T*)y,
-                                       (const T*)a, (const T*)b, M, C, ld, rows, partial, nk, tf_get_stat_rows()));
+#define COLSTATS_LAUNCH(HASY, NK)                                                                                                   \
+  DISPATCH_T(dtype, hipLaunchKernelGGL((colstats_kernel<T, HASY, NK>), dim3(nblk), dim3(256), lds, (hipStream_t)stream, (const T*)g, \
+                                       (const T*)y, (const T*)a, (const T*)b, M, C, ld, rows, partial, tf_get_stat_rows()))
+  if (y) { if (nk == 3) COLSTATS_LAUNCH(true, 3); else if (nk == 2) COLSTATS_LAUNCH(true, 2); else COLSTATS_LAUNCH(true, 1); }
+  else   { if (nk == 3) COLSTATS_LAUNCH(false, 3); else if (nk == 2) COLSTATS_LAUNCH(false, 2); else COLSTATS_LAUNCH(false, 1); }
+#undef COLSTATS_LAUNCH
   TF_CHECK_LAUNCH();
   return TF_OK;
 }
@@ -627,8 +657,13 @@ extern "C" int tf_bn_add_relu(int dtype, const void* x, const float* s1, const f
                               int64_t M, int C, void* y, void* stream) {
   if (!x || !r || !y || !s1 || !h1 || C % 8) return TF_ERR_ARG;
   const size_t total = (size_t)M * (C / (dtype == TF_BF16 ? 8 : 4));
-  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_add_relu_kernel<T>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const T*)x, s1, h1,
-                                       (const T*)r, s2, h2, (size_t)M, C, (T*)y));
+  if (s2 && h2) {
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_add_relu_kernel<T, true>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const T*)x, s1,
+                                         h1, (const T*)r, s2, h2, (size_t)M, C, (T*)y));
+  } else {
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_add_relu_kernel<T, false>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const T*)x, s1,
+                                         h1, (const T*)r, s2, h2, (size_t)M, C, (T*)y));
+  }
   TF_CHECK_LAUNCH();
   return TF_OK;
 }

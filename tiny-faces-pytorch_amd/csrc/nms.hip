@@ -12,28 +12,38 @@
 
 namespace {
 
+// rank[i] = #{j : s_j > s_i or (s_j == s_i and j < i)} == position of i in the stable descending argsort
+// (evaluation.py:84 -> torchvision nms sorts by score; ties keep input order).  32 boxes x 8 column slices per block:
+// lanes with the same slice read the same LDS word (broadcast), so a wave touches two addresses per step.
 __global__ void __launch_bounds__(256) nms_rank_kernel(const double* __restrict__ scores, const double* __restrict__ boxes,
                                                        int n, int* __restrict__ order, double* __restrict__ sboxes) {
-  __shared__ double tile[1024];
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  __shared__ double tile[2048];
+  __shared__ int part[8][32];
+  const int li = threadIdx.x & 31, p = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + li;
   const double si = i < n ? scores[i] : 0.0;
   int rank = 0;
-  for (int j0 = 0; j0 < n; j0 += 1024) {
+  for (int j0 = 0; j0 < n; j0 += 2048) {
     __syncthreads();
-    for (int k = threadIdx.x; k < 1024; k += 256) tile[k] = (j0 + k < n) ? scores[j0 + k] : 0.0;
+    for (int k = threadIdx.x; k < 2048; k += 256) tile[k] = (j0 + k < n) ? scores[j0 + k] : -1.0e300;
     __syncthreads();
-    const int lim = min(1024, n - j0);
-    if (i < n) {
-      for (int k = 0; k < lim; ++k) {
-        const double sj = tile[k];
-        rank += (sj > si) || (sj == si && (j0 + k) < i);
-      }
+    const int lim = min(2048, n - j0);
+    // strictly-greater never counts the -1e300 padding; the tie term is masked by the index bound
+#pragma unroll 4
+    for (int k = p; k < lim; k += 8) {
+      const double sj = tile[k];
+      rank += (sj > si) || (sj == si && (j0 + k) < i);
     }
   }
-  if (i < n) {
-    order[rank] = i;
+  part[p][li] = rank;
+  __syncthreads();
+  if (p == 0 && i < n) {
+    int r = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) r += part[q][li];
+    order[r] = i;
     const double4 b = *reinterpret_cast<const double4*>(boxes + 4 * (size_t)i);
-    *reinterpret_cast<double4*>(sboxes + 4 * (size_t)rank) = b;
+    *reinterpret_cast<double4*>(sboxes + 4 * (size_t)r) = b;
   }
 }
 
@@ -69,41 +79,63 @@ __global__ void __launch_bounds__(64) nms_mask_kernel(const double* __restrict__
   mask[(size_t)i * nwords + cb] = bits;
 }
 
+// Greedy scan over the score-sorted boxes, 64 at a time.  Wave 0 walks the chain: it resolves chunk c against removed[c]
+// (64 scalar steps on the diagonal word), then folds the rows it kept into removed[c+1] itself (one prefetched word per lane,
+// wave OR-reduction), so the next chunk can start at once.  Waves 1..15 trail one chunk behind and push the kept rows of
+// chunk c-1 into removed[w], w >= c+1, five row-slices per word with LDS atomics; one barrier per chunk joins the two.
 __global__ void __launch_bounds__(1024) nms_scan_kernel(const unsigned long long* __restrict__ mask, const int* __restrict__ order,
                                                         int n, int nwords, int64_t* __restrict__ keep, int* __restrict__ num_keep) {
-  extern __shared__ unsigned long long removed[];   // nwords + 1 (slot nwords = keep bits of the current chunk)
-  for (int w = threadIdx.x; w <= nwords; w += blockDim.x) removed[w] = 0;
+  extern __shared__ unsigned long long removed[];   // nwords + 2: [nwords] / [nwords+1] = keep bits of even / odd chunks
+  for (int w = threadIdx.x; w < nwords + 2; w += blockDim.x) removed[w] = 0;
   __syncthreads();
   int kcount = 0;                                    // meaningful in wave 0 only
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int c = 0; c < nwords; ++c) {
+  for (int c = 0; c <= nwords; ++c) {
     if (wave == 0) {
-      const int i = c * 64 + lane;
-      unsigned long long diag = (i < n) ? mask[(size_t)i * nwords + c] : 0ull;
-      unsigned long long rem = removed[c];
-      const int nvalid = min(64, n - c * 64);                // boxes past n do not exist
-      unsigned long long kb = 0;
-      const unsigned int dlo = (unsigned int)diag, dhi = (unsigned int)(diag >> 32);
-      for (int b = 0; b < 64; ++b) {
-        // readlane returns a SIGNED int: go through unsigned or the low word sign-extends into the high word
-        const unsigned long long d = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dhi, b) << 32) |
-                                     (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dlo, b);
-        if (b < nvalid && !((rem >> b) & 1ull)) { kb |= 1ull << b; rem |= d; }
+      if (c < nwords) {
+        const int i = c * 64 + lane;
+        const unsigned long long diag = (i < n) ? mask[(size_t)i * nwords + c] : 0ull;
+        const unsigned long long next = (i < n && c + 1 < nwords) ? mask[(size_t)i * nwords + c + 1] : 0ull;
+        const int oi = (i < n) ? order[i] : 0;                  // issued with the mask words, long before it is needed
+        unsigned long long rem = removed[c];
+        const int nvalid = min(64, n - c * 64);                // boxes past n do not exist
+        unsigned long long kb = 0;
+        const unsigned int dlo = (unsigned int)diag, dhi = (unsigned int)(diag >> 32);
+        for (int b = 0; b < 64; ++b) {
+          // readlane returns a SIGNED int: go through unsigned or the low word sign-extends into the high word
+          const unsigned long long d = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dhi, b) << 32) |
+                                       (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dlo, b);
+          if (b < nvalid && !((rem >> b) & 1ull)) { kb |= 1ull << b; rem |= d; }
+        }
+        const bool mine = (kb >> lane) & 1ull;
+        if (mine) keep[kcount + __popcll(kb & ((1ull << lane) - 1ull))] = (int64_t)oi;
+        kcount += __popcll(kb);
+        // rows kept in this chunk -> removed[c+1] (the only word the next resolve needs from this chunk)
+        unsigned int lo = mine ? (unsigned int)next : 0u, hi = mine ? (unsigned int)(next >> 32) : 0u;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { lo |= __shfl_xor(lo, off, 64); hi |= __shfl_xor(hi, off, 64); }
+        if (lane == 0) {
+          if (c + 1 < nwords) atomicOr(&removed[c + 1], ((unsigned long long)hi << 32) | lo);
+          removed[nwords + (c & 1)] = kb;
+        }
       }
-      if ((kb >> lane) & 1ull) keep[kcount + __popcll(kb & ((1ull << lane) - 1ull))] = (int64_t)order[i];
-      kcount += __popcll(kb);
-      if (lane == 0) removed[nwords] = kb;
-    }
-    __syncthreads();
-    const unsigned long long kb = removed[nwords];
-    for (int w = c + 1 + threadIdx.x; w < nwords; w += blockDim.x) {
-      unsigned long long acc = 0, k = kb;
-      while (k) {
-        const int b = __ffsll((long long)k) - 1;
-        k &= k - 1;
-        acc |= mask[(size_t)(c * 64 + b) * nwords + w];
+    } else if (c >= 1) {
+      // trailing push of chunk c-1's kept rows into words >= c+1
+      const unsigned long long kb = removed[nwords + ((c - 1) & 1)];
+      const int t = threadIdx.x - 64;                    // 0..959
+      const int slice = t % 5, wi = t / 5;                // 192 words per sweep, 5 row-slices each
+      // slice s owns bits {s, s+5, ...}: walk the set bits, keep every 5th
+      for (int w = c + 1 + wi; w < nwords; w += 192) {
+        unsigned long long acc = 0, k = kb;
+        int idx = 0;
+        while (k) {
+          const int b = __ffsll((long long)k) - 1;
+          k &= k - 1;
+          if (idx == slice) acc |= mask[(size_t)((c - 1) * 64 + b) * nwords + w];
+          idx = idx == 4 ? 0 : idx + 1;
+        }
+        if (acc) atomicOr(&removed[w], acc);
       }
-      removed[w] |= acc;
     }
     __syncthreads();
   }
@@ -128,14 +160,14 @@ extern "C" int tf_nms_f64(const double* boxes, const double* scores, int n, doub
   if (!boxes || !scores || !keep_out) return TF_ERR_ARG;
   if (!ws || ws_bytes < tf_nms_workspace_bytes(n)) return TF_ERR_WORKSPACE;
   const int nwords = (n + 63) / 64;
-  if ((size_t)(nwords + 1) * 8 > 64 * 1024) return TF_ERR_UNSUPPORTED;   // n <= 524k
+  if ((size_t)(nwords + 2) * 8 > 64 * 1024) return TF_ERR_UNSUPPORTED;   // n <= 524k
   char* w = (char*)ws;
   int* order = (int*)w;                 w += align256((size_t)n * 4);
   double* sboxes = (double*)w;          w += align256((size_t)n * 32);
   unsigned long long* mask = (unsigned long long*)w;
-  hipLaunchKernelGGL(nms_rank_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, scores, boxes, n, order, sboxes);
+  hipLaunchKernelGGL(nms_rank_kernel, dim3((n + 31) / 32), dim3(256), 0, stream, scores, boxes, n, order, sboxes);
   hipLaunchKernelGGL(nms_mask_kernel, dim3(nwords, nwords), dim3(64), 0, stream, sboxes, n, iou_thresh, nwords, mask);
-  hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(1024), (size_t)(nwords + 1) * 8, stream, mask, order, n, nwords,
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(1024), (size_t)(nwords + 2) * 8, stream, mask, order, n, nwords,
                      keep_out, num_keep);
   TF_CHECK_LAUNCH();
   return TF_OK;

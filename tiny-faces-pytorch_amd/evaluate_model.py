@@ -37,7 +37,8 @@ def main():
     if args.dataset != "synthetic":
         raise SystemExit("WIDER FACE file loading is out of scope this round: use `synthetic` or call get_detections on your own images")
     g = torch.Generator().manual_seed(0)
-    with torch.no_grad():
+    model = model.to(device).eval()
+    with torch.no_grad(), model.constant_weights():          # the checkpoint does not change between images: pack the weights once
         for i in range(args.num_images):
             img = torch.rand(3, 480, 640, generator=g)
             dets = get_detections(model, img, templates, ops.RF, tf, args.prob_thresh, args.nms_thresh, device=device)

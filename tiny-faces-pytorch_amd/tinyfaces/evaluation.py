@@ -47,7 +47,9 @@ def get_detections(model, img, templates, rf, img_transforms, prob_thresh=0.65, 
     cap = sum(((x.shape[2] + 7) // 8) * ((x.shape[3] + 7) // 8) for _, x in levels) * nt
     dets = torch.empty(max(cap, 1), 5, dtype=torch.float64, device=device)
     count = torch.zeros(1, dtype=torch.int32, device=device)
-    with torch.no_grad():
+    biggest = max(levels, key=lambda l: l[1].shape[2] * l[1].shape[3])[1]
+    # weights are constant across the pyramid (and across images when the caller already opened a session): pack once
+    with torch.no_grad(), model.constant_weights(reserve=(1, biggest.shape[2], biggest.shape[3])):
         for scale, x in levels:
             out = model(x.to(device, non_blocking=True))                  # (1, 5nt, H', W')
             _, _, H, W = out.shape

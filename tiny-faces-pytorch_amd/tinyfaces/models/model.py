@@ -10,6 +10,7 @@ What is kept from the reference:
 What is different: forward/backward never run torch ops.  One C-ABI call per pass launches the
 hand-written gfx950 kernels; a CPU tensor raises (there is no CPU fallback).
 """
+import contextlib
 import ctypes as C
 import os
 
@@ -19,6 +20,8 @@ from torch import nn
 
 from .. import _hip
 from .._hip import check, lib, ptr, stream
+
+TF_DETNET_WEIGHTS_READY = 1      # include/tinyfaces_hip.h
 
 
 class _Bottleneck(nn.Module):
@@ -114,6 +117,8 @@ class DetectionModel(nn.Module):
         self._ws = None
         self._ws_generation = 0
         self._table_key = None
+        self._session_depth = 0          # constant_weights() nesting
+        self._ready_key = None           # (workspace ptr, dtype, table key) whose packed eval weights sit in the workspace
         if isinstance(pretrained_weights, (str, os.PathLike)):           # no network here: a local file only
             sd = torch.load(pretrained_weights, map_location="cpu")
             self.load_state_dict(sd.get("model", sd), strict=False)
@@ -237,6 +242,25 @@ class DetectionModel(nn.Module):
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
         return self._ws
 
+    @contextlib.contextmanager
+    def constant_weights(self, reserve=None):
+        """Promise that no parameter/buffer value changes inside the block (eval mode): the executor packs the weights
+        and folds the BN statistics on the first forward and reuses them for every later one, whatever the image size.
+        The pyramid of get_detections (evaluation.py:49-82) is 3-5 forwards on constant weights.  `reserve=(N, H, W)` sizes
+        the workspace for the largest input up front so that it is not re-allocated (which would drop the packed copy)."""
+        if reserve is not None:
+            dev = next(self.parameters()).device
+            self._workspace(dev, lib().tf_detnet_workspace_bytes(self.compute_dtype, *reserve, self.num_out, 0))
+        if self._session_depth == 0:
+            self._ready_key = None
+        self._session_depth += 1
+        try:
+            yield self
+        finally:
+            self._session_depth -= 1
+            if self._session_depth == 0:
+                self._ready_key = None
+
     def _run_forward(self, x, training):
         N, _, H, W = x.shape
         H3, W3 = C.c_int(), C.c_int()
@@ -247,9 +271,17 @@ class DetectionModel(nn.Module):
         self._ws_shape = (N, H, W)
         out = torch.empty(N, self.num_out, H3.value, W3.value, dtype=torch.float32, device=x.device)
         bn = self.model.bn1
+        flags = 0
+        if training:
+            self._ready_key = None
+        elif self._session_depth > 0:
+            key = (ws.data_ptr(), self.compute_dtype, self._table_key)
+            if key == self._ready_key:
+                flags = TF_DETNET_WEIGHTS_READY
+            self._ready_key = key
         with torch.cuda.device(x.device):
             check(lib().tf_detnet_forward(self.compute_dtype, int(training), ptr(x), N, H, W, self.num_out, self._param_ptrs,
-                                          float(bn.eps), float(bn.momentum), ptr(out), ptr(ws), ws.numel(), stream()),
+                                          float(bn.eps), float(bn.momentum), ptr(out), ptr(ws), ws.numel(), flags, stream()),
                   "tf_detnet_forward")
         if training:
             if getattr(self, "_flat_nbt", None) is not None:
