@@ -31,6 +31,7 @@ import torch  # noqa: E402
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}       # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 FWD_GFLOP_PER_IMG = 73.559                           # BASELINE.md section 3 (2*MACs of all 97 convs @500x500)
+PROFILE_EVERY = 11                                    # roofline timing: HIP events around every 11th MFMA launch (287 launches/step is not a multiple: the sample rotates over the layers)
 KIND_NAMES = {0: "conv_igemm<f32,128x128>", 1: "conv_igemm<f32,128x64>", 2: "conv_igemm<f32,64x64>",
               3: "conv_igemm<bf16,128x128>", 4: "conv_igemm<bf16,128x64>", 5: "conv_igemm<bf16,64x64>",
               8: "wgrad<f32,64>", 9: "wgrad<f32,128>", 10: "wgrad<bf16,64>", 11: "wgrad<bf16,128>",
@@ -169,6 +170,8 @@ def main():
     device = torch.device(f"cuda:{local % torch.cuda.device_count() if share else local}")
     torch.cuda.set_device(device)
     _hip.lib()                                           # fail loudly if the HIP library is missing
+    if os.environ.get("TINYFACES_STAT_ROWS"):            # tuning knob: BN statistic partial rows (default TF_STAT_ROWS = 64)
+        _hip.lib().tf_set_stat_rows(int(os.environ["TINYFACES_STAT_ROWS"]))
 
     templates = load_templates()
     t_d = torch.as_tensor(templates, dtype=torch.float64).to(device)
@@ -193,7 +196,7 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     if not args.no_profile:
-        _hip.lib().tf_profile_enable(1)
+        _hip.lib().tf_profile_enable(PROFILE_EVERY)     # HIP events around 1 MFMA launch in PROFILE_EVERY (an event pair costs ~5 us of stream time)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -233,11 +236,12 @@ def main():
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         out["roofline"] = {"kernel": KIND_NAMES.get(dom["kind"], str(dom["kind"])), "bound": "mfma", "achieved": round(ach, 2), "peak": peak,
                            "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None, "launches": dom["launches"],
+                           "sampling": f"HIP events around 1 launch in {PROFILE_EVERY} over the timed region",
                            "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
                            "algorithmic_gflop_per_launch": round(dom["flops"] / dom["launches"] / 1e9, 3),
                            "algorithmic_gb_s": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9, 1),
-                           "share_of_timed_region": round(dom["ms"] / (dt * 1e3), 3)}
-        out["kernels"] = [{"kernel": KIND_NAMES.get(r["kind"], str(r["kind"])), "launches": r["launches"], "ms_per_step": round(r["ms"] / args.steps, 3),
+                           "share_of_timed_region": round(dom["ms"] * PROFILE_EVERY / (dt * 1e3), 3)}
+        out["kernels"] = [{"kernel": KIND_NAMES.get(r["kind"], str(r["kind"])), "launches": r["launches"], "ms_per_step": round(r["ms"] * PROFILE_EVERY / args.steps, 3),
                            "tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 1), "gb_s": round(r["bytes"] / (r["ms"] * 1e-3) / 1e9, 1)} for r in prof]
     if world == 1 and not args.no_eval:
         try:

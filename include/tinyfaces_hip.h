@@ -138,8 +138,9 @@ int tf_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n,
 #define TF_EPI_JOIN 64
 /* partial-sum rows of one launch are folded (atomics) into at most this many rows; consumers pass clear=1 to the
  * last finalize that reads them so that the buffer is zero again for the next producer */
-#define TF_STAT_ROWS 64
-/* rows <= 0: do not fold (one partial row per tile / block, plain stores: bit-reproducible statistics); default TF_STAT_ROWS */
+#define TF_STAT_ROWS 16
+/* rows <= 0: do not fold (one partial row per tile / block, plain stores: bit-reproducible statistics; the executor then
+ * uses the separate finalize kernels); 1..TF_STAT_ROWS: folded rows (fp32 atomics); default 8 */
 int tf_set_stat_rows(int rows);
 int tf_get_stat_rows(void);
 
@@ -222,6 +223,30 @@ int tf_bn_relu(int dtype, const void* x, const float* scale, const float* shift,
 /* Bottleneck output in training mode: y = relu(x*s1+h1 + (r*s2+h2 | r)) */
 int tf_bn_add_relu(int dtype, const void* x, const float* s1, const float* h1, const void* r, const float* s2,
                    const float* h2, int64_t M, int C, void* y, void* stream);
+/* ---- training-mode BN consumers that finalize the batch statistics in-kernel (no separate finalize launch) ----
+ * The producer (tf_conv2d with TF_EPI_STATS/STATS2, tf_colstats) leaves `rows` = tf_get_stat_rows() <= TF_STAT_ROWS
+ * partial rows [rows][nk][C] in a region that was zero before it ran; every block re-derives the coefficients of its
+ * 64-channel slice; the first row-block of each slice publishes scale/shift/mean/invstd (+ running statistics update)
+ * or dgamma/dbeta.  Same arithmetic as tf_bn_finalize / tf_bn_bwd_finalize (torch.nn.BatchNorm2d training semantics of
+ * the torchvision trunk built at tinyfaces/models/model.py:17-23).                                                    */
+typedef struct tf_bn_fwd_desc {
+  const float* stat;                 /* [rows][2][C] sum, sum of squares */
+  const float* gamma; const float* beta;
+  float* scale; float* shift; float* mean; float* invstd;        /* published */
+  float* running_mean; float* running_var;                        /* updated in place (may be NULL) */
+} tf_bn_fwd_desc;
+typedef struct tf_bn_bwd_desc {
+  const float* stat;                 /* [rows][nk][C]: k = 0 sum gz, k = kidx sum gz*x */
+  const float* gamma; const float* mean; const float* invstd;
+  float* dgamma; float* dbeta;       /* published (may be NULL) */
+  int nk, kidx;
+} tf_bn_bwd_desc;
+int tf_bn_relu_fused(int dtype, const void* x, const tf_bn_fwd_desc* bn, int rows, int64_t M, int C, float count,
+                     float eps, float momentum, void* y, void* stream);
+int tf_bn_add_relu_fused(int dtype, const void* x, const tf_bn_fwd_desc* bn, const void* r, const tf_bn_fwd_desc* bn_r /* NULL: identity */,
+                         int rows, int64_t M, int C, float count, float eps, float momentum, void* y, void* stream);
+int tf_bn_bwd_apply_fused(int dtype, const void* g, const void* y /* NULL: no ReLU mask */, const void* x, const tf_bn_bwd_desc* bn,
+                          int rows, int64_t M, int C, float count, void* out, void* stream);
 /* score4_upsample (frozen bilinear ConvTranspose2d k4 s2 p1, model.py:34-40,107) + crop (:110-124)
  * + add (:126); wup_diag [C][4][4] = the channel diagonal of the (C,C,4,4) weight; output NCHW fp32. */
 int tf_upsample_add_crop(int dtype, const void* s3, const void* s4, const float* wup_diag, int B, int C, int ldc,
@@ -266,7 +291,7 @@ int tf_detnet_backward(int dtype, const float* x_nchw, int N, int H, int W, int 
  * rows of 5 doubles to HOST memory: kind, launches, total_ms, algorithmic flops, algorithmic
  * bytes.  kind 0..5 = conv_igemm (dtype*3 + tile-1), 8..11 = wgrad (8 + dtype*2 + (tile==128)),
  * 12/13 = conv_dma f32/bf16, 14 = wgrad_dma bf16. */
-int tf_profile_enable(int on);
+int tf_profile_enable(int every);   /* 0 = off, 1 = bracket every launch, n = every n-th launch (sampling keeps the timed region undisturbed) */
 int tf_profile_collect(double* host_out, int max_rows);
 /* test hook: raw lane mapping of ds_read_b64_tr_b16 (see tests/test_gpu_small_ops.py) */
 int tf_probe_tr16(unsigned short* out256, void* stream);

@@ -318,6 +318,86 @@ def test_bn_train_forward_backward_chain(dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("C,ds", [(64, False), (256, True), (1024, False), (512, True)])
+def test_bn_fused_consumers_chain(dtype, C, ds):
+    """The in-kernel-finalize consumers (bn_fused.hip): colstats rows -> tf_bn_relu_fused / tf_bn_add_relu_fused forward,
+    colstats(masked) rows -> tf_bn_bwd_apply_fused backward, vs torch BatchNorm2d(train) (+ second BN on the residual
+    branch when ds) + add + relu autograd.  Rows come from a zeroed region, as in the executor."""
+    from tinyfaces import _hip
+    from tinyfaces._hip import lib, ptr, stream, tf_dtype
+    g = _g(100 + C)
+    N, H, W = 3, 11, 13
+    M = N * H * W
+    tfd = tf_dtype(dtype)
+    R = lib().tf_get_stat_rows()
+    assert 1 <= R <= 16
+    xr = torch.randn(N, C, H, W, generator=g) * 1.3 + 0.2
+    idn = torch.randn(N, C, H, W, generator=g) * 0.7 - 0.1
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    gamma2, beta2 = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    xq = q(xr, dtype).requires_grad_(True)
+    iq = q(idn, dtype).requires_grad_(True)
+    gm, bt = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    gm2, bt2 = gamma2.clone().requires_grad_(True), beta2.clone().requires_grad_(True)
+    rm, rv, rm2, rv2 = torch.zeros(C), torch.ones(C), torch.zeros(C), torch.ones(C)
+    dev = lambda t: t.clone().cuda()
+    rmd, rvd, rm2d, rv2d = dev(rm), dev(rv), dev(rm2), dev(rv2)
+    branch = F.batch_norm(iq, rm2, rv2, gm2, bt2, True, 0.1, 1e-5) if ds else iq
+    yref = torch.relu(F.batch_norm(xq, rm, rv, gm, bt, True, 0.1, 1e-5) + branch)
+    r1ref = torch.relu(F.batch_norm(xq.detach(), torch.zeros(C), torch.ones(C), gamma, beta, True, 0.1, 1e-5))
+    gy = torch.randn(yref.shape, generator=g)
+    yref.backward(q(gy, dtype))
+    x_d, id_d = to_nhwc(xr, dtype), to_nhwc(idn, dtype)
+    z = lambda: torch.zeros(C, device="cuda")
+
+    def fwd_rows(t):
+        rows = torch.zeros(16, 2, C, device="cuda")
+        assert lib().tf_colstats(tfd, ptr(t), None, ptr(t), None, M, C, C, ptr(rows), stream()) == 0
+        return rows
+    rows1, rows2 = fwd_rows(x_d), fwd_rows(id_d)
+    gd, bd, g2d, b2d = gamma.cuda(), beta.cuda(), gamma2.cuda(), beta2.cuda()
+    sc, sh, mean, invstd = z(), z(), z(), z()
+    sc2, sh2, mean2, invstd2 = z(), z(), z(), z()
+    d1 = _hip.BnFwdDesc(ptr(rows1), ptr(gd), ptr(bd), ptr(sc), ptr(sh), ptr(mean), ptr(invstd), ptr(rmd), ptr(rvd))
+    d2 = _hip.BnFwdDesc(ptr(rows2), ptr(g2d), ptr(b2d), ptr(sc2), ptr(sh2), ptr(mean2), ptr(invstd2), ptr(rm2d), ptr(rv2d))
+    # bn + relu (no running-stat update in this call: the descriptor without running pointers)
+    keep = [z(), z(), z(), z()]                                   # published vectors of the throw-away call (must stay alive)
+    d1n = _hip.BnFwdDesc(ptr(rows1), ptr(gd), ptr(bd), ptr(keep[0]), ptr(keep[1]), ptr(keep[2]), ptr(keep[3]), None, None)
+    r1_d = torch.empty_like(x_d)
+    assert lib().tf_bn_relu_fused(tfd, ptr(x_d), d1n, R, M, C, float(M), 1e-5, 0.1, ptr(r1_d), stream()) == 0
+    dr1 = err(from_nhwc(r1_d), r1ref)
+    y_d = torch.empty_like(x_d)
+    assert lib().tf_bn_add_relu_fused(tfd, ptr(x_d), d1, ptr(id_d), d2 if ds else None, R, M, C, float(M), 1e-5, 0.1, ptr(y_d), stream()) == 0
+    dy = err(from_nhwc(y_d), yref.detach())
+    drm, drv = err(rmd.cpu(), rm), err(rvd.cpu(), rv)
+    if ds:
+        drm2, drv2 = err(rm2d.cpu(), rm2), err(rv2d.cpu(), rv2)
+        assert drm2[0] < 1e-4 and drv2[0] < 1e-3
+    # backward: sums of gz = gy*(y>0): k1 with x, k2 with the residual-branch input (ds)
+    gy_d = to_nhwc(gy, dtype)
+    nk = 3 if ds else 2
+    brow = torch.zeros(16, nk, C, device="cuda")
+    assert lib().tf_colstats(tfd, ptr(gy_d), ptr(y_d), ptr(x_d), ptr(id_d) if ds else None, M, C, C, ptr(brow), stream()) == 0
+    dga, dbe, dga2, dbe2 = z(), z(), z(), z()
+    b1 = _hip.BnBwdDesc(ptr(brow), ptr(gd), ptr(mean), ptr(invstd), ptr(dga), ptr(dbe), nk, 1)
+    gx_d = torch.empty_like(x_d)
+    assert lib().tf_bn_bwd_apply_fused(tfd, ptr(gy_d), ptr(y_d), ptr(x_d), b1, R, M, C, float(M), ptr(gx_d), stream()) == 0
+    dgx = err(from_nhwc(gx_d), xq.grad)
+    dgg, dgb = err(dga.cpu(), gm.grad), err(dbe.cpu(), bt.grad)
+    t = 1e-5 if dtype == torch.float32 else 1.5e-2
+    tg = 1e-4 if dtype == torch.float32 else 2e-2
+    if ds:
+        b2 = _hip.BnBwdDesc(ptr(brow), ptr(g2d), ptr(mean2), ptr(invstd2), ptr(dga2), ptr(dbe2), nk, 2)
+        gi_d = torch.empty_like(x_d)
+        assert lib().tf_bn_bwd_apply_fused(tfd, ptr(gy_d), ptr(y_d), ptr(id_d), b2, R, M, C, float(M), ptr(gi_d), stream()) == 0
+        dgi = err(from_nhwc(gi_d), iq.grad)
+        assert dgi[2] < tg and err(dga2.cpu(), gm2.grad)[2] < tg and err(dbe2.cpu(), bt2.grad)[2] < tg
+    report(f"bn_fused[{dtype},C={C},ds={ds}]", r1_rel=dr1[2], y_rel=dy[2], rm=drm[0], rv=drv[0], gx_rel=dgx[2], dgamma_rel=dgg[2], dbeta_rel=dgb[2])
+    assert dr1[2] < t and dy[2] < t and dgx[2] < tg
+    assert drm[0] < 1e-4 and drv[0] < 1e-3 and dgg[2] < tg and dgb[2] < tg
+
+
+@pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("hw", [(8, 8), (13, 17), (63, 63)])
 def test_upsample_add_crop_fwd_bwd(dtype, hw):
     """score4_upsample (ConvTranspose2d k4 s2 p1, bilinear diagonal) + crop + add, vs torch (model.py:104-126)."""

@@ -11,6 +11,7 @@ static const char* const kSymbols[] = {
     "tf_conv_mtiles", "tf_conv2d", "tf_pack_weight", "tf_pack_weights_batched", "tf_conv2d_wgrad", "tf_unpack_dw",
     "tf_stem_im2col", "tf_maxpool_fwd", "tf_maxpool_bwd", "tf_colstats_blocks", "tf_colstats",
     "tf_bn_finalize", "tf_bn_fold", "tf_bn_bwd_finalize", "tf_bn_bwd_apply", "tf_bn_relu", "tf_bn_add_relu",
+    "tf_bn_relu_fused", "tf_bn_add_relu_fused", "tf_bn_bwd_apply_fused",
     "tf_upsample_add_crop", "tf_upsample_add_crop_bwd", "tf_reduce_partials",
     "tf_detnet_num_params", "tf_detnet_param_name", "tf_detnet_param_numel", "tf_detnet_workspace_bytes",
     "tf_detnet_out_shape", "tf_detnet_param_region_bytes", "tf_detnet_forward", "tf_detnet_backward", "tf_detnet_set_dual_stream",
@@ -18,8 +19,8 @@ static const char* const kSymbols[] = {
 };
 
 extern "C" int tf_version(void) { return 100; }
-static int g_stat_rows = TF_STAT_ROWS;
-extern "C" int tf_set_stat_rows(int rows) { g_stat_rows = rows <= 0 ? (1 << 30) : rows; return TF_OK; }
+static int g_stat_rows = 8;
+extern "C" int tf_set_stat_rows(int rows) { g_stat_rows = rows <= 0 ? (1 << 30) : (rows > TF_STAT_ROWS ? TF_STAT_ROWS : rows); return TF_OK; }
 extern "C" int tf_get_stat_rows(void) { return g_stat_rows; }
 extern "C" int tf_symbol_count(void) { return (int)(sizeof(kSymbols) / sizeof(kSymbols[0])); }
 extern "C" const char* tf_symbol_name(int i) { return (i >= 0 && i < tf_symbol_count()) ? kSymbols[i] : nullptr; }

@@ -17,6 +17,7 @@
 //          output y = relu(bn3(c3) + identity) is a separate pass.
 //          backward: dgrad epilogues apply the ReLU mask and emit the BN-backward sums; the
 //          residual-join gradient is folded into conv1's dgrad epilogue.
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -125,10 +126,13 @@ struct Arena {
 };
 
 // per-BN scratch: scale/shift (forward affine), mean/invstd, backward coefficients
-struct BnBuf { float *scale, *shift, *mean, *invstd, *cA, *cB, *cD; };
+// fst / bst: this BN's own statistic rows ([TF_STAT_ROWS][2][C] forward sums, [TF_STAT_ROWS][3][C] backward sums) for the
+// consumers that finalize in-kernel (bn_fused.hip); all of them are zeroed by ONE memset per pass
+struct BnBuf { float *scale, *shift, *mean, *invstd, *cA, *cB, *cD, *fst, *bst; int C; };
 BnBuf bn_alloc(Arena& ar, int C) {
   BnBuf b; float* p = ar.f32((size_t)7 * C);
   b.scale = p; b.shift = p + C; b.mean = p + 2 * C; b.invstd = p + 3 * C; b.cA = p + 4 * C; b.cB = p + 5 * C; b.cD = p + 6 * C;
+  b.fst = b.bst = nullptr; b.C = C;
   return b;
 }
 
@@ -148,6 +152,7 @@ struct Plan {                    // everything a forward carves; backward re-der
   std::vector<Blk> blk;
   void *w_h3, *w_h4, *w_h3t, *w_h4t, *s3, *s4; float *hbias3, *hbias4, *ones, *wup_diag;
   float* partial; size_t partial_floats;
+  float *stat_fwd, *stat_bwd; size_t stat_fwd_floats, stat_bwd_floats;   // per-BN statistic regions (fused finalize)
   // backward-only
   void *g3, *g4, *G0, *G1, *T4, *R3, *wt; float* dwp;
   void *S1[2], *S2[2], *S3[2], *SD[2];   // per block parity: g_c3, g_c2, g_c1, g_d (read by the weight-gradient stream)   // gradient buffers (roles in tf_detnet_backward) + transposed-weight scratch
@@ -194,6 +199,24 @@ void build_plan(Plan& P, Arena& ar, int dtype, int N, int H, int W, int nout, in
   P.hbias3 = ar.f32(kHeadLd); P.hbias4 = ar.f32(kHeadLd); P.ones = ar.f32(kHeadLd);
   P.wup_diag = ar.f32((size_t)nout * 16);
   P.param_bytes = ar.off;
+  // ---- per-BN statistic regions, contiguous so that one memset per pass clears them
+  {
+    std::vector<BnBuf*> bns;
+    for (size_t i = 0; i < A.blocks.size(); ++i) {
+      Plan::Blk& b = P.blk[i];
+      bns.push_back(&b.b1); bns.push_back(&b.b2); bns.push_back(&b.b3);
+      if (A.blocks[i].has_ds) bns.push_back(&b.bd);
+    }
+    size_t nf = 0, nb = 0;
+    for (BnBuf* q : bns) { nf += (size_t)TF_STAT_ROWS * 2 * q->C; nb += (size_t)TF_STAT_ROWS * 3 * q->C; }
+    P.stat_fwd_floats = training ? nf : 0; P.stat_bwd_floats = training ? nb : 0;
+    P.stat_fwd = ar.f32(P.stat_fwd_floats); P.stat_bwd = ar.f32(P.stat_bwd_floats);
+    size_t of = 0, ob = 0;
+    for (BnBuf* q : bns) {
+      q->fst = training && P.stat_fwd ? P.stat_fwd + of : nullptr; q->bst = training && P.stat_bwd ? P.stat_bwd + ob : nullptr;
+      of += (size_t)TF_STAT_ROWS * 2 * q->C; ob += (size_t)TF_STAT_ROWS * 3 * q->C;
+    }
+  }
   // ---- activations
   P.col = ar.get(M1 * kStemK * es);
   P.cstem = ar.get(M1 * 64 * es);
@@ -300,6 +323,20 @@ void bn_forward(Ctx& c, const ConvUnit& u, int C, BnBuf& b, bool training, const
   }
 }
 
+tf_bn_fwd_desc fwd_desc(const Ctx& c, const ConvUnit& u, const BnBuf& b) {
+  tf_bn_fwd_desc d;
+  d.stat = b.fst; d.gamma = c.P(u.gamma); d.beta = c.P(u.beta);
+  d.scale = b.scale; d.shift = b.shift; d.mean = b.mean; d.invstd = b.invstd;
+  d.running_mean = (float*)c.params[u.rmean]; d.running_var = (float*)c.params[u.rvar];
+  return d;
+}
+tf_bn_bwd_desc bwd_desc(const Ctx& c, const ConvUnit& u, const BnBuf& b, const float* stat, int nk, int kidx) {
+  tf_bn_bwd_desc d;
+  d.stat = stat; d.gamma = c.P(u.gamma); d.mean = b.mean; d.invstd = b.invstd; d.dgamma = c.G(u.gamma); d.dbeta = c.G(u.beta);
+  d.nk = nk; d.kidx = kidx;
+  return d;
+}
+
 }  // namespace
 
 extern "C" int tf_detnet_num_params(void) { return (int)arch().names.size(); }
@@ -361,6 +398,12 @@ extern "C" int tf_detnet_forward(int dtype, int training, const float* x, int N,
   const bool ready = !tr && (flags & TF_DETNET_WEIGHTS_READY);
 
   c.skip_fold = ready;
+  // statistics folded into <= TF_STAT_ROWS rows: the elementwise consumers finalize them in-kernel (bn_fused.hip);
+  // unfolded (tf_set_stat_rows(0), bit-reproducible sums): separate finalize kernels on the shared partial buffer
+  const int srows = tf_get_stat_rows();
+  static const bool g_unfused_env = getenv("TINYFACES_UNFUSED_BN") != nullptr;     // A/B knob
+  const bool fused = tr && srows <= TF_STAT_ROWS && !g_unfused_env;
+  if (fused && hipMemsetAsync(P.stat_fwd, 0, P.stat_fwd_floats * 4, c.stream) != hipSuccess) c.chk(TF_ERR_LAUNCH);
   if (tr && hipMemsetAsync(P.partial, 0, (size_t)TF_STAT_ROWS * 3 * 1024 * 4, c.stream) != hipSuccess) c.chk(TF_ERR_LAUNCH);   // statistic rows start at zero
   // ---- stem: im2col + GEMM (+BN+ReLU) + maxpool
   const int M1 = N * P.H1 * P.W1;
@@ -403,35 +446,52 @@ extern "C" int tf_detnet_forward(int dtype, int training, const float* x, int N,
     const int Min = N * b.Hin * b.Win, Mout = N * b.Hout * b.Wout;
     // conv1 1x1
     conv_fill(a, dtype, 0, N, b.Hin, b.Win, B.cin, b.Hin, b.Win, pl, 1, 1, 0, pl, yin, b.w1, b.c1);
-    if (tr) { a.epi = TF_EPI_STATS; a.stat_out = P.partial; }
+    if (tr) { a.epi = TF_EPI_STATS; a.stat_out = fused ? b.b1.fst : P.partial; }
     else { bn_forward(c, B.c1, pl, b.b1, false, nullptr, nullptr, 0, eps, mom); a.epi = TF_EPI_AFFINE | TF_EPI_RELU; a.epi_scale = b.b1.scale; a.epi_shift = b.b1.shift; }
     c.chk(tf_conv2d(&a, c.stream));
-    if (tr) bn_forward(c, B.c1, pl, b.b1, true, &a, P.partial, (float)Min, eps, mom);
+    // a1 = relu(bn1(c1)), materialised on purpose: every consumer (conv2, its weight gradient) uses the LDS-DMA pipeline
+    if (fused) {
+      const tf_bn_fwd_desc d = fwd_desc(c, B.c1, b.b1);
+      c.chk(tf_bn_relu_fused(dtype, b.c1, &d, srows, Min, pl, (float)Min, eps, mom, b.a1, c.stream));
+    } else if (tr) {
+      bn_forward(c, B.c1, pl, b.b1, true, &a, P.partial, (float)Min, eps, mom);
+      c.chk(tf_bn_relu(dtype, b.c1, b.b1.scale, b.b1.shift, Min, pl, b.a1, c.stream));
+    }
     // conv2 3x3 (stride here)
-    if (tr) c.chk(tf_bn_relu(dtype, b.c1, b.b1.scale, b.b1.shift, Min, pl, b.a1, c.stream));   // un-fused on purpose: every consumer uses the DMA pipeline
     conv_fill(a, dtype, 0, N, b.Hin, b.Win, pl, b.Hout, b.Wout, pl, 3, B.stride, 1, pl, tr ? b.a1 : b.c1, b.w2, b.c2);
-    if (tr) { a.epi = TF_EPI_STATS; a.stat_out = P.partial; }
+    if (tr) { a.epi = TF_EPI_STATS; a.stat_out = fused ? b.b2.fst : P.partial; }
     else { bn_forward(c, B.c2, pl, b.b2, false, nullptr, nullptr, 0, eps, mom); a.epi = TF_EPI_AFFINE | TF_EPI_RELU; a.epi_scale = b.b2.scale; a.epi_shift = b.b2.shift; }
     c.chk(tf_conv2d(&a, c.stream));
-    if (tr) bn_forward(c, B.c2, pl, b.b2, true, &a, P.partial, (float)Mout, eps, mom);
+    if (tr && !fused) bn_forward(c, B.c2, pl, b.b2, true, &a, P.partial, (float)Mout, eps, mom);
     // downsample 1x1 (stride)
     if (B.has_ds) {
       conv_fill(a, dtype, 0, N, b.Hin, b.Win, B.cin, b.Hout, b.Wout, c4, 1, B.stride, 0, c4, yin, b.wd, b.d);
-      if (tr) { a.epi = TF_EPI_STATS; a.stat_out = P.partial; }
+      if (tr) { a.epi = TF_EPI_STATS; a.stat_out = fused ? b.bd.fst : P.partial; }
       else { bn_forward(c, B.ds, c4, b.bd, false, nullptr, nullptr, 0, eps, mom); a.epi = TF_EPI_AFFINE; a.epi_scale = b.bd.scale; a.epi_shift = b.bd.shift; }
       c.chk(tf_conv2d(&a, c.stream));
-      if (tr) bn_forward(c, B.ds, c4, b.bd, true, &a, P.partial, (float)Mout, eps, mom);
+      if (tr && !fused) bn_forward(c, B.ds, c4, b.bd, true, &a, P.partial, (float)Mout, eps, mom);
+    }
+    // a2 = relu(bn2(c2))
+    if (fused) {
+      const tf_bn_fwd_desc d = fwd_desc(c, B.c2, b.b2);
+      c.chk(tf_bn_relu_fused(dtype, b.c2, &d, srows, Mout, pl, (float)Mout, eps, mom, b.a2, c.stream));
+    } else if (tr) {
+      c.chk(tf_bn_relu(dtype, b.c2, b.b2.scale, b.b2.shift, Mout, pl, b.a2, c.stream));
     }
     // conv3 1x1 (+ BN + residual + ReLU)
-    if (tr) c.chk(tf_bn_relu(dtype, b.c2, b.b2.scale, b.b2.shift, Mout, pl, b.a2, c.stream));
     conv_fill(a, dtype, 0, N, b.Hout, b.Wout, pl, b.Hout, b.Wout, c4, 1, 1, 0, c4, tr ? b.a2 : b.c2, b.w3, tr ? b.c3 : b.y);
-    if (tr) { a.epi = TF_EPI_STATS; a.stat_out = P.partial; }
+    if (tr) { a.epi = TF_EPI_STATS; a.stat_out = fused ? b.b3.fst : P.partial; }
     else {
       bn_forward(c, B.c3, c4, b.b3, false, nullptr, nullptr, 0, eps, mom);
       a.epi = TF_EPI_AFFINE | TF_EPI_RES | TF_EPI_RELU; a.epi_scale = b.b3.scale; a.epi_shift = b.b3.shift; a.aux = B.has_ds ? b.d : yin;
     }
     c.chk(tf_conv2d(&a, c.stream));
-    if (tr) {
+    if (fused) {
+      const tf_bn_fwd_desc d3 = fwd_desc(c, B.c3, b.b3);
+      tf_bn_fwd_desc dd; if (B.has_ds) dd = fwd_desc(c, B.ds, b.bd);
+      c.chk(tf_bn_add_relu_fused(dtype, b.c3, &d3, B.has_ds ? b.d : yin, B.has_ds ? &dd : nullptr, srows, Mout, c4, (float)Mout, eps, mom, b.y,
+                                 c.stream));
+    } else if (tr) {
       bn_forward(c, B.c3, c4, b.b3, true, &a, P.partial, (float)Mout, eps, mom);
       c.chk(tf_bn_add_relu(dtype, b.c3, b.b3.scale, b.b3.shift, B.has_ds ? b.d : yin, B.has_ds ? b.bd.scale : nullptr,
                            B.has_ds ? b.bd.shift : nullptr, Mout, c4, b.y, c.stream));
@@ -515,6 +575,10 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
   const void* res4 = P.blk[A.layer_end[2]].y;
 
   if (hipMemsetAsync(P.partial, 0, (size_t)TF_STAT_ROWS * 3 * 1024 * 4, c.stream) != hipSuccess) c.chk(TF_ERR_LAUNCH);   // statistic rows start at zero
+  const int srows = tf_get_stat_rows();
+  static const bool g_unfused_env = getenv("TINYFACES_UNFUSED_BN") != nullptr;
+  const bool fused = srows <= TF_STAT_ROWS && !g_unfused_env;   // see tf_detnet_forward
+  if (fused && hipMemsetAsync(P.stat_bwd, 0, P.stat_bwd_floats * 4, c.stream) != hipSuccess) c.chk(TF_ERR_LAUNCH);
   if (grad_flat && grad_flat_bytes) {                     // one memset for every weight gradient (atomics accumulate into them)
     if (hipMemsetAsync(grad_flat, 0, grad_flat_bytes, c.stream) != hipSuccess) c.chk(TF_ERR_LAUNCH);
     c.grads_zeroed = true;
@@ -576,38 +640,60 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
     if (i + 2 < (int)A.blocks.size()) c.wait_on_main(block_done[i + 2]);
     // (1) per-channel sums for bn3 (and the downsample BN) with gz = g_y * (y > 0)
     const int nb = tf_colstats_blocks(Mout, c4, dtype);
-    c.chk(tf_colstats(dtype, Gcur, b.y, b.c3, B.has_ds ? b.d : nullptr, Mout, c4, c4, P.partial, c.stream));
     const int nk = B.has_ds ? 3 : 2;
-    bn_backward_coefs(c, B.c3, c4, b.b3, P.partial, nb, nk, 1, c4, (float)Mout, B.has_ds ? 0 : 1);   // the last reader clears the partial rows
-    if (B.has_ds) bn_backward_coefs(c, B.ds, c4, b.bd, P.partial, nb, nk, 2, c4, (float)Mout, 1);
+    c.chk(tf_colstats(dtype, Gcur, b.y, b.c3, B.has_ds ? b.d : nullptr, Mout, c4, c4, fused ? b.b3.bst : P.partial, c.stream));
     // (2) g_c3 -> T1
-    c.chk(tf_bn_bwd_apply(dtype, Gcur, b.y, b.c3, b.b3.cA, b.b3.cB, b.b3.cD, Mout, c4, T1, c.stream));
+    if (fused) {
+      const tf_bn_bwd_desc d = bwd_desc(c, B.c3, b.b3, b.b3.bst, nk, 1);
+      c.chk(tf_bn_bwd_apply_fused(dtype, Gcur, b.y, b.c3, &d, srows, Mout, c4, (float)Mout, T1, c.stream));
+    } else {
+      bn_backward_coefs(c, B.c3, c4, b.b3, P.partial, nb, nk, 1, c4, (float)Mout, B.has_ds ? 0 : 1);   // the last reader clears the partial rows
+      if (B.has_ds) bn_backward_coefs(c, B.ds, c4, b.bd, P.partial, nb, nk, 2, c4, (float)Mout, 1);
+      c.chk(tf_bn_bwd_apply(dtype, Gcur, b.y, b.c3, b.b3.cA, b.b3.cB, b.b3.cD, Mout, c4, T1, c.stream));
+    }
     c.fork();
-    // (3) wgrad conv3 (its input is relu(bn2(c2)), re-materialised in the loader)
+    // (3) wgrad conv3 (its input is relu(bn2(c2)), materialised in the forward)
     wgrad(c, B.c3, c4, N, b.Hout, b.Wout, b.Hout, b.Wout, b.a2, pl, T1, c4, nullptr);
     // (4) dgrad conv3 -> gz2 in T2 (masked by relu(bn2(c2))) + BN-backward sums
     conv_fill(a, dtype, 1, N, b.Hout, b.Wout, c4, b.Hout, b.Wout, pl, 1, 1, 0, pl, T1, b.w3t, T2);
-    a.epi = TF_EPI_MASK | TF_EPI_STATS2; a.aux = b.c2; a.mask_scale = b.b2.scale; a.mask_shift = b.b2.shift; a.stat_out = P.partial;
+    a.epi = TF_EPI_MASK | TF_EPI_STATS2; a.aux = b.c2; a.mask_scale = b.b2.scale; a.mask_shift = b.b2.shift;
+    a.stat_out = fused ? b.b2.bst : P.partial;
     c.chk(tf_conv2d(&a, c.stream));
-    bn_backward_coefs(c, B.c2, pl, b.b2, P.partial, tf_conv_mtiles(&a), 2, 1, pl, (float)Mout);
     // (5) g_c2 in place
-    c.chk(tf_bn_bwd_apply(dtype, T2, nullptr, b.c2, b.b2.cA, b.b2.cB, b.b2.cD, Mout, pl, T2, c.stream));
+    if (fused) {
+      const tf_bn_bwd_desc d = bwd_desc(c, B.c2, b.b2, b.b2.bst, 2, 1);
+      c.chk(tf_bn_bwd_apply_fused(dtype, T2, nullptr, b.c2, &d, srows, Mout, pl, (float)Mout, T2, c.stream));
+    } else {
+      bn_backward_coefs(c, B.c2, pl, b.b2, P.partial, tf_conv_mtiles(&a), 2, 1, pl, (float)Mout);
+      c.chk(tf_bn_bwd_apply(dtype, T2, nullptr, b.c2, b.b2.cA, b.b2.cB, b.b2.cD, Mout, pl, T2, c.stream));
+    }
     c.fork();
     // (6) wgrad conv2 (input relu(bn1(c1)))
     wgrad(c, B.c2, pl, N, b.Hin, b.Win, b.Hout, b.Wout, b.a1, pl, T2, pl, nullptr, 0, 0, 0, P.dwp);
-    // (7) dgrad conv2 -> gz1 in T1 (+ sums); output spatial = conv2's input
+    // (7) dgrad conv2 -> gz1 in U1 (+ sums); output spatial = conv2's input
     conv_fill(a, dtype, 1, N, b.Hout, b.Wout, pl, b.Hin, b.Win, pl, 3, B.stride, 1, pl, T2, b.w2t, U1);
-    a.epi = TF_EPI_MASK | TF_EPI_STATS2; a.aux = b.c1; a.mask_scale = b.b1.scale; a.mask_shift = b.b1.shift; a.stat_out = P.partial;
+    a.epi = TF_EPI_MASK | TF_EPI_STATS2; a.aux = b.c1; a.mask_scale = b.b1.scale; a.mask_shift = b.b1.shift;
+    a.stat_out = fused ? b.b1.bst : P.partial;
     c.chk(tf_conv2d(&a, c.stream));
-    bn_backward_coefs(c, B.c1, pl, b.b1, P.partial, tf_conv_mtiles(&a), 2, 1, pl, (float)Min);
     // (8) g_c1 in place
-    c.chk(tf_bn_bwd_apply(dtype, U1, nullptr, b.c1, b.b1.cA, b.b1.cB, b.b1.cD, Min, pl, U1, c.stream));
+    if (fused) {
+      const tf_bn_bwd_desc d = bwd_desc(c, B.c1, b.b1, b.b1.bst, 2, 1);
+      c.chk(tf_bn_bwd_apply_fused(dtype, U1, nullptr, b.c1, &d, srows, Min, pl, (float)Min, U1, c.stream));
+    } else {
+      bn_backward_coefs(c, B.c1, pl, b.b1, P.partial, tf_conv_mtiles(&a), 2, 1, pl, (float)Min);
+      c.chk(tf_bn_bwd_apply(dtype, U1, nullptr, b.c1, b.b1.cA, b.b1.cB, b.b1.cD, Min, pl, U1, c.stream));
+    }
     c.fork();
     // (9) wgrad conv1 (input = block input, already activated)
     wgrad(c, B.c1, pl, N, b.Hin, b.Win, b.Hin, b.Win, yin, B.cin, U1, pl, nullptr);
     // (10) gradient w.r.t. the block input -> Gnext
     if (B.has_ds) {
-      c.chk(tf_bn_bwd_apply(dtype, Gcur, b.y, b.d, b.bd.cA, b.bd.cB, b.bd.cD, Mout, c4, T3, c.stream));
+      if (fused) {
+        const tf_bn_bwd_desc d = bwd_desc(c, B.ds, b.bd, b.b3.bst, 3, 2);      // the downsample BN's sums are row 2 of bn3's region
+        c.chk(tf_bn_bwd_apply_fused(dtype, Gcur, b.y, b.d, &d, srows, Mout, c4, (float)Mout, T3, c.stream));
+      } else {
+        c.chk(tf_bn_bwd_apply(dtype, Gcur, b.y, b.d, b.bd.cA, b.bd.cB, b.bd.cD, Mout, c4, T3, c.stream));
+      }
       c.fork();
       wgrad(c, B.ds, c4, N, b.Hin, b.Win, b.Hout, b.Wout, yin, B.cin, T3, c4, nullptr);
       conv_fill(a, dtype, 1, N, b.Hout, b.Wout, c4, b.Hin, b.Win, B.cin, 1, B.stride, 0, B.cin, T3, b.wdt, P.T4);

@@ -9,7 +9,8 @@
 namespace {
 struct Rec { int kind; double flops, bytes; hipEvent_t a, b; };
 std::mutex g_mu;
-bool g_on = false;
+int g_every = 0;            // 0 = off, n = bracket every n-th profiled launch (1 = all)
+unsigned long long g_seq = 0;
 std::vector<Rec> g_recs;
 std::vector<hipEvent_t> g_pool;
 
@@ -20,8 +21,9 @@ hipEvent_t get_event() {
 }  // namespace
 
 tf::ProfScope::ProfScope(int kind, double flops, double bytes, hipStream_t s) : slot(-1), stream(s) {
-  if (!g_on) return;
+  if (!g_every) return;
   std::lock_guard<std::mutex> lk(g_mu);
+  if (g_seq++ % (unsigned long long)g_every) return;
   Rec r{kind, flops, bytes, get_event(), get_event()};
   (void)hipEventRecord(r.a, s);
   g_recs.push_back(r);
@@ -35,7 +37,8 @@ tf::ProfScope::~ProfScope() {
 
 extern "C" int tf_profile_enable(int on) {
   std::lock_guard<std::mutex> lk(g_mu);
-  g_on = on != 0;
+  g_every = on < 0 ? 0 : on;
+  g_seq = 0;
   return TF_OK;
 }
 

@@ -23,6 +23,17 @@ class HipLibraryMissing(RuntimeError):
     pass
 
 
+class BnFwdDesc(C.Structure):
+    """tf_bn_fwd_desc (include/tinyfaces_hip.h)."""
+    _fields_ = [("stat", vp), ("gamma", vp), ("beta", vp), ("scale", vp), ("shift", vp), ("mean", vp), ("invstd", vp),
+                ("running_mean", vp), ("running_var", vp)]
+
+
+class BnBwdDesc(C.Structure):
+    """tf_bn_bwd_desc (include/tinyfaces_hip.h)."""
+    _fields_ = [("stat", vp), ("gamma", vp), ("mean", vp), ("invstd", vp), ("dgamma", vp), ("dbeta", vp), ("nk", i32), ("kidx", i32)]
+
+
 class ConvArgs(C.Structure):
     _fields_ = [("dtype", i32), ("mode", i32),
                 ("N", i32), ("H", i32), ("W", i32), ("Cin", i32), ("OH", i32), ("OW", i32), ("Cout", i32),
@@ -74,6 +85,9 @@ _SIGNATURES = {
     "tf_bn_bwd_apply": (i32, [i32, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp]),
     "tf_bn_relu": (i32, [i32, vp, vp, vp, i64, i32, vp, vp]),
     "tf_bn_add_relu": (i32, [i32, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp]),
+    "tf_bn_relu_fused": (i32, [i32, vp, C.POINTER(BnFwdDesc), i32, i64, i32, f32, f32, f32, vp, vp]),
+    "tf_bn_add_relu_fused": (i32, [i32, vp, C.POINTER(BnFwdDesc), vp, C.POINTER(BnFwdDesc), i32, i64, i32, f32, f32, f32, vp, vp]),
+    "tf_bn_bwd_apply_fused": (i32, [i32, vp, vp, vp, C.POINTER(BnBwdDesc), i32, i64, i32, f32, vp, vp]),
     "tf_upsample_add_crop": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
     "tf_upsample_add_crop_bwd": (i32, [i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
     "tf_reduce_partials": (i32, [vp, i32, i32, i32, i32, i32, vp, i32, vp]),
