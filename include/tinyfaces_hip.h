@@ -128,6 +128,10 @@ int tf_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n,
  *   MASK    v = (aux[p,c]*mask_scale[c]+mask_shift[c] > 0) ? v : 0        (dgrad through ReLU(BN(aux)))
  *   STATS2  stat_out[mtile][0][c] = sum v, [1][c] = sum v*aux[p,c]        (after MASK)
  *   JOIN    v += (aux2[p,c] > 0) ? aux3[p,c] : 0                          (residual-join gradient)
+ *   MASK2   v = (aux2[p,c] > 0) ? v : 0    (after RES: gradient through the ReLU that produced aux2; LDS-DMA kernel only)
+ *   STATS3  stat_out[mtile][0][c] = sum v, [1][c] = sum v*aux3[p,c]       (after MASK2; LDS-DMA kernel only)
+ *           RES|MASK2|STATS3 on the last data-gradient conv of a Bottleneck hands the next block (in backward order)
+ *           its already-masked output gradient together with the BN3-backward sums.
  */
 #define TF_EPI_AFFINE 1
 #define TF_EPI_RES 2
@@ -136,6 +140,8 @@ int tf_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n,
 #define TF_EPI_MASK 16
 #define TF_EPI_STATS2 32
 #define TF_EPI_JOIN 64
+#define TF_EPI_MASK2 128
+#define TF_EPI_STATS3 256
 /* partial-sum rows of one launch are folded (atomics) into at most this many rows; consumers pass clear=1 to the
  * last finalize that reads them so that the buffer is zero again for the next producer */
 #define TF_STAT_ROWS 16

@@ -378,8 +378,14 @@ extern "C" int tf_conv2d(const tf_conv_args* a, void* stream_) {
   if (a->dtype != TF_BF16 && a->dtype != TF_F32) return TF_ERR_UNSUPPORTED;
   if (a->Cin % kch != 0 || a->ldy % 4 != 0 || a->ldy < a->Cout) return TF_ERR_ARG;
   if (a->stride != 1 && a->stride != 2) return TF_ERR_UNSUPPORTED;
-  if ((a->epi & (TF_EPI_STATS | TF_EPI_STATS2)) && !a->stat_out) return TF_ERR_ARG;
-  if ((a->epi & TF_EPI_STATS) && (a->epi & TF_EPI_STATS2)) return TF_ERR_ARG;
+  if ((a->epi & (TF_EPI_STATS | TF_EPI_STATS2 | TF_EPI_STATS3)) && !a->stat_out) return TF_ERR_ARG;
+  {
+    const int ns = !!(a->epi & TF_EPI_STATS) + !!(a->epi & TF_EPI_STATS2) + !!(a->epi & TF_EPI_STATS3);
+    if (ns > 1) return TF_ERR_ARG;
+  }
+  if ((a->epi & TF_EPI_MASK2) && !a->aux2) return TF_ERR_ARG;
+  if ((a->epi & TF_EPI_STATS3) && !a->aux3) return TF_ERR_ARG;
+  if ((a->epi & TF_EPI_JOIN) && (a->epi & (TF_EPI_MASK2 | TF_EPI_STATS3))) return TF_ERR_ARG;     // aux2 / aux3 have one meaning per launch
   if ((a->epi & (TF_EPI_RES | TF_EPI_MASK | TF_EPI_STATS2)) && !a->aux) return TF_ERR_ARG;
   if ((a->epi & TF_EPI_JOIN) && (!a->aux2 || !a->aux3)) return TF_ERR_ARG;
   if ((a->epi & TF_EPI_AFFINE) && (!a->epi_scale || !a->epi_shift)) return TF_ERR_ARG;
@@ -390,6 +396,7 @@ extern "C" int tf_conv2d(const tf_conv_args* a, void* stream_) {
     if (a->pro_scale) return TF_ERR_UNSUPPORTED;
     return tf_conv_dma_launch(a, t % 10, t >= 20 ? 4 : 3, stream);
   }
+  if (a->epi & (TF_EPI_MASK2 | TF_EPI_STATS3)) return TF_ERR_UNSUPPORTED;      // only the LDS-DMA kernel implements them
   if (a->dtype == TF_BF16) {
     if (t == 1) return launch_conv<tf::bf16_t, 128, 128>(a, stream);
     if (t == 2) return launch_conv<tf::bf16_t, 128, 64>(a, stream);

@@ -273,6 +273,12 @@ __global__ void __launch_bounds__(256) conv_dma_kernel(const DmaK a) {
 #pragma unroll
         for (int j = 0; j < EPS; ++j) v[j] += (y2[j] > 0.f) ? g3[j] : 0.f;
       }
+      if (a.epi & TF_EPI_MASK2) {
+        float y2[EPS];
+        tf::unpack16<T>(*reinterpret_cast<const uint4*>(a.aux2 + o), y2);
+#pragma unroll
+        for (int j = 0; j < EPS; ++j) v[j] = (y2[j] > 0.f) ? v[j] : 0.f;
+      }
       if (a.epi & TF_EPI_RELU) {
 #pragma unroll
         for (int j = 0; j < EPS; ++j) v[j] = fmaxf(v[j], 0.f);
@@ -281,10 +287,16 @@ __global__ void __launch_bounds__(256) conv_dma_kernel(const DmaK a) {
 #pragma unroll
         for (int j = 0; j < EPS; ++j) { s1[j] += v[j]; s2[j] += v[j] * ax[j]; }
       }
+      if (a.epi & TF_EPI_STATS3) {
+        float x3[EPS];
+        tf::unpack16<T>(*reinterpret_cast<const uint4*>(a.aux3 + o), x3);
+#pragma unroll
+        for (int j = 0; j < EPS; ++j) { s1[j] += v[j]; s2[j] += v[j] * x3[j]; }
+      }
       *reinterpret_cast<uint4*>(a.y + o) = tf::pack16<T>(v);
     }
   }
-  if (a.epi & (TF_EPI_STATS | TF_EPI_STATS2)) {       // block-uniform: deterministic column sums of the tile
+  if (a.epi & (TF_EPI_STATS | TF_EPI_STATS2 | TF_EPI_STATS3)) {       // block-uniform: column sums of the tile
     // lanes sharing a chunk inside a wave differ in the lane bits >= log2(CPR)
 #pragma unroll
     for (int o = CPR; o < 64; o <<= 1) {
@@ -341,6 +353,8 @@ int launch_kind(const tf_conv_args* A, hipStream_t stream) {
     double bytes = ((double)A->N * A->H * A->W * A->Cin + (double)A->Cout * Kt + M * A->Cout) * es;
     if (A->epi & (TF_EPI_RES | TF_EPI_MASK | TF_EPI_STATS2)) bytes += M * A->Cout * es;
     if (A->epi & TF_EPI_JOIN) bytes += 2 * M * A->Cout * es;
+    if (A->epi & TF_EPI_MASK2) bytes += M * A->Cout * es;
+    if (A->epi & TF_EPI_STATS3) bytes += M * A->Cout * es;
     tf::ProfScope prof(sizeof(T) == 2 ? 13 : 12, 2.0 * M * A->Cout * Kt, bytes, stream);   // 12 = conv_dma f32, 13 = conv_dma bf16
     hipLaunchKernelGGL((conv_dma_kernel<T, BM, BN, NS, KIND>), dim3(mtiles * k.ntiles), dim3(256), lds, stream, k);
   }

@@ -621,6 +621,13 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
   // T2 = gz2 -> g_c2; T3 = g_d; T4 = downsample-branch input gradient; R3 = gradient w.r.t. res3 from the head.
   void *Gcur = P.G0, *Gnext = P.G1;
   conv_fill(a, dtype, 1, N, P.H4, P.W4, kHeadLd, P.H4, P.W4, 1024, 1, 1, 0, 1024, P.g4, P.w_h4t, Gcur);
+  if (fused) {
+    // fused flow: Gcur always carries gz = g_y * (y > 0) of the block about to be processed, and (unless that block has a
+    // downsample branch) its BN3-backward sums are accumulated by the conv that produces it (MASK2 | STATS3)
+    const size_t last = A.blocks.size() - 1;
+    a.epi = TF_EPI_MASK2; a.aux2 = P.blk[last].y;
+    if (!A.blocks[last].has_ds) { a.epi |= TF_EPI_STATS3; a.aux3 = P.blk[last].c3; a.stat_out = P.blk[last].b3.bst; }
+  }
   c.chk(tf_conv2d(&a, c.stream));
   conv_fill(a, dtype, 1, N, P.H3, P.W3, kHeadLd, P.H3, P.W3, 512, 1, 1, 0, 512, P.g3, P.w_h3t, P.R3);
   c.chk(tf_conv2d(&a, c.stream));
@@ -641,11 +648,12 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
     // (1) per-channel sums for bn3 (and the downsample BN) with gz = g_y * (y > 0)
     const int nb = tf_colstats_blocks(Mout, c4, dtype);
     const int nk = B.has_ds ? 3 : 2;
-    c.chk(tf_colstats(dtype, Gcur, b.y, b.c3, B.has_ds ? b.d : nullptr, Mout, c4, c4, fused ? b.b3.bst : P.partial, c.stream));
+    if (!fused) c.chk(tf_colstats(dtype, Gcur, b.y, b.c3, b.d, Mout, c4, c4, P.partial, c.stream));
+    else if (B.has_ds) c.chk(tf_colstats(dtype, Gcur, nullptr, b.c3, b.d, Mout, c4, c4, b.b3.bst, c.stream));   // Gcur is already masked
     // (2) g_c3 -> T1
     if (fused) {
       const tf_bn_bwd_desc d = bwd_desc(c, B.c3, b.b3, b.b3.bst, nk, 1);
-      c.chk(tf_bn_bwd_apply_fused(dtype, Gcur, b.y, b.c3, &d, srows, Mout, c4, (float)Mout, T1, c.stream));
+      c.chk(tf_bn_bwd_apply_fused(dtype, Gcur, nullptr, b.c3, &d, srows, Mout, c4, (float)Mout, T1, c.stream));
     } else {
       bn_backward_coefs(c, B.c3, c4, b.b3, P.partial, nb, nk, 1, c4, (float)Mout, B.has_ds ? 0 : 1);   // the last reader clears the partial rows
       if (B.has_ds) bn_backward_coefs(c, B.ds, c4, b.bd, P.partial, nb, nk, 2, c4, (float)Mout, 1);
@@ -686,11 +694,18 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
     c.fork();
     // (9) wgrad conv1 (input = block input, already activated)
     wgrad(c, B.c1, pl, N, b.Hin, b.Win, b.Hin, b.Win, yin, B.cin, U1, pl, nullptr);
-    // (10) gradient w.r.t. the block input -> Gnext
+    // (10) gradient w.r.t. the block input -> Gnext.  Fused flow: the conv that completes it also applies the ReLU mask of
+    //      the previous block's output (MASK2 with aux2 = yin) and, unless that block has a downsample branch, accumulates
+    //      its BN3-backward sums (STATS3 with aux3 = its c3), so the next iteration starts at step (2).
+    auto hand_over = [&](tf_conv_args& q) {
+      if (!fused || i == 0) return;                        // block 0's input is the max-pool output: no ReLU in between
+      q.epi |= TF_EPI_MASK2; q.aux2 = yin;
+      if (!A.blocks[i - 1].has_ds) { q.epi |= TF_EPI_STATS3; q.aux3 = P.blk[i - 1].c3; q.stat_out = P.blk[i - 1].b3.bst; }
+    };
     if (B.has_ds) {
       if (fused) {
         const tf_bn_bwd_desc d = bwd_desc(c, B.ds, b.bd, b.b3.bst, 3, 2);      // the downsample BN's sums are row 2 of bn3's region
-        c.chk(tf_bn_bwd_apply_fused(dtype, Gcur, b.y, b.d, &d, srows, Mout, c4, (float)Mout, T3, c.stream));
+        c.chk(tf_bn_bwd_apply_fused(dtype, Gcur, nullptr, b.d, &d, srows, Mout, c4, (float)Mout, T3, c.stream));
       } else {
         c.chk(tf_bn_bwd_apply(dtype, Gcur, b.y, b.d, b.bd.cA, b.bd.cB, b.bd.cD, Mout, c4, T3, c.stream));
       }
@@ -701,10 +716,12 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
       c.chk(tf_conv2d(&a, c.stream));
       conv_fill(a, dtype, 1, N, b.Hin, b.Win, pl, b.Hin, b.Win, B.cin, 1, 1, 0, B.cin, U1, b.w1t, Gnext);
       a.epi = TF_EPI_RES; a.aux = P.T4;
+      hand_over(a);
       c.chk(tf_conv2d(&a, c.stream));
     } else {
       conv_fill(a, dtype, 1, N, b.Hin, b.Win, pl, b.Hin, b.Win, B.cin, 1, 1, 0, B.cin, U1, b.w1t, Gnext);
-      a.epi = TF_EPI_JOIN; a.aux2 = b.y; a.aux3 = Gcur;       // identity branch: + g_y * (y > 0)
+      if (fused) { a.epi = TF_EPI_RES; a.aux = Gcur; hand_over(a); }       // identity branch: Gcur is already g_y * (y > 0)
+      else { a.epi = TF_EPI_JOIN; a.aux2 = b.y; a.aux3 = Gcur; }            // identity branch: + g_y * (y > 0)
       c.chk(tf_conv2d(&a, c.stream));
     }
     block_done[i] = c.mark_side();

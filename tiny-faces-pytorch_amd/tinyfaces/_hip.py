@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtinyfaces_hip.so")
 
 TF_F32, TF_BF16 = 0, 1
-EPI_AFFINE, EPI_RES, EPI_RELU, EPI_STATS, EPI_MASK, EPI_STATS2, EPI_JOIN = 1, 2, 4, 8, 16, 32, 64
+EPI_AFFINE, EPI_RES, EPI_RELU, EPI_STATS, EPI_MASK, EPI_STATS2, EPI_JOIN, EPI_MASK2, EPI_STATS3 = 1, 2, 4, 8, 16, 32, 64, 128, 256
 ERRORS = {-1: "TF_ERR_ARG", -2: "TF_ERR_LAUNCH", -3: "TF_ERR_UNSUPPORTED", -4: "TF_ERR_WORKSPACE"}
 
 vp, i32, i64, u64, f32, f64, sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_double, C.c_size_t
