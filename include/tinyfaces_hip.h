@@ -175,6 +175,14 @@ int tf_pack_weight(const float* w_oihw, int Cout, int Cin, int KH, int KW, int t
 /* the same for many weights in one or two launches (job table passed as kernel arguments, no H2D copy) */
 typedef struct tf_pack_job { const float* src; void* dst; int cout, cin, taps, transpose, rows_pad, cols_pad; } tf_pack_job;
 int tf_pack_weights_batched(int dtype, const tf_pack_job* host_jobs, int njobs, void* stream);
+/* both layouts of a weight from ONE read of the fp32 master (LDS-tiled): dst = [rows_pad >= cout][taps][cols_pad >= cin]
+ * (forward operand), dst_t = [rows_pad_t >= cin][taps][cols_pad_t >= cout] (data-gradient operand); either may be NULL;
+ * padding is written as zeros.  A training forward packs both, so the backward call packs nothing. */
+typedef struct tf_pack2_job {
+  const float* src; void* dst; void* dst_t;
+  int cout, cin, taps, rows_pad, cols_pad, rows_pad_t, cols_pad_t;
+} tf_pack2_job;
+int tf_pack_weights_tiled(int dtype, const tf_pack2_job* host_jobs, int njobs, void* stream);
 
 /* weight gradient: dW[co][ci][kh][kw] (+)= sum_p dY[p,co] * xhat[gather(p,tap),ci] (fp32 atomics
  * into dw_oihw, which the caller zeroes).  Same prologue semantics as tf_conv2d. */

@@ -192,6 +192,41 @@ def test_conv_dgrad_res_mask2_stats3(dtype, tile):
                         epi=_hip.EPI_MASK2, aux2=to_nhwc(yprev, dtype), tile=2)
 
 
+@pytest.mark.parametrize("dtype", DT)
+def test_pack_weights_tiled_equals_elementwise_pack(dtype):
+    """tf_pack_weights_tiled (one read of the fp32 master, both operand layouts, LDS-tiled) must write exactly what the
+    per-element tf_pack_weight writes, padding included: 1x1 / 3x3, Cout not a multiple of the tile (heads: 125), the
+    flattened stem weight (147 -> 192 columns), forward-only and transposed-only jobs, >40 jobs (two launches)."""
+    import ctypes as C
+    from tinyfaces import _hip, ops
+    from tinyfaces._hip import lib, ptr, stream, tf_dtype
+    g = _g(5)
+    tfd = tf_dtype(dtype)
+    shapes = [(64, 147, 1, 192, False), (64, 64, 1, 0, True), (64, 64, 3, 0, True), (256, 64, 1, 0, True), (128, 128, 3, 0, True),
+              (125, 512, 1, 0, True), (125, 1024, 1, 0, True), (1024, 256, 1, 0, True), (256, 256, 3, 0, True)]
+    shapes = shapes + [(64 + 8 * i, 64, 1, 0, True) for i in range(36)]           # > 40 jobs
+    ws, jobs, outs = [], (_hip.Pack2Job * len(shapes))(), []
+    for n, (co, ci, k, cpad, both) in enumerate(shapes):
+        w = torch.randn(co, ci, k, k, generator=g).cuda()
+        rp, cp = (co + 127) // 128 * 128, cpad or ci
+        rpt, cpt = (ci + 127) // 128 * 128, (co + 3) // 4 * 4          # 4 elements per store: padded like the executor's head operands
+        o = torch.full((rp, k * k, cp), 7.0, dtype=dtype, device="cuda")
+        ot = torch.full((rpt, k * k, cpt), 7.0, dtype=dtype, device="cuda") if both else None
+        if n == 1:
+            o, ot = None, ot                                                       # transposed-only job
+        jobs[n] = _hip.Pack2Job(ptr(w), ptr(o), ptr(ot), co, ci, k * k, rp, cp, rpt, cpt)
+        ws.append(w); outs.append((o, ot))
+    assert lib().tf_pack_weights_tiled(tfd, C.cast(jobs, C.c_void_p), len(shapes), stream()) == 0
+    torch.cuda.synchronize()
+    for (co, ci, k, cpad, both), w, (o, ot) in zip(shapes, ws, outs):
+        if o is not None:
+            ref = ops.pack_weight(w, dtype, cols_pad=cpad or None)
+            assert torch.equal(o.view(-1), ref.view(-1)), (co, ci, k)
+        if ot is not None:
+            reft = ops.pack_weight(w, dtype, transpose=True, cols_pad=(co + 3) // 4 * 4)
+            assert torch.equal(ot.view(-1), reft.view(-1)), (co, ci, k, "t")
+
+
 WG_CASES = [
     # N, H, W, Cin, Cout, K, stride
     (1, 9, 7, 64, 64, 1, 1),

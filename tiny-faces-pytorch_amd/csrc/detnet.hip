@@ -277,6 +277,7 @@ struct Ctx {
   bool grads_zeroed = false;
   bool skip_fold = false;
   std::vector<tf_pack_job> jobs;
+  std::vector<tf_pack2_job> jobs2;
   hipStream_t side = nullptr;                 // weight gradients run here, concurrently with the data-gradient chain
   std::vector<hipEvent_t>* events = nullptr; size_t ev_next = 0;
   hipEvent_t next_event() {
@@ -288,7 +289,10 @@ struct Ctx {
   hipEvent_t mark_side() { if (!side) return nullptr; hipEvent_t e = next_event(); if (e) (void)hipEventRecord(e, side); return e; }
   void wait_on_main(hipEvent_t e) { if (e) (void)hipStreamWaitEvent(stream, e, 0); }
   hipStream_t wstream() const { return side ? side : stream; }
-  void flush_packs() { if (!jobs.empty()) { chk(tf_pack_weights_batched(dtype, jobs.data(), (int)jobs.size(), stream)); jobs.clear(); } }
+  void flush_packs() {
+    if (!jobs.empty()) { chk(tf_pack_weights_batched(dtype, jobs.data(), (int)jobs.size(), stream)); jobs.clear(); }
+    if (!jobs2.empty()) { chk(tf_pack_weights_tiled(dtype, jobs2.data(), (int)jobs2.size(), stream)); jobs2.clear(); }
+  }
   const float* P(int i) const { return (const float*)params[i]; }
   float* G(int i) const { return grads ? (float*)grads[i] : nullptr; }
   void chk(int r) { if (r != TF_OK && rc == TF_OK) rc = r; }
@@ -310,6 +314,17 @@ void pack(Ctx& c, const ConvUnit& u, int cout, void* out, bool transpose, int ci
   if (!transpose) { j.rows_pad = (cout + 127) / 128 * 128; j.cols_pad = cols_pad_override ? cols_pad_override : cin; }
   else            { j.rows_pad = (cin + 127) / 128 * 128;  j.cols_pad = cols_pad_override ? cols_pad_override : cout; }
   c.jobs.push_back(j);
+}
+
+// forward operand [cout pad 128][taps][cin] and (training) data-gradient operand [cin pad 128][taps][cout] in one job
+void pack2(Ctx& c, const ConvUnit& u, int cout, void* out, void* out_t, int cin_override = 0, int cols_pad_override = 0, int k_override = 0) {
+  const int cin = cin_override ? cin_override : u.cin;
+  const int k = k_override ? k_override : u.k;
+  tf_pack2_job j;
+  j.src = c.P(u.w); j.dst = out; j.dst_t = out_t; j.cout = cout; j.cin = cin; j.taps = k * k;
+  j.rows_pad = (cout + 127) / 128 * 128; j.cols_pad = cols_pad_override ? cols_pad_override : cin;
+  j.rows_pad_t = (cin + 127) / 128 * 128; j.cols_pad_t = cout;
+  c.jobs2.push_back(j);
 }
 
 // BN after a conv: eval -> fold running stats; train -> finalize batch partials (+ running update)
@@ -410,19 +425,21 @@ extern "C" int tf_detnet_forward(int dtype, int training, const float* x, int N,
   c.chk(tf_stem_im2col(x, N, H, W, dtype, P.col, kStemK, c.stream));
   // ---- every weight of the pass re-packed from the fp32 master copy in two launches
   if (!ready) {
-  pack(c, A.stem, 64, P.wstem, false, 147, kStemK, 1);     // conv1.weight flattened OIHW == im2col k order
+  // every operand of the pass (and, in training, of the backward pass) from ONE read of the fp32 masters
+  pack2(c, A.stem, 64, P.wstem, nullptr, 147, kStemK, 1);     // conv1.weight flattened OIHW == im2col k order
   for (size_t i = 0; i < A.blocks.size(); ++i) {
     const Block& B = A.blocks[i];
     Plan::Blk& b = P.blk[i];
-    pack(c, B.c1, B.planes, b.w1, false); pack(c, B.c2, B.planes, b.w2, false); pack(c, B.c3, B.planes * 4, b.w3, false);
-    if (B.has_ds) pack(c, B.ds, B.planes * 4, b.wd, false);
+    pack2(c, B.c1, B.planes, b.w1, b.w1t); pack2(c, B.c2, B.planes, b.w2, b.w2t); pack2(c, B.c3, B.planes * 4, b.w3, b.w3t);
+    if (B.has_ds) pack2(c, B.ds, B.planes * 4, b.wd, b.wdt);
   }
   {
-    tf_pack_job j;
-    j.src = c.P(A.head3.w); j.dst = P.w_h3; j.cout = nout; j.cin = 512; j.taps = 1; j.transpose = 0; j.rows_pad = kHeadLd; j.cols_pad = 512;
-    c.jobs.push_back(j);
-    j.src = c.P(A.head4.w); j.dst = P.w_h4; j.cin = 1024; j.cols_pad = 1024;
-    c.jobs.push_back(j);
+    tf_pack2_job j;
+    j.src = c.P(A.head3.w); j.dst = P.w_h3; j.dst_t = P.w_h3t; j.cout = nout; j.cin = 512; j.taps = 1;
+    j.rows_pad = kHeadLd; j.cols_pad = 512; j.rows_pad_t = 512; j.cols_pad_t = kHeadLd;
+    c.jobs2.push_back(j);
+    j.src = c.P(A.head4.w); j.dst = P.w_h4; j.dst_t = P.w_h4t; j.cin = 1024; j.cols_pad = 1024; j.rows_pad_t = 1024;
+    c.jobs2.push_back(j);
   }
   c.flush_packs();
   }
@@ -583,21 +600,7 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
     if (hipMemsetAsync(grad_flat, 0, grad_flat_bytes, c.stream) != hipSuccess) c.chk(TF_ERR_LAUNCH);
     c.grads_zeroed = true;
   }
-  // ---- every data-gradient (transposed) weight operand of the pass in two launches
-  for (size_t i = 0; i < A.blocks.size(); ++i) {
-    const Block& B = A.blocks[i];
-    Plan::Blk& b = P.blk[i];
-    pack(c, B.c1, B.planes, b.w1t, true); pack(c, B.c2, B.planes, b.w2t, true); pack(c, B.c3, B.planes * 4, b.w3t, true);
-    if (B.has_ds) pack(c, B.ds, B.planes * 4, b.wdt, true);
-  }
-  {
-    tf_pack_job j;
-    j.src = c.P(A.head3.w); j.dst = P.w_h3t; j.cout = nout; j.cin = 512; j.taps = 1; j.transpose = 1; j.rows_pad = 512; j.cols_pad = kHeadLd;
-    c.jobs.push_back(j);
-    j.src = c.P(A.head4.w); j.dst = P.w_h4t; j.cin = 1024; j.rows_pad = 1024;
-    c.jobs.push_back(j);
-  }
-  c.flush_packs();
+  // (the transposed weight operands w*t were packed by the training forward, together with the forward operands)
 
   // ---- heads
   c.chk(tf_upsample_add_crop_bwd(dtype, gout, P.wup_diag, N, nout, kHeadLd, P.H3, P.W3, P.H4, P.W4, P.g3, P.g4, c.stream));
@@ -632,6 +635,8 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
   conv_fill(a, dtype, 1, N, P.H3, P.W3, kHeadLd, P.H3, P.W3, 512, 1, 1, 0, 512, P.g3, P.w_h3t, P.R3);
   c.chk(tf_conv2d(&a, c.stream));
 
+  // one fork per weight gradient (default) or, TINYFACES_FORK_PER_BLOCK=1, one per block: measured 948 vs 943 img/s
+  static const bool fork_each = getenv("TINYFACES_FORK_PER_BLOCK") == nullptr;
   // ---- bottlenecks in reverse
   std::vector<hipEvent_t> block_done(A.blocks.size(), nullptr);
   for (int i = (int)A.blocks.size() - 1; i >= 0; --i) {
@@ -659,9 +664,9 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
       if (B.has_ds) bn_backward_coefs(c, B.ds, c4, b.bd, P.partial, nb, nk, 2, c4, (float)Mout, 1);
       c.chk(tf_bn_bwd_apply(dtype, Gcur, b.y, b.c3, b.b3.cA, b.b3.cB, b.b3.cD, Mout, c4, T1, c.stream));
     }
-    c.fork();
     // (3) wgrad conv3 (its input is relu(bn2(c2)), materialised in the forward)
-    wgrad(c, B.c3, c4, N, b.Hout, b.Wout, b.Hout, b.Wout, b.a2, pl, T1, c4, nullptr);
+    auto wg3 = [&]() { wgrad(c, B.c3, c4, N, b.Hout, b.Wout, b.Hout, b.Wout, b.a2, pl, T1, c4, nullptr); };
+    if (fork_each) { c.fork(); wg3(); }
     // (4) dgrad conv3 -> gz2 in T2 (masked by relu(bn2(c2))) + BN-backward sums
     conv_fill(a, dtype, 1, N, b.Hout, b.Wout, c4, b.Hout, b.Wout, pl, 1, 1, 0, pl, T1, b.w3t, T2);
     a.epi = TF_EPI_MASK | TF_EPI_STATS2; a.aux = b.c2; a.mask_scale = b.b2.scale; a.mask_shift = b.b2.shift;
@@ -675,9 +680,9 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
       bn_backward_coefs(c, B.c2, pl, b.b2, P.partial, tf_conv_mtiles(&a), 2, 1, pl, (float)Mout);
       c.chk(tf_bn_bwd_apply(dtype, T2, nullptr, b.c2, b.b2.cA, b.b2.cB, b.b2.cD, Mout, pl, T2, c.stream));
     }
-    c.fork();
     // (6) wgrad conv2 (input relu(bn1(c1)))
-    wgrad(c, B.c2, pl, N, b.Hin, b.Win, b.Hout, b.Wout, b.a1, pl, T2, pl, nullptr, 0, 0, 0, P.dwp);
+    auto wg2 = [&]() { wgrad(c, B.c2, pl, N, b.Hin, b.Win, b.Hout, b.Wout, b.a1, pl, T2, pl, nullptr, 0, 0, 0, P.dwp); };
+    if (fork_each) { c.fork(); wg2(); }
     // (7) dgrad conv2 -> gz1 in U1 (+ sums); output spatial = conv2's input
     conv_fill(a, dtype, 1, N, b.Hout, b.Wout, pl, b.Hin, b.Win, pl, 3, B.stride, 1, pl, T2, b.w2t, U1);
     a.epi = TF_EPI_MASK | TF_EPI_STATS2; a.aux = b.c1; a.mask_scale = b.b1.scale; a.mask_shift = b.b1.shift;
@@ -691,9 +696,9 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
       bn_backward_coefs(c, B.c1, pl, b.b1, P.partial, tf_conv_mtiles(&a), 2, 1, pl, (float)Min);
       c.chk(tf_bn_bwd_apply(dtype, U1, nullptr, b.c1, b.b1.cA, b.b1.cB, b.b1.cD, Min, pl, U1, c.stream));
     }
-    c.fork();
     // (9) wgrad conv1 (input = block input, already activated)
-    wgrad(c, B.c1, pl, N, b.Hin, b.Win, b.Hin, b.Win, yin, B.cin, U1, pl, nullptr);
+    auto wg1 = [&]() { wgrad(c, B.c1, pl, N, b.Hin, b.Win, b.Hin, b.Win, yin, B.cin, U1, pl, nullptr); };
+    if (fork_each) { c.fork(); wg1(); }
     // (10) gradient w.r.t. the block input -> Gnext.  Fused flow: the conv that completes it also applies the ReLU mask of
     //      the previous block's output (MASK2 with aux2 = yin) and, unless that block has a downsample branch, accumulates
     //      its BN3-backward sums (STATS3 with aux3 = its c3), so the next iteration starts at step (2).
@@ -709,8 +714,7 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
       } else {
         c.chk(tf_bn_bwd_apply(dtype, Gcur, b.y, b.d, b.bd.cA, b.bd.cB, b.bd.cD, Mout, c4, T3, c.stream));
       }
-      c.fork();
-      wgrad(c, B.ds, c4, N, b.Hin, b.Win, b.Hout, b.Wout, yin, B.cin, T3, c4, nullptr);
+      if (fork_each) { c.fork(); wgrad(c, B.ds, c4, N, b.Hin, b.Win, b.Hout, b.Wout, yin, B.cin, T3, c4, nullptr); }
       conv_fill(a, dtype, 1, N, b.Hout, b.Wout, c4, b.Hin, b.Win, B.cin, 1, B.stride, 0, B.cin, T3, b.wdt, P.T4);
       if (extra) { a.epi = TF_EPI_RES; a.aux = extra; }
       c.chk(tf_conv2d(&a, c.stream));
@@ -723,6 +727,13 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
       if (fused) { a.epi = TF_EPI_RES; a.aux = Gcur; hand_over(a); }       // identity branch: Gcur is already g_y * (y > 0)
       else { a.epi = TF_EPI_JOIN; a.aux2 = b.y; a.aux3 = Gcur; }            // identity branch: + g_y * (y > 0)
       c.chk(tf_conv2d(&a, c.stream));
+    }
+    if (!fork_each) {
+      // alternative schedule: the block's four weight gradients start together once its data-gradient chain is enqueued
+      // and overlap the NEXT block's chain (their operands live in this parity's buffers until block i-2 reuses them)
+      c.fork();
+      wg3(); wg2(); wg1();
+      if (B.has_ds) wgrad(c, B.ds, c4, N, b.Hin, b.Win, b.Hout, b.Wout, yin, B.cin, T3, c4, nullptr);
     }
     block_done[i] = c.mark_side();
     void* t = Gcur; Gcur = Gnext; Gnext = t;

@@ -2,6 +2,8 @@
 // accesses, fp32 math): weight packing, stem im2col, max-pool, BN statistics / finalize /
 // backward, residual join, bilinear head upsample + crop + add and their gradients.
 // Each replaces the torch op cited in tinyfaces_hip.h (tinyfaces/models/model.py:90-126).
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
@@ -42,6 +44,74 @@ __global__ void __launch_bounds__(256) pack_batched_kernel(const PackJobs jobs) 
     float v = 0.f;
     if (co < J.cout && ci < J.cin) v = J.src[((size_t)co * J.cin + ci) * taps + tap];
     tf::Elem<T>::store(out + i, v);
+  }
+}
+
+// Both operand layouts of one weight in one pass: the OIHW fp32 master is read once (coalesced runs of ci*taps floats per
+// output channel) into an LDS tile, then written as [co][tap][ci] (forward operand) and/or [ci][tap][co] (data-gradient
+// operand), each in full segments along its own fastest axis.  The per-element kernel above reads the source with a
+// taps*4-byte (normal) or Cin*taps*4-byte (transposed) lane stride: 1.5 TB/s of traffic for 330 us per training step.
+struct Pack2Jobs { tf_pack2_job j[40]; int tile0[41]; };
+template <typename T>
+__global__ void __launch_bounds__(256) pack2_kernel(const Pack2Jobs jobs, int njobs) {
+  extern __shared__ float tile[];
+  int ji = 0;
+  while (ji + 1 < njobs && (int)blockIdx.x >= jobs.tile0[ji + 1]) ++ji;
+  const tf_pack2_job& J = jobs.j[ji];
+  const int taps = J.taps;
+  const int TR = taps == 1 ? 64 : 32, TC = TR;                 // co x ci tile
+  const int pitch = TC * taps + 1;
+  const int ext_co = max(J.dst ? J.rows_pad : 0, J.dst_t ? J.cols_pad_t : 0);
+  const int ext_ci = max(J.dst ? J.cols_pad : 0, J.dst_t ? J.rows_pad_t : 0);
+  const int tiles_ci = (ext_ci + TC - 1) / TC;
+  const int t = (int)blockIdx.x - jobs.tile0[ji];
+  const int co0 = (t / tiles_ci) * TR, ci0 = (t % tiles_ci) * TC;
+  (void)ext_co;
+  // ---- load: rows of (TC*taps) consecutive floats
+  const int run = TC * taps;
+  for (int e = threadIdx.x; e < TR * run; e += 256) {
+    const int r = e / run, k = e - r * run;
+    const int co = co0 + r, ci = ci0 + k / taps;
+    float v = 0.f;
+    if (co < J.cout && ci < J.cin) v = J.src[((size_t)co * J.cin + ci0) * taps + k];
+    tile[r * pitch + k] = v;
+  }
+  __syncthreads();
+  // ---- forward operand [co][tap][ci]: ci fastest, 4 consecutive channels per lane (8-byte bf16 / 16-byte fp32 stores)
+  auto store4 = [](T* p, float a, float b, float c_, float d) {
+    if constexpr (sizeof(T) == 2) {
+      uint2 q;
+      q.x = tf::pack_bf16x2(a, b);
+      q.y = tf::pack_bf16x2(c_, d);
+      *reinterpret_cast<uint2*>(p) = q;
+    } else {
+      *reinterpret_cast<float4*>(p) = make_float4(a, b, c_, d);
+    }
+  };
+  const int Q = TC / 4;
+  if (J.dst) {
+    T* out = reinterpret_cast<T*>(J.dst);
+    for (int e = threadIdx.x; e < TR * taps * Q; e += 256) {
+      const int q = e % Q, tap = (e / Q) % taps, r = e / (Q * taps);
+      const int co = co0 + r, ci = ci0 + 4 * q;
+      if (co < J.rows_pad && ci < J.cols_pad) {
+        const float* t0 = tile + r * pitch + (4 * q) * taps + tap;
+        store4(out + ((size_t)co * taps + tap) * J.cols_pad + ci, t0[0], t0[taps], t0[2 * taps], t0[3 * taps]);
+      }
+    }
+  }
+  // ---- data-gradient operand [ci][tap][co]: co fastest (LDS column walk, odd pitch: conflict-free)
+  if (J.dst_t) {
+    T* out = reinterpret_cast<T*>(J.dst_t);
+    const int QR = TR / 4;
+    for (int e = threadIdx.x; e < TC * taps * QR; e += 256) {
+      const int q = e % QR, tap = (e / QR) % taps, cl = e / (QR * taps);
+      const int co = co0 + 4 * q, ci = ci0 + cl;
+      if (ci < J.rows_pad_t && co < J.cols_pad_t) {
+        const float* t0 = tile + (4 * q) * pitch + cl * taps + tap;
+        store4(out + ((size_t)ci * taps + tap) * J.cols_pad_t + co, t0[0], t0[pitch], t0[2 * pitch], t0[3 * pitch]);
+      }
+    }
   }
 }
 
@@ -544,6 +614,34 @@ extern "C" int tf_pack_weights_batched(int dtype, const tf_pack_job* host_jobs, 
     const int n = njobs - j0 < 64 ? njobs - j0 : 64;
     for (int k = 0; k < n; ++k) pj.j[k] = host_jobs[j0 + k];
     DISPATCH_T(dtype, hipLaunchKernelGGL(pack_batched_kernel<T>, dim3(48, n), dim3(256), 0, (hipStream_t)stream, pj));
+  }
+  TF_CHECK_LAUNCH();
+  return TF_OK;
+}
+
+extern "C" int tf_pack_weights_tiled(int dtype, const tf_pack2_job* host_jobs, int njobs, void* stream) {
+  if (njobs < 0 || (njobs > 0 && !host_jobs)) return TF_ERR_ARG;
+  for (int j0 = 0; j0 < njobs; j0 += 40) {
+    Pack2Jobs pj;
+    const int n = njobs - j0 < 40 ? njobs - j0 : 40;
+    int tiles = 0, max_taps = 1;
+    for (int k = 0; k < n; ++k) {
+      const tf_pack2_job& J = host_jobs[j0 + k];
+      if (!J.src || (!J.dst && !J.dst_t) || J.taps < 1 || J.taps > 9) return TF_ERR_ARG;
+      if ((J.dst && J.cols_pad % 4) || (J.dst_t && J.cols_pad_t % 4)) return TF_ERR_ARG;      // 4 elements per store
+      pj.j[k] = J;
+      pj.tile0[k] = tiles;
+      const int T_ = J.taps == 1 ? 64 : 32;
+      const int ext_co = std::max(J.dst ? J.rows_pad : 0, J.dst_t ? J.cols_pad_t : 0);
+      const int ext_ci = std::max(J.dst ? J.cols_pad : 0, J.dst_t ? J.rows_pad_t : 0);
+      tiles += ((ext_co + T_ - 1) / T_) * ((ext_ci + T_ - 1) / T_);
+      if (J.taps > max_taps) max_taps = J.taps;
+    }
+    pj.tile0[n] = tiles;
+    const int T_ = max_taps == 1 ? 64 : 32;
+    const size_t lds = (size_t)T_ * (T_ * max_taps + 1) * 4;
+    const size_t lds1 = (size_t)64 * 65 * 4;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(pack2_kernel<T>, dim3(tiles), dim3(256), lds > lds1 ? lds : lds1, (hipStream_t)stream, pj, n));
   }
   TF_CHECK_LAUNCH();
   return TF_OK;

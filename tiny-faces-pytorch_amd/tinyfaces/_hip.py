@@ -23,6 +23,12 @@ class HipLibraryMissing(RuntimeError):
     pass
 
 
+class Pack2Job(C.Structure):
+    """tf_pack2_job (include/tinyfaces_hip.h)."""
+    _fields_ = [("src", vp), ("dst", vp), ("dst_t", vp), ("cout", i32), ("cin", i32), ("taps", i32), ("rows_pad", i32), ("cols_pad", i32),
+                ("rows_pad_t", i32), ("cols_pad_t", i32)]
+
+
 class BnFwdDesc(C.Structure):
     """tf_bn_fwd_desc (include/tinyfaces_hip.h)."""
     _fields_ = [("stat", vp), ("gamma", vp), ("beta", vp), ("scale", vp), ("shift", vp), ("mean", vp), ("invstd", vp),
@@ -100,6 +106,7 @@ _SIGNATURES = {
     "tf_detnet_forward": (i32, [i32, i32, vp, i32, i32, i32, i32, vp, f32, f32, vp, vp, sz, i32, vp]),
     "tf_detnet_backward": (i32, [i32, vp, i32, i32, i32, i32, vp, vp, vp, vp, sz, vp, sz, vp]),
     "tf_pack_weights_batched": (i32, [i32, vp, i32, vp]),
+    "tf_pack_weights_tiled": (i32, [i32, vp, i32, vp]),
     "tf_detnet_set_dual_stream": (i32, [i32]),
     "tf_probe_tr16": (i32, [vp, vp]),
     "tf_set_stat_rows": (i32, [i32]),
