@@ -112,7 +112,7 @@ def test_nms_golden(golden, ci):
     assert np.array_equal(keep, g[f"{tag}_keep"])                       # identical indices, identical order
 
 
-@pytest.mark.parametrize("n,seed", [(63, 1), (64, 2), (65, 3), (1000, 4), (5000, 5), (20000, 6)])
+@pytest.mark.parametrize("n,seed", [(63, 1), (64, 2), (65, 3), (1000, 4), (5000, 5), (12288, 7), (12289, 8), (20000, 6)])
 def test_nms_random_vs_oracle(n, seed):
     from tinyfaces import ops
     from oracle.nms import nms as onms

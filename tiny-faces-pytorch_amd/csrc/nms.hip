@@ -80,9 +80,14 @@ __global__ void __launch_bounds__(64) nms_mask_kernel(const double* __restrict__
 }
 
 // Greedy scan over the score-sorted boxes, 64 at a time.  Wave 0 walks the chain: it resolves chunk c against removed[c]
-// (64 scalar steps on the diagonal word), then folds the rows it kept into removed[c+1] itself (one prefetched word per lane,
-// wave OR-reduction), so the next chunk can start at once.  Waves 1..15 trail one chunk behind and push the kept rows of
-// chunk c-1 into removed[w], w >= c+1, five row-slices per word with LDS atomics; one barrier per chunk joins the two.
+// (64 scalar steps on the diagonal word), then folds the rows it kept into removed[c+1] itself (one word per lane, wave
+// OR-reduction), so the next chunk can start at once; its three global words per chunk (diagonal, next column, original
+// index) are fetched one chunk AHEAD, so no memory latency sits on the chain.  Waves 1..15 trail one chunk behind and push
+// the kept rows of chunk c-1 into removed[w], w >= c+1: a thread owns one word and a 13-row range, issues its (predicated)
+// row loads together and ORs once into LDS.  One barrier per chunk joins the two.  PREFETCH (n <= 12288: every (word, row
+// range) pair has its own thread): the trailing threads fetch the 13 rows of chunk c while wave 0 is still resolving it and
+// only select + OR them once its keep bits are known, so the push carries no memory latency either.
+template <bool PREFETCH>
 __global__ void __launch_bounds__(1024) nms_scan_kernel(const unsigned long long* __restrict__ mask, const int* __restrict__ order,
                                                         int n, int nwords, int64_t* __restrict__ keep, int* __restrict__ num_keep) {
   extern __shared__ unsigned long long removed[];   // nwords + 2: [nwords] / [nwords+1] = keep bits of even / odd chunks
@@ -90,51 +95,89 @@ __global__ void __launch_bounds__(1024) nms_scan_kernel(const unsigned long long
   __syncthreads();
   int kcount = 0;                                    // meaningful in wave 0 only
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int c = 0; c <= nwords; ++c) {
-    if (wave == 0) {
-      if (c < nwords) {
-        const int i = c * 64 + lane;
-        const unsigned long long diag = (i < n) ? mask[(size_t)i * nwords + c] : 0ull;
-        const unsigned long long next = (i < n && c + 1 < nwords) ? mask[(size_t)i * nwords + c + 1] : 0ull;
-        const int oi = (i < n) ? order[i] : 0;                  // issued with the mask words, long before it is needed
-        unsigned long long rem = removed[c];
-        const int nvalid = min(64, n - c * 64);                // boxes past n do not exist
-        unsigned long long kb = 0;
-        const unsigned int dlo = (unsigned int)diag, dhi = (unsigned int)(diag >> 32);
-        for (int b = 0; b < 64; ++b) {
-          // readlane returns a SIGNED int: go through unsigned or the low word sign-extends into the high word
-          const unsigned long long d = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dhi, b) << 32) |
-                                       (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dlo, b);
-          if (b < nvalid && !((rem >> b) & 1ull)) { kb |= 1ull << b; rem |= d; }
-        }
-        const bool mine = (kb >> lane) & 1ull;
-        if (mine) keep[kcount + __popcll(kb & ((1ull << lane) - 1ull))] = (int64_t)oi;
-        kcount += __popcll(kb);
-        // rows kept in this chunk -> removed[c+1] (the only word the next resolve needs from this chunk)
-        unsigned int lo = mine ? (unsigned int)next : 0u, hi = mine ? (unsigned int)(next >> 32) : 0u;
+  // wave 0: operands of the chunk being resolved (fetched during the previous iteration)
+  unsigned long long diag = 0, next = 0;
+  unsigned long long pv[13];                         // PREFETCH: this thread's rows of the chunk in flight
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { lo |= __shfl_xor(lo, off, 64); hi |= __shfl_xor(hi, off, 64); }
-        if (lane == 0) {
-          if (c + 1 < nwords) atomicOr(&removed[c + 1], ((unsigned long long)hi << 32) | lo);
-          removed[nwords + (c & 1)] = kb;
+  for (int j = 0; j < 13; ++j) pv[j] = 0;
+  int oi = 0;
+  if (wave == 0) {
+    const int i = lane;
+    if (i < n) { diag = mask[(size_t)i * nwords]; next = nwords > 1 ? mask[(size_t)i * nwords + 1] : 0ull; oi = order[i]; }
+  }
+  for (int c = 0; c < nwords; ++c) {
+    if (wave == 0) {
+      // prefetch chunk c+1
+      unsigned long long pdiag = 0, pnext = 0;
+      int poi = 0;
+      {
+        const int i2 = (c + 1) * 64 + lane;
+        if (c + 1 < nwords && i2 < n) {
+          pdiag = mask[(size_t)i2 * nwords + c + 1];
+          pnext = (c + 2 < nwords) ? mask[(size_t)i2 * nwords + c + 2] : 0ull;
+          poi = order[i2];
+        }
+      }
+      // removed[c] is the same word in every lane: make it scalar so that the whole resolve runs on the scalar unit
+      const unsigned long long remv = removed[c];
+      const unsigned long long rem = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(remv >> 32)) << 32) |
+                                     (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)remv);
+      const int nvalid = min(64, n - c * 64);                // boxes past n do not exist
+      const unsigned long long valid = nvalid >= 64 ? ~0ull : ((1ull << nvalid) - 1ull);
+      // walk the SURVIVORS only (one step per kept box, ~14 of 64 on the bench pyramid): the lowest candidate is kept
+      // (everything that could suppress it is decided), then it strikes out the later boxes it overlaps
+      unsigned long long cand = valid & ~rem, kb = 0;
+      const unsigned int dlo = (unsigned int)diag, dhi = (unsigned int)(diag >> 32);
+      while (cand) {
+        const int b = __builtin_ctzll(cand);
+        // readlane returns a SIGNED int: go through unsigned or the low word sign-extends into the high word
+        const unsigned long long d = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dhi, b) << 32) |
+                                     (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dlo, b);
+        kb |= 1ull << b;
+        cand &= ~(d | (1ull << b));
+      }
+      const bool mine = (kb >> lane) & 1ull;
+      if (mine) keep[kcount + __popcll(kb & ((1ull << lane) - 1ull))] = (int64_t)oi;
+      kcount += __popcll(kb);
+      // rows kept in this chunk -> removed[c+1] (the only word the next resolve needs from this chunk)
+      if (mine && next && c + 1 < nwords) atomicOr(&removed[c + 1], next);     // LDS atomics: cheaper than a 64-bit wave OR-reduction
+      if (lane == 0) removed[nwords + (c & 1)] = kb;
+      diag = pdiag; next = pnext; oi = poi;
+    } else if (PREFETCH) {
+      const int t = threadIdx.x - 64;                    // 0..959
+      const int slice = t % 5, w = t / 5;                 // one word, rows 13*slice .. 13*slice+12 of every chunk
+      if (c >= 1 && w >= c + 1 && w < nwords) {           // rows of chunk c-1 were fetched during the previous iteration
+        const unsigned long long kb = removed[nwords + ((c - 1) & 1)];
+        const unsigned int bits = (unsigned int)(kb >> (13 * slice)) & 0x1FFFu;
+        unsigned long long acc = 0;
+#pragma unroll
+        for (int j = 0; j < 13; ++j) acc |= ((bits >> j) & 1u) ? pv[j] : 0ull;
+        if (acc) atomicOr(&removed[w], acc);
+      }
+      if (w >= c + 2 && w < nwords) {
+#pragma unroll
+        for (int j = 0; j < 13; ++j) {
+          const int rl = 13 * slice + j, row = c * 64 + rl;
+          pv[j] = (rl < 64 && row < n) ? mask[(size_t)row * nwords + w] : 0ull;
         }
       }
     } else if (c >= 1) {
       // trailing push of chunk c-1's kept rows into words >= c+1
       const unsigned long long kb = removed[nwords + ((c - 1) & 1)];
       const int t = threadIdx.x - 64;                    // 0..959
-      const int slice = t % 5, wi = t / 5;                // 192 words per sweep, 5 row-slices each
-      // slice s owns bits {s, s+5, ...}: walk the set bits, keep every 5th
-      for (int w = c + 1 + wi; w < nwords; w += 192) {
-        unsigned long long acc = 0, k = kb;
-        int idx = 0;
-        while (k) {
-          const int b = __ffsll((long long)k) - 1;
-          k &= k - 1;
-          if (idx == slice) acc |= mask[(size_t)((c - 1) * 64 + b) * nwords + w];
-          idx = idx == 4 ? 0 : idx + 1;
+      const int slice = t % 5, wi = t / 5;                // 192 words per sweep; slice s owns rows 13s .. 13s+12 of the chunk
+      const unsigned int bits = (unsigned int)(kb >> (13 * slice)) & 0x1FFFu;
+      const size_t row0 = (size_t)(c - 1) * 64 + 13 * slice;
+      if (bits) {
+        for (int w = c + 1 + wi; w < nwords; w += 192) {
+          unsigned long long v[13];
+#pragma unroll
+          for (int j = 0; j < 13; ++j) v[j] = ((bits >> j) & 1u) ? mask[(row0 + j) * nwords + w] : 0ull;
+          unsigned long long acc = 0;
+#pragma unroll
+          for (int j = 0; j < 13; ++j) acc |= v[j];
+          if (acc) atomicOr(&removed[w], acc);
         }
-        if (acc) atomicOr(&removed[w], acc);
       }
     }
     __syncthreads();
@@ -167,8 +210,10 @@ extern "C" int tf_nms_f64(const double* boxes, const double* scores, int n, doub
   unsigned long long* mask = (unsigned long long*)w;
   hipLaunchKernelGGL(nms_rank_kernel, dim3((n + 31) / 32), dim3(256), 0, stream, scores, boxes, n, order, sboxes);
   hipLaunchKernelGGL(nms_mask_kernel, dim3(nwords, nwords), dim3(64), 0, stream, sboxes, n, iou_thresh, nwords, mask);
-  hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(1024), (size_t)(nwords + 2) * 8, stream, mask, order, n, nwords,
-                     keep_out, num_keep);
+  if (nwords <= 192)
+    hipLaunchKernelGGL(nms_scan_kernel<true>, dim3(1), dim3(1024), (size_t)(nwords + 2) * 8, stream, mask, order, n, nwords, keep_out, num_keep);
+  else
+    hipLaunchKernelGGL(nms_scan_kernel<false>, dim3(1), dim3(1024), (size_t)(nwords + 2) * 8, stream, mask, order, n, nwords, keep_out, num_keep);
   TF_CHECK_LAUNCH();
   return TF_OK;
 }
