@@ -6,17 +6,23 @@
 // tinyfaces/trainer.py:86 triggers.
 //
 // Data layout in HBM: activations NHWC ("pixels x channels"), dtype bf16 (fast) or fp32
-// (parity); BN vectors, statistics and all gradients fp32; weights re-packed per call from the
-// fp32 OIHW master copy into K-contiguous [Cout][tap][Cin] (forward / wgrad operand) and
-// [Cin][tap][Cout] (data-gradient operand).
+// (parity); BN vectors, statistics and all gradients fp32; weights re-packed once per training
+// step (or once per constant_weights() session in eval) from the fp32 OIHW master copy into
+// K-contiguous [Cout][tap][Cin] (forward / wgrad operand) and [Cin][tap][Cout] (data-gradient
+// operand), both from one read of the master (tf_pack_weights_tiled).
 //
-// Fusion plan (what never makes an HBM round trip):
-//   eval : BN folded to a per-channel affine inside every conv epilogue, + residual + ReLU
-//   train: conv epilogue emits per-tile (sum, sumsq) partials -> tiny finalize -> the NEXT
-//          conv (and the wgrad) applies BN+ReLU while staging its input tile; only the block
-//          output y = relu(bn3(c3) + identity) is a separate pass.
-//          backward: dgrad epilogues apply the ReLU mask and emit the BN-backward sums; the
-//          residual-join gradient is folded into conv1's dgrad epilogue.
+// Fusion plan (what never makes an HBM round trip, and what never costs a launch):
+//   eval : BN folded to a per-channel affine inside every conv epilogue, + residual + ReLU.
+//   train: conv epilogues fold per-tile (sum, sumsq) into the BN's own statistic rows; the
+//          elementwise consumer (bn_relu_fused -> a1/a2, bn_add_relu_fused -> y) finalizes them
+//          in-kernel, so a bottleneck is 6 launches.  a1/a2 are materialised on purpose: every
+//          conv and every weight gradient then runs on the LDS-DMA pipeline (no prologue).
+//   backward: dgrad epilogues apply the ReLU mask and fold the BN-backward sums; the last data
+//          gradient of a block hands the previous block g*(y>0) AND its BN3-backward sums
+//          (RES|MASK2|STATS3); bn_bwd_apply_fused finalizes in-kernel; weight gradients run on
+//          a second stream against parity buffers.
+//   tf_set_stat_rows(0) (unfolded, bit-reproducible statistics) falls back to the separate
+//   finalize kernels and the unmasked gradient flow: the A/B and race-screen path.
 #include <cstdlib>
 #include <cstring>
 #include <string>
