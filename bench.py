@@ -100,6 +100,25 @@ def cpu_baseline(bs=1, steps=1):
             "sample": f"{steps} timed steps (1 warm-up) of bs={bs} 500x500: numpy target assignment + torch-CPU fp32 fwd/loss/bwd/SGD"}
 
 
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01e_pmc_traffic.json")
+PMC_PATTERNS = {13: "conv_dma_kernel<tf::bf16_t, 64, 64, 3", 12: "conv_dma_kernel<float, 64, 64, 4", 14: "wgrad_dma_kernel"}
+
+
+def pmc_traffic(kind):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
+    (scripts/gpu_pmc_bench.sh: FETCH_SIZE x2 + WRITE_SIZE, separate passes).  Counters cannot be read from inside the
+    process, so this is the offline measurement, labelled as such; None when the file or the kernel is missing."""
+    try:
+        with open(PMC_TRAFFIC_FILE) as f:
+            data = json.load(f)
+        pat = PMC_PATTERNS[kind]
+        rows = [v for k, v in data["kernels"].items() if k.startswith(pat)]
+        n = sum(r["launches"] for r in rows)
+        return round(sum(r["hbm_bytes"] * r["launches"] for r in rows) / n) if n else None
+    except Exception:
+        return None
+
+
 def bench_eval(model, templates, device, runs=5):
     """configs[1]: 1280x960 image, 3-scale pyramid (480x640, 960x1280, 1920x2560): forward x3 + decode + one NMS."""
     from tinyfaces import ops
@@ -235,7 +254,10 @@ def main():
         peak = PEAK_TFLOPS["bf16" if dom["kind"] in (3, 4, 5, 10, 11, 13, 14) else "fp32"]
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         out["roofline"] = {"kernel": KIND_NAMES.get(dom["kind"], str(dom["kind"])), "bound": "mfma", "achieved": round(ach, 2), "peak": peak,
-                           "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None, "launches": dom["launches"],
+                           "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": pmc_traffic(dom["kind"]),
+                           "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes of this command (profiles/r01e_pmc_traffic.json); "
+                                           "algorithmic bytes per launch = %d" % round(dom["bytes"] / dom["launches"]),
+                           "launches": dom["launches"],
                            "sampling": f"HIP events around 1 launch in {PROFILE_EVERY} over the timed region",
                            "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
                            "algorithmic_gflop_per_launch": round(dom["flops"] / dom["launches"] / 1e9, 3),
