@@ -179,17 +179,24 @@ def main():
     from tinyfaces.models.loss import DetectionCriterion
     from tinyfaces.models.model import DetectionModel
 
+    # stdout carries exactly ONE JSON line: libraries (RCCL prints a version banner through C stdio) get stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     share = os.environ.get("TINYFACES_BENCH_SHARE_GPU") == "1"      # functional test of the N>1 path on a 1-GPU box (gloo, shared device)
     if world > 1:
         parallel.init_from_env("gloo" if share else "nccl")
+    elif os.environ.get("TINYFACES_FORCE_DIST") == "1":      # test knob: the RCCL + event-overlap path with a 1-rank group on one GPU
+        parallel.init_from_env("nccl")
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     device = torch.device(f"cuda:{local % torch.cuda.device_count() if share else local}")
     torch.cuda.set_device(device)
     _hip.lib()                                           # fail loudly if the HIP library is missing
-    if os.environ.get("TINYFACES_STAT_ROWS"):            # tuning knob: BN statistic partial rows (default TF_STAT_ROWS = 64)
+    if os.environ.get("TINYFACES_STAT_ROWS"):            # tuning knob: BN statistic partial rows (default 8)
         _hip.lib().tf_set_stat_rows(int(os.environ["TINYFACES_STAT_ROWS"]))
 
     templates = load_templates()
@@ -197,7 +204,7 @@ def main():
     torch.manual_seed(0)
     model = tame_init_(DetectionModel(num_objects=1, num_templates=25)).set_compute_dtype(args.dtype)
     if args.eval_only:
-        print(json.dumps({"eval": bench_eval(model.to(device), templates, device, runs=10)}))
+        os.write(json_fd, (json.dumps({"eval": bench_eval(model.to(device), templates, device, runs=10)}) + "\n").encode())
         return
     crit = DetectionCriterion(25, seed=rank, lazy_meters=True)
     eng = TrainEngine(model, crit, lr=1e-4, momentum=0.9, weight_decay=5e-4, device=device)
@@ -272,7 +279,7 @@ def main():
             out["eval"] = {"error": repr(e)}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
-    print(json.dumps(out))
+    os.write(json_fd, (json.dumps(out) + "\n").encode())
 
 
 if __name__ == "__main__":

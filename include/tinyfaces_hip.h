@@ -292,6 +292,13 @@ int tf_detnet_forward(int dtype, int training, const float* x_nchw, int N, int H
                       float* out_nchw, void* ws, size_t ws_bytes, int flags, void* stream);
 /* 1 (default): weight gradients run on an internal second stream concurrently with the data-gradient chain; 0: single stream */
 int tf_detnet_set_dual_stream(int on);
+/* Data-parallel overlap: hipEvent_t handles recorded by the NEXT tf_detnet_backward calls when the gradients of all
+ * bottlenecks >= blocks[k] (and of the heads) are enqueued (blocks[k] = -1: at the very end, stem included).  A
+ * communication stream that waits on events[k] can all-reduce that bucket while the rest of the backward pass runs
+ * (the reference has no distributed path; this serves the 8-GPU data-parallel row of SURVEY.md section 8e).
+ * n = 0 clears.  BN gamma/beta gradients of a block are written on the caller's stream BEFORE the fork that precedes the
+ * event's stream position, so one event covers them too. */
+int tf_detnet_set_grad_events(const int* blocks, void* const* events, int n);
 /* grad_flat (optional): when every entry of `grads` lies inside [grad_flat, grad_flat + grad_flat_bytes) the whole
  * range is zeroed with ONE memset instead of one per weight gradient. */
 int tf_detnet_backward(int dtype, const float* x_nchw, int N, int H, int W, int num_out,

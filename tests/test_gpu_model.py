@@ -327,3 +327,49 @@ def test_constant_weights_session_is_bit_identical(models, dtype):
             assert float((y2 - ref[0]).abs().max()) > 0.5
         finally:
             w.data.copy_(old)
+
+
+def test_grad_ready_events_are_recorded_in_backward_order():
+    """tf_detnet_set_grad_events (data-parallel overlap): the executor records the caller's events while enqueuing the
+    backward pass.  The event of a LATER bucket (lower block index) must not complete before an earlier one, all of them
+    must complete, and once the last (-1) has, the gradients equal those of a run without events."""
+    import ctypes as C
+    from tinyfaces import _hip
+    from tinyfaces.models.model import DetectionModel
+    m = DetectionModel(num_templates=25)
+    _load_oracle_weights(m)
+    m = m.cuda().set_compute_dtype(torch.bfloat16).train()
+    x = torch.randn(2, 3, 160, 192, generator=torch.Generator().manual_seed(11)).cuda()
+
+    def grads():
+        m.zero_grad(set_to_none=True)
+        y = m(x)
+        y.backward(torch.ones_like(y))
+        return y
+
+    blocks_py = [22, 14, 7, -1]
+    evs = [torch.cuda.Event(enable_timing=True) for _ in blocks_py]
+    for e in evs:
+        e.record()
+    torch.cuda.synchronize()
+    blocks = (C.c_int * 4)(*blocks_py)
+    handles = (C.c_void_p * 4)(*[int(e.cuda_event) for e in evs])
+    try:
+        _hip.lib().tf_set_stat_rows(0)          # reproducible BN statistics: two runs differ by weight-gradient atomics only
+        assert _hip.lib().tf_detnet_set_grad_events(blocks, handles, 4) == 0
+        t0 = torch.cuda.Event(enable_timing=True)
+        t0.record()
+        grads()
+        evs[-1].synchronize()
+        got = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+        times = [t0.elapsed_time(e) for e in evs]
+        assert _hip.lib().tf_detnet_set_grad_events(None, None, 0) == 0
+        grads()
+        torch.cuda.synchronize()
+    finally:
+        _hip.lib().tf_detnet_set_grad_events(None, None, 0)
+        _hip.lib().tf_set_stat_rows(8)
+    assert all(t > 0 for t in times) and times == sorted(times), times
+    worst = max(float((got[k] - p.grad).abs().max() / (p.grad.abs().max() + 1e-30)) for k, p in m.named_parameters() if p.grad is not None)
+    report("grad_events", times_ms=[round(t, 3) for t in times], worst_rel=worst)
+    assert worst < 1e-3

@@ -26,6 +26,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "common.h"
@@ -574,6 +575,23 @@ void wgrad(Ctx& c, const ConvUnit& u, int cout, int N, int H, int W, int OH, int
 }  // namespace
 
 static bool g_force_single = false;
+// gradient-ready events (data-parallel overlap): after the weight gradients of bottleneck `block` (backward order: the
+// LAST block of a bucket) are enqueued, the caller's event is recorded on the stream that carries them, so a communication
+// stream can start reducing that bucket while the rest of the backward pass runs.  block -1 = the very end (stem done).
+static std::vector<std::pair<int, hipEvent_t>> g_grad_events;
+extern "C" int tf_detnet_set_grad_events(const int* blocks, void* const* events, int n) {
+  g_grad_events.clear();
+  if (n < 0 || (n > 0 && (!blocks || !events))) return TF_ERR_ARG;
+  for (int k = 0; k < n; ++k) {
+    if (!events[k]) return TF_ERR_ARG;
+    g_grad_events.emplace_back(blocks[k], (hipEvent_t)events[k]);
+  }
+  return TF_OK;
+}
+static void record_grad_events(int block, hipStream_t s, int& rc) {
+  for (const auto& e : g_grad_events)
+    if (e.first == block && hipEventRecord(e.second, s) != hipSuccess && rc == TF_OK) rc = TF_ERR_LAUNCH;
+}
 // 1 = weight gradients on a second stream (default), 0 = everything on the caller's stream (A/B + race tests)
 extern "C" int tf_detnet_set_dual_stream(int on) { g_force_single = !on; return TF_OK; }
 
@@ -742,6 +760,7 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
       if (B.has_ds) wgrad(c, B.ds, c4, N, b.Hin, b.Win, b.Hout, b.Wout, yin, B.cin, T3, c4, nullptr);
     }
     block_done[i] = c.mark_side();
+    record_grad_events(i, c.wstream(), c.rc);      // everything up to here on that stream: the weight/BN gradients of blocks >= i and of the heads
     void* t = Gcur; Gcur = Gnext; Gnext = t;
   }
 
@@ -760,6 +779,7 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
     wgrad(c, s, 64, 1, 1, M1, 1, M1, P.col, kStemK, gz, 64, nullptr, 147, 1, 147);
   }
   c.wait_on_main(c.mark_side());           // join: the caller's stream sees every weight gradient
+  record_grad_events(-1, c.stream, c.rc);
   if (hipGetLastError() != hipSuccess && c.rc == TF_OK) c.rc = TF_ERR_LAUNCH;
   return c.rc;
 }

@@ -103,6 +103,7 @@ _SIGNATURES = {
     "tf_detnet_workspace_bytes": (sz, [i32, i32, i32, i32, i32, i32]),
     "tf_detnet_out_shape": (i32, [i32, i32, C.POINTER(i32), C.POINTER(i32)]),
     "tf_detnet_param_region_bytes": (sz, [i32, i32, i32]),
+    "tf_detnet_set_grad_events": (i32, [vp, vp, i32]),
     "tf_detnet_forward": (i32, [i32, i32, vp, i32, i32, i32, i32, vp, f32, f32, vp, vp, sz, i32, vp]),
     "tf_detnet_backward": (i32, [i32, vp, i32, i32, i32, i32, vp, vp, vp, vp, sz, vp, sz, vp]),
     "tf_pack_weights_batched": (i32, [i32, vp, i32, vp]),

@@ -2,15 +2,23 @@
 no per-parameter Python loop and no host sync:
 
     targets (HIP) -> forward (HIP executor) -> criterion fwd+bwd (HIP) -> backward (HIP executor)
-    -> [RCCL all-reduce of the flat gradient] -> fused SGD (one launch per parameter group)
+    -> [RCCL all-reduce of the flat gradient, overlapped with the backward pass] -> fused SGD (one launch per group)
+
+Data-parallel overlap: the flat gradient is cut into 4 buckets along the backward order (heads + layer3.15-22,
+layer3.7-14, layer3.0-6, layer1/2 + stem).  The executor records an event when a bucket's gradients are enqueued
+(tf_detnet_set_grad_events); a communication stream waits on it and starts that bucket's all-reduce while the
+remaining bottlenecks are still being differentiated, so only the last, small bucket is exposed.
 
 Semantics are those of main.py:67-70 (SGD momentum 0.9, weight decay 5e-4, the 4 learning-rate groups of
 model.py:67-87) and of DetectionCriterion (loss.py).  `trainer.train` (autograd + torch.optim) remains the
 drop-in path; this engine is what bench.py and the bundled main.py use."""
+import ctypes as C
+
 import torch
 import torch.distributed as dist
 
 from . import ops, parallel
+from ._hip import lib
 
 
 class TrainEngine:
@@ -26,12 +34,50 @@ class TrainEngine:
         self.lr, self.momentum, self.weight_decay = lr, momentum, weight_decay
         self.bucket_elems = int(bucket_mb * (1 << 20) // 4)
         self.steps = 0
+        self._overlap = None
+        if parallel.is_distributed():
+            self._setup_overlap()
+
+    # first bottleneck (executor index: layer1 0-2, layer2 3-6, layer3 7-29) of each bucket, in backward order
+    _BUCKET_FIRST_BLOCK = (22, 14, 7)
+
+    def _setup_overlap(self):
+        names = [f"model.{l}.{i}." for l, n in (("layer1", 3), ("layer2", 4), ("layer3", 23)) for i in range(n)]
+        seg = self.model._segments
+        ranges, end = [], self.flat_p.numel()
+        for b in self._BUCKET_FIRST_BLOCK:
+            start = min(o for k, (o, _) in seg.items() if k.startswith(names[b]))
+            ranges.append((b, start, end))
+            end = start
+        ranges.append((-1, 0, end))                       # layer1, layer2, stem: ready at the very end
+        events = []
+        for _ in ranges:
+            ev = torch.cuda.Event()
+            ev.record()                                   # materialises the hipEvent_t handle
+            events.append(ev)
+        blocks = (C.c_int * len(ranges))(*[r[0] for r in ranges])
+        handles = (C.c_void_p * len(ranges))(*[int(ev.cuda_event) for ev in events])
+        rc = lib().tf_detnet_set_grad_events(blocks, handles, len(ranges))
+        if rc != 0:
+            raise RuntimeError(f"tf_detnet_set_grad_events failed: {rc}")
+        self._overlap = dict(ranges=ranges, events=events, comm=torch.cuda.Stream(device=self.device), keep=(blocks, handles))
 
     def set_lr(self, lr):
         self.lr = lr
 
     def _allreduce(self, gflat):
-        """Few large buckets, launched in reverse-execution order (heads / layer3 first), async on RCCL's stream."""
+        """Per bucket: the communication stream waits for the executor's gradient-ready event, then the all-reduce is
+        issued from it (RCCL's own stream orders itself after the issuing stream); the compute stream only waits at
+        the end.  Without the events (not set up): few large buckets after the whole backward pass."""
+        if self._overlap is not None:
+            ov, works = self._overlap, []
+            for (_, start, end), ev in zip(ov["ranges"], ov["events"]):
+                with torch.cuda.stream(ov["comm"]):
+                    ov["comm"].wait_event(ev)
+                    works.append(dist.all_reduce(gflat[start:end], op=dist.ReduceOp.SUM, async_op=True))
+            for w in works:
+                w.wait()
+            return
         works, end = [], gflat.numel()
         while end > 0:
             start = max(0, end - self.bucket_elems)

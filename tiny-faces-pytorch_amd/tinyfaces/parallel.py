@@ -15,8 +15,11 @@ import torch
 import torch.distributed as dist
 
 
+_FORCE = os.environ.get("TINYFACES_FORCE_DIST") == "1"      # test knob: run the collective path with a 1-rank group
+
+
 def is_distributed():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE)
 
 
 def rank():
@@ -30,7 +33,11 @@ def world_size():
 def init_from_env(backend=None):
     """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun contract).
     backend 'nccl' is RCCL on ROCm; 'gloo' for the CPU tests."""
-    if "RANK" not in os.environ or int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+    if _FORCE and "RANK" not in os.environ:
+        os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+    elif "RANK" not in os.environ or int(os.environ.get("WORLD_SIZE", "1")) <= 1:
         return False
     if not dist.is_initialized():
         backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
