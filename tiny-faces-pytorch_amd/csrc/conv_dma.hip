@@ -378,7 +378,16 @@ int tf_conv_dma_launch(const tf_conv_args* a, int tile, int depth, hipStream_t s
   if (a->dtype == TF_BF16) {
     if (tile == 1) return launch<tf::bf16_t, 128, 128, 3>(a, stream);
     if (tile == 2) return depth == 4 ? launch<tf::bf16_t, 128, 64, 4>(a, stream) : launch<tf::bf16_t, 128, 64, 3>(a, stream);
-    return depth == 3 ? launch<tf::bf16_t, 64, 64, 3>(a, stream) : launch<tf::bf16_t, 64, 64, 4>(a, stream);
+    if (depth == 3) {
+      // convs of up to 16 K-stages (every 1x1 of the trunk, K <= 1024) are dispatch + prologue + epilogue bound rather than
+      // K-loop bound: a 2-deep ring is 32 KiB of LDS, so five blocks fit a CU instead of three and more of those phases
+      // overlap.  A/B on one box, img/s: 956 (3-deep everywhere), 989 (<= 4 stages), 996 (<= 8), 1008 (<= 16), 1001 (all).
+      static const int ns2_max = [] { const char* e = getenv("TINYFACES_NS2_MAXSTAGES"); return e ? atoi(e) : 16; }();
+      const int nst = a->KH * a->KW * (a->Cin / 64);
+      if (nst <= ns2_max) return launch<tf::bf16_t, 64, 64, 2>(a, stream);
+      return launch<tf::bf16_t, 64, 64, 3>(a, stream);
+    }
+    return launch<tf::bf16_t, 64, 64, 4>(a, stream);
   }
   if (tile == 1) return launch<float, 128, 128, 3>(a, stream);
   if (tile == 2) return launch<float, 128, 64, 3>(a, stream);
