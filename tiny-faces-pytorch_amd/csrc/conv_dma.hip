@@ -186,6 +186,17 @@ __global__ void __launch_bounds__(256) conv_dma_kernel(const DmaK a) {
   const int wave = tid >> 6, wm = wave & 1, wn = wave >> 1;
 
   const int nst = a.nstages;
+  if constexpr (NS == 1) {
+    // no ring: one 16 KiB stage buffer (the epilogue staging tile is larger), eight blocks per CU hide each other's
+    // load latency -- for the 1-4 stage convs whose time is dispatch + prologue + epilogue
+    for (int st = 0; st < nst; ++st) {
+      if (st) __builtin_amdgcn_s_barrier();         // everyone finished reading the previous stage
+      issue();
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      MmaD<T>::template stage<NF, MF>(smem, smem + XBYTES, wm * WM, wn * WN, acc);
+    }
+  } else {
 #pragma unroll
   for (int j = 0; j < NS - 1; ++j)
     if (j < nst && !(a.dbg & 8)) issue();
@@ -201,6 +212,7 @@ __global__ void __launch_bounds__(256) conv_dma_kernel(const DmaK a) {
     const char* xs = smem + cs * BUF;
     if (!(a.dbg & 2)) MmaD<T>::template stage<NF, MF>(xs, xs + XBYTES, wm * WM, wn * WN, acc);
     if (++cs == NS) cs = 0;
+  }
   }
   __builtin_amdgcn_s_barrier();                     // all waves done reading the ring -> reuse it as the staging tile
   if (a.dbg & 4) { if (acc[0][0][0] == 123.456f) a.y[0] = 1; return; }
@@ -384,6 +396,9 @@ int tf_conv_dma_launch(const tf_conv_args* a, int tile, int depth, hipStream_t s
       // overlap.  A/B on one box, img/s: 956 (3-deep everywhere), 989 (<= 4 stages), 996 (<= 8), 1008 (<= 16), 1001 (all).
       static const int ns2_max = [] { const char* e = getenv("TINYFACES_NS2_MAXSTAGES"); return e ? atoi(e) : 16; }();
       const int nst = a->KH * a->KW * (a->Cin / 64);
+      // ... and no ring at all up to 4 stages (17 KiB of LDS, 8 blocks/CU): 1007 -> 1013 img/s
+      static const int ns1_max = [] { const char* e = getenv("TINYFACES_NS1_MAXSTAGES"); return e ? atoi(e) : 4; }();
+      if (nst <= ns1_max) return launch<tf::bf16_t, 64, 64, 1>(a, stream);
       if (nst <= ns2_max) return launch<tf::bf16_t, 64, 64, 2>(a, stream);
       return launch<tf::bf16_t, 64, 64, 3>(a, stream);
     }

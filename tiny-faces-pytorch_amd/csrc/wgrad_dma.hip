@@ -5,6 +5,7 @@
 // linear [pixel][8 x 16 B]; the 16-byte slots are XOR-swizzled by ((row>>1)&3)<<1 ON THE SOURCE so that the
 // ds_read_b64_tr_b16 transposing reads of the two 16-lane groups served per LDS cycle (8 pixel rows x 32 bytes) cover all
 // 64 banks exactly once.  No producer-BN prologue: the executor hands materialised activations.
+#include <cstdlib>
 #include "common.h"
 #include "profile.h"
 
@@ -173,7 +174,8 @@ int tf_wgrad_dma_launch(const tf_wgrad_args* A, hipStream_t stream) {
   const int ntaps = A->KH * A->KW, tiles = k.nco * k.nci * ntaps;
   int sk = A->splitk;
   if (sk <= 0) {
-    sk = (512 + tiles - 1) / tiles;                         // ~512 blocks measured best (scripts/microbench.py wgrad)
+    static const int target = [] { const char* e = getenv("TINYFACES_WGRAD_BLOCKS"); return e ? atoi(e) : 512; }();
+    sk = (target + tiles - 1) / tiles;                      // ~512 blocks measured best (scripts/microbench.py wgrad)
     const int maxsk = (k.M + 4 * PK - 1) / (4 * PK);
     if (sk > maxsk) sk = maxsk;
     if (sk < 1) sk = 1;
