@@ -607,7 +607,15 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
   static std::vector<hipEvent_t> g_events;
   static const bool g_single_env = getenv("TINYFACES_SINGLE_STREAM") != nullptr;
   if (!g_single_env && !g_force_single) {
-    if (!g_side && hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) != hipSuccess) g_side = nullptr;
+    if (!g_side) {
+      // the weight gradients are off the critical chain: lowest priority, so the data-gradient chain's workgroups are placed first
+      int least = 0, greatest = 0;
+      static const bool flat_prio = getenv("TINYFACES_SIDE_PRIO_DEFAULT") != nullptr;      // A/B knob
+      if (flat_prio || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess ||
+          hipStreamCreateWithPriority(&g_side, hipStreamNonBlocking, least) != hipSuccess) {
+        if (hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) != hipSuccess) g_side = nullptr;
+      }
+    }
     c.side = g_side; c.events = &g_events;
   }
   tf_conv_args a;
