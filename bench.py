@@ -35,7 +35,7 @@ PROFILE_EVERY = 11                                    # roofline timing: HIP eve
 KIND_NAMES = {0: "conv_igemm<f32,128x128>", 1: "conv_igemm<f32,128x64>", 2: "conv_igemm<f32,64x64>",
               3: "conv_igemm<bf16,128x128>", 4: "conv_igemm<bf16,128x64>", 5: "conv_igemm<bf16,64x64>",
               8: "wgrad<f32,64>", 9: "wgrad<f32,128>", 10: "wgrad<bf16,64>", 11: "wgrad<bf16,128>",
-              12: "conv_dma<f32,64x64x3>", 13: "conv_dma<bf16,64x64x3>", 14: "wgrad_dma<bf16,64x64x3>"}
+              12: "conv_dma<f32,64x64>", 13: "conv_dma<bf16,64x64>", 14: "wgrad_dma<bf16,64x64x3>"}      # conv_dma: ring depth 1/2/3 by K (csrc/conv_dma.hip)
 
 
 def tame_init_(model, seed=0):
@@ -101,7 +101,7 @@ def cpu_baseline(bs=1, steps=1):
 
 
 PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01e_pmc_traffic.json")
-PMC_PATTERNS = {13: "conv_dma_kernel<tf::bf16_t, 64, 64, 3", 12: "conv_dma_kernel<float, 64, 64, 4", 14: "wgrad_dma_kernel"}
+PMC_PATTERNS = {13: "conv_dma_kernel<tf::bf16_t, 64, 64,", 12: "conv_dma_kernel<float, 64, 64,", 14: "wgrad_dma_kernel"}
 
 
 def pmc_traffic(kind):
