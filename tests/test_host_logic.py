@@ -57,3 +57,33 @@ def test_transforms_match_oracle_restatement():
     tf1 = transforms.Compose([transforms.ToTensor(), transforms.Normalize([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])])
     tf2 = refstub.Compose([refstub.ToTensor(), refstub.Normalize([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])])
     assert torch.equal(tf1(a), tf2(b))
+
+
+def test_engine_bucket_ranges_partition_the_flat_gradient():
+    """TrainEngine.bucket_ranges (data-parallel overlap): the four buckets tile the flat gradient buffer exactly, follow the
+    backward order (heads + late layer3 first, stem last) and every parameter lies inside exactly one bucket."""
+    import torch
+    from tinyfaces.engine import TrainEngine
+    from tinyfaces.models.model import DetectionModel
+    m = DetectionModel(num_templates=25)
+    flat = m.flatten_parameters()
+    seg = m._segments
+    ranges = TrainEngine.bucket_ranges(seg, flat.numel())
+    assert [r[0] for r in ranges] == [22, 14, 7, -1]
+    assert ranges[0][2] == flat.numel() and ranges[-1][1] == 0
+    for (_, s0, e0), (_, s1, e1) in zip(ranges, ranges[1:]):
+        assert e1 == s0 and s1 < e1                              # contiguous, descending, non-empty
+    def bucket_of(name):
+        o, n = seg[name]
+        hit = [k for k, (_, s, e) in enumerate(ranges) if s <= o and o + n <= e]
+        assert len(hit) == 1, name
+        return hit[0]
+    assert bucket_of("score_res3.weight") == 0 and bucket_of("score_res4.bias") == 0 and bucket_of("score4_upsample.weight") == 0
+    assert bucket_of("model.layer3.22.conv3.weight") == 0 and bucket_of("model.layer3.15.conv1.weight") == 0
+    assert bucket_of("model.layer3.14.bn3.bias") == 1 and bucket_of("model.layer3.7.conv1.weight") == 1
+    assert bucket_of("model.layer3.6.conv3.weight") == 2 and bucket_of("model.layer3.0.downsample.0.weight") == 2
+    assert bucket_of("model.layer2.3.conv3.weight") == 3 and bucket_of("model.conv1.weight") == 3 and bucket_of("model.layer1.0.conv1.weight") == 3
+    for name in seg:
+        bucket_of(name)
+    sizes = [(e - s) * 4 / 2**20 for _, s, e in ranges]
+    assert all(20 < x < 45 for x in sizes[:3]) and sizes[3] < 10, sizes      # three ~35 MB messages + a small tail

@@ -41,15 +41,23 @@ class TrainEngine:
     # first bottleneck (executor index: layer1 0-2, layer2 3-6, layer3 7-29) of each bucket, in backward order
     _BUCKET_FIRST_BLOCK = (22, 14, 7)
 
-    def _setup_overlap(self):
+    @staticmethod
+    def bucket_ranges(segments, total, first_blocks=_BUCKET_FIRST_BLOCK):
+        """[(event block, start, end)] in backward order: bucket k covers the flat-gradient elements of every bottleneck
+        >= first_blocks[k] not covered by an earlier bucket (plus the heads for k = 0); the last bucket (block -1 = "end
+        of the backward pass") takes the rest (layer1, layer2, stem).  `segments` = DetectionModel._segments
+        ({state_dict key: (offset, numel)} in executor order)."""
         names = [f"model.{l}.{i}." for l, n in (("layer1", 3), ("layer2", 4), ("layer3", 23)) for i in range(n)]
-        seg = self.model._segments
-        ranges, end = [], self.flat_p.numel()
-        for b in self._BUCKET_FIRST_BLOCK:
-            start = min(o for k, (o, _) in seg.items() if k.startswith(names[b]))
+        ranges, end = [], total
+        for b in first_blocks:
+            start = min(o for k, (o, _) in segments.items() if k.startswith(names[b]))
             ranges.append((b, start, end))
             end = start
-        ranges.append((-1, 0, end))                       # layer1, layer2, stem: ready at the very end
+        ranges.append((-1, 0, end))
+        return ranges
+
+    def _setup_overlap(self):
+        ranges = self.bucket_ranges(self.model._segments, self.flat_p.numel())
         events = []
         for _ in ranges:
             ev = torch.cuda.Event()
