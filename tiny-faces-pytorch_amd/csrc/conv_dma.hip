@@ -94,8 +94,12 @@ __device__ __forceinline__ void dma16(const void* gsrc, void* lds_wave_base) {
 
 // KIND: 1 = pointwise GEMM (1x1, stride 1, pad 0: forward or data-gradient, no per-stage address logic at all),
 //       0 = generic forward gather, 2 = generic transposed gather (data gradient of a KxK / strided conv)
+// waves-per-EU 5: 92-96 VGPRs, accumulators in VGPRs, no spills (the default allocation is 90 + 16..24 AGPRs = 4 waves, which
+// caps the 2-deep / ring-less variants at 4 blocks per CU).  Measured on one box: 4 and 5 waves tie (1034 img/s), 6 waves
+// spill 32-92 bytes and lose 8 %; a software-pipelined fragment loop (reads of stage s+1 under the MFMAs of stage s) added
+// +0.2 % -- at 4-5 blocks per CU the other blocks already cover a wave's LDS latency, so the simple stage() stays.
 template <typename T, int BM, int BN, int NS, int KIND>
-__global__ void __launch_bounds__(256) conv_dma_kernel(const DmaK a) {
+__global__ void __launch_bounds__(256, 5) conv_dma_kernel(const DmaK a) {
   constexpr int KCH = MmaD<T>::KCH;
   constexpr int EPS = tf::Elem<T>::kPer16B;
   constexpr int XR = BM / 32, WR = BN / 32;
