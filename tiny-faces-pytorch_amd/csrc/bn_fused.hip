@@ -9,6 +9,9 @@
 // streaming its rows; the blocks with blockIdx.x == 0 also publish what later kernels need (scale/shift/mean/invstd +
 // running statistics forward, dgamma/dbeta backward).  Regions are zeroed once per pass.
 // Reference semantics: torch.nn.BatchNorm2d in training mode (torchvision resnet101 as used by model.py:17-23).
+#include <algorithm>
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -233,7 +236,8 @@ inline dim3 fused_grid(int64_t M, int C, int dtype) {
   const int rpp = 256 / (cs / eps);
   const int slices = C / cs;
   int64_t gx = (M + rpp - 1) / rpp;
-  const int64_t cap = 2048 / slices;                 // ~2k blocks: enough loads in flight, bounded coefficient re-derivation
+  static const int total_cap = [] { const char* e = getenv("TINYFACES_EW_BLOCKS"); return e ? atoi(e) : 2048; }();
+  const int64_t cap = std::max(1, total_cap / slices);   // ~2k blocks: enough loads in flight, bounded coefficient re-derivation
   if (gx > cap) gx = cap;
   if (gx < 1) gx = 1;
   return dim3((unsigned)gx, (unsigned)slices);
