@@ -306,6 +306,26 @@ int tf_detnet_backward(int dtype, const float* x_nchw, int N, int H, int W, int 
                        void* grad_flat, size_t grad_flat_bytes,
                        void* ws, size_t ws_bytes, void* stream);
 
+/* ---- image preparation in front of the detector -----------------------------------
+ * One pass from the decoded uint8 RGB image to the normalised fp32 CHW tensor: PIL BILINEAR resize (bit-exact with Pillow's
+ * 8-bit two-pass resample; tinyfaces/datasets/wider_face.py:136-146 and tinyfaces/evaluation.py:46 through
+ * torchvision.transforms.functional.resize), crop + paste on the mean colour (tinyfaces/datasets/processor.py:41-76),
+ * horizontal flip (tinyfaces/datasets/wider_face.py:155-157), ToTensor + Normalize (main.py:44-46).  Only the pixels of the
+ * window are resampled.  Training: OH = OW = 500; evaluation: crop = the whole resized image, paste (0,0), OH x OW = RH x RW. */
+typedef struct tf_image_prepare_args {
+  const unsigned char* img;              /* device, [H][W][3] uint8 */
+  int H, W;                              /* decoded size */
+  int RH, RW;                            /* size after the resize (== H, W: no resize) */
+  int crop_y, crop_x, crop_h, crop_w;    /* window of the RESIZED image */
+  int paste_y, paste_x;                  /* top-left corner of the window in the output */
+  int flip;                              /* 1: the finished buffer is mirrored (np.fliplr) */
+  int OH, OW;                            /* output size */
+  float mean[3], std[3];                 /* Normalize */
+  unsigned char bg[3];                   /* colour outside the window: (mean * 255) truncated = 123, 116, 103 */
+  float* out;                            /* device, fp32 [3][OH][OW] */
+} tf_image_prepare_args;
+int tf_image_prepare(const tf_image_prepare_args* a, void* stream);
+
 /* ---- measurement hooks (bench.py `roofline`) ------------------------------------------
  * While enabled, every MFMA kernel launch (conv_igemm / wgrad) is bracketed by HIP events on
  * the stream it is launched on.  tf_profile_collect blocks until they completed and writes

@@ -281,8 +281,47 @@ def gen_trainer(out):
     out["param_checksum"] = np.array(float(sum(v.double().sum() for k, v in sd.items() if v.is_floating_point())))
 
 
+def synth_image(seed, H, W):
+    """Smooth + noisy uint8 RGB test image (compresses well, still exercises every resample tap); regenerated by the tests
+    from (seed, H, W) so the fixture stores only the reference's OUTPUTS."""
+    rng = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:H, 0:W]
+    img = np.stack([127 + 110 * np.sin(xx / (9.0 + c) + c) * np.cos(yy / (6.0 + 2 * c)) for c in range(3)], 2)
+    img = img + rng.randint(-2, 3, (H, W, 3))
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def gen_augment(out):
+    """WIDERFace.process_inputs (tinyfaces/datasets/wider_face.py:133-192) + DataProcessor.crop_image
+    (tinyfaces/datasets/processor.py:41-112) of the reference, PIL behind the torchvision resize stub.
+    Also a direct PIL resize vector for the eval pyramid (tinyfaces/evaluation.py:46)."""
+    from PIL import Image
+    from tinyfaces.datasets.wider_face import WIDERFace
+    templates = load_templates()
+    proc = DataProcessor((500, 500), (63, 63), 0.7, 0.3, templates, rf=RF)
+    ds = object.__new__(WIDERFace)                       # no dataset on disk: only the fields process_inputs reads
+    ds.processor, ds.input_size, ds.debug, ds.templates = proc, (500, 500), False, templates
+    cases = [(3, 700, 900), (4, 300, 400), (7, 1024, 768), (9, 520, 480), (12, 260, 1200), (21, 499, 501)]
+    out["cases"] = np.array(cases, dtype=np.int64)
+    for n, (seed, H, W) in enumerate(cases):
+        img = synth_image(seed, H, W)
+        rng = np.random.RandomState(100 + seed)
+        boxes = random_boxes(rng, 12, size=max(H, W))
+        out[f"a{n}_boxes_in"] = boxes
+        np.random.seed(1000 + seed)
+        res_img, cm, rm, bb = ds.process_inputs(Image.fromarray(img, "RGB"), boxes.copy())
+        out[f"a{n}_img"] = res_img
+        out[f"a{n}_boxes"] = np.asarray(bb, dtype=np.float64).reshape(-1, 4)
+        out[f"a{n}_pos"] = np.int64((cm == 1).sum())      # a checksum of the maps that follow (same random stream)
+    # evaluation.py:46: transforms.functional.resize(image, int(min_side * scale)) for scales 2^-1 .. 2^1 of a 180x240 image
+    img = synth_image(5, 180, 240)
+    for k, s in enumerate((0.5, 2)):
+        r = refstub.resize(Image.fromarray(img, "RGB"), int(180 * s))
+        out[f"r{k}_img"] = np.array(r)
+
+
 GENERATORS = {"targets": gen_targets, "decode": gen_decode, "criterion": gen_criterion, "nms": gen_nms,
-              "model": gen_model, "detections": gen_detections, "trainer": gen_trainer}
+              "model": gen_model, "detections": gen_detections, "trainer": gen_trainer, "augment": gen_augment}
 
 
 def main():

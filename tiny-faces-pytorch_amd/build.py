@@ -17,7 +17,7 @@ LIB = os.path.join(HERE, "tinyfaces", "libtinyfaces_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # files whose float64 arithmetic must round exactly like numpy's: no FMA contraction
-EXACT = {"targets.hip", "nms.hip", "decode.hip"}
+EXACT = {"targets.hip", "nms.hip", "decode.hip", "augment.hip"}
 
 
 def _deps_mtime():

@@ -23,6 +23,13 @@ class HipLibraryMissing(RuntimeError):
     pass
 
 
+class ImagePrepareArgs(C.Structure):
+    """tf_image_prepare_args (include/tinyfaces_hip.h)."""
+    _fields_ = [("img", vp), ("H", i32), ("W", i32), ("RH", i32), ("RW", i32), ("crop_y", i32), ("crop_x", i32), ("crop_h", i32),
+                ("crop_w", i32), ("paste_y", i32), ("paste_x", i32), ("flip", i32), ("OH", i32), ("OW", i32),
+                ("mean", f32 * 3), ("std", f32 * 3), ("bg", C.c_ubyte * 3), ("out", vp)]
+
+
 class Pack2Job(C.Structure):
     """tf_pack2_job (include/tinyfaces_hip.h)."""
     _fields_ = [("src", vp), ("dst", vp), ("dst_t", vp), ("cout", i32), ("cin", i32), ("taps", i32), ("rows_pad", i32), ("cols_pad", i32),
@@ -74,6 +81,7 @@ _SIGNATURES = {
     "tf_decode_compact": (i32, [vp, i32, i32, i32, vp, i32, vp, vp, f32, f64, i32, i32, i32, i32, vp, vp, i32, vp, sz, vp]),
     "tf_criterion_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "tf_criterion_fwd_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, f32, i32, i32, f32, vp, vp, u64, vp, vp, vp, vp, vp, sz, vp]),
+    "tf_image_prepare": (i32, [C.POINTER(ImagePrepareArgs), vp]),
     "tf_sgd_step": (i32, [vp, vp, vp, i64, f32, f32, f32, f32, vp]),
     "tf_conv_mtiles": (i32, [C.POINTER(ConvArgs)]),
     "tf_conv2d": (i32, [C.POINTER(ConvArgs), vp]),

@@ -202,6 +202,39 @@ def criterion_fwd_bwd(output, class_map, regression_map, n_templates=25, reg_wei
 
 
 # --------------------------------------------------------------------------- SGD
+IMAGE_MEAN, IMAGE_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)        # main.py:44-46
+
+
+def image_prepare(img_u8, resized_hw=None, crop=None, paste=(0, 0), flip=False, out_hw=None, mean=IMAGE_MEAN, std=IMAGE_STD,
+                  out=None):
+    """uint8 (H, W, 3) device image -> normalised float32 (3, OH, OW) device tensor in one HIP pass (tf_image_prepare):
+    PIL-exact BILINEAR resize to `resized_hw`, window `crop` = (y, x, h, w) of the resized image pasted at `paste` = (y, x)
+    on the mean colour, optional mirror, ToTensor + Normalize.  Defaults: no resize, whole image, out_hw = window size
+    (the evaluation pyramid level of tinyfaces/evaluation.py:46-53); training passes the 500x500 crop parameters of
+    tinyfaces/datasets/processor.py:41-76."""
+    require_gpu(img_u8, "image_prepare")
+    if img_u8.dtype != torch.uint8 or img_u8.dim() != 3 or img_u8.shape[2] != 3:
+        raise ValueError("image_prepare: expected a uint8 (H, W, 3) tensor")
+    img_u8 = img_u8.contiguous()
+    H, W = int(img_u8.shape[0]), int(img_u8.shape[1])
+    RH, RW = (H, W) if resized_hw is None else (int(resized_hw[0]), int(resized_hw[1]))
+    cy, cx, ch, cw = (0, 0, RH, RW) if crop is None else [int(v) for v in crop]
+    OH, OW = (ch, cw) if out_hw is None else (int(out_hw[0]), int(out_hw[1]))
+    if out is None:
+        out = torch.empty(3, OH, OW, dtype=torch.float32, device=img_u8.device)
+    a = _hip.ImagePrepareArgs()
+    a.img, a.H, a.W, a.RH, a.RW = ptr(img_u8), H, W, RH, RW
+    a.crop_y, a.crop_x, a.crop_h, a.crop_w = cy, cx, ch, cw
+    a.paste_y, a.paste_x, a.flip, a.OH, a.OW = int(paste[0]), int(paste[1]), int(bool(flip)), OH, OW
+    for c in range(3):
+        a.mean[c], a.std[c] = float(mean[c]), float(std[c])
+        a.bg[c] = int(np.int8(np.float64(mean[c]) * 255)) & 0xFF          # processor.py:66-71: (mean * 255).astype(int8)
+    a.out = ptr(out)
+    with torch.cuda.device(img_u8.device):
+        check(lib().tf_image_prepare(C.byref(a), stream()), "tf_image_prepare")
+    return out
+
+
 def sgd_step(param, grad, momentum_buf, lr, momentum, weight_decay, grad_scale=1.0):
     """torch.optim.SGD.step for one flat fp32 segment (main.py:67-70)."""
     require_gpu(param, "sgd_step")
