@@ -155,6 +155,26 @@ def test_get_detections_vs_reference_golden(golden, models):
         assert np.allclose(dets[:, :4], ref, rtol=1e-3, atol=2e-2)
 
 
+def test_get_detections_pyramid_on_gpu_is_identical(golden, models):
+    """the pyramid levels built on the device (tf_image_prepare) are bit-identical to PIL + ToTensor + Normalize
+    on the host, so the detections are exactly the same rows; a transform the fast path cannot mirror is refused loudly."""
+    from tinyfaces import transforms
+    from tinyfaces.evaluation import get_detections
+    from oracle.targets import RF
+    m, _ = models
+    g = golden("detections")
+    templates = golden("targets")["templates"]
+    tf = transforms.Compose([transforms.ToTensor(), transforms.Normalize([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])])
+    m.set_compute_dtype(torch.bfloat16)
+    kw = dict(prob_thresh=float(g["thr"]), nms_thresh=0.3, scales=tuple(g["scales"].tolist()), device="cuda")
+    a = get_detections(m, torch.from_numpy(g["img"]), templates, RF, tf, **kw)
+    b = get_detections(m, torch.from_numpy(g["img"]), templates, RF, tf, pyramid_on_gpu=True, **kw)
+    report("get_detections_gpu_pyramid", k=a.shape[0], identical=bool(np.array_equal(a, b)))
+    assert a.shape[0] > 0 and np.array_equal(a, b)
+    with pytest.raises(ValueError, match="pyramid_on_gpu"):
+        get_detections(m, torch.from_numpy(g["img"]), templates, RF, lambda im: transforms.ToTensor()(im), pyramid_on_gpu=True, **kw)
+
+
 def test_trainer_two_steps_vs_reference_golden(golden):
     """trainer.train (trainer.py:68-90) with torch.optim.SGD exactly as main.py:67-70 builds it."""
     from tinyfaces import trainer

@@ -21,12 +21,23 @@ def get_model(checkpoint=None, num_templates=25):
     return model
 
 
+def _normalize_of(img_transforms):
+    """(mean, std) when img_transforms is the Compose([ToTensor, Normalize]) of evaluate_model.py:35-37, else None."""
+    ts = getattr(img_transforms, "transforms", None)
+    if ts is not None and len(ts) == 2 and type(ts[0]).__name__ == "ToTensor" and type(ts[1]).__name__ == "Normalize":
+        return tuple(float(v) for v in ts[1].mean), tuple(float(v) for v in ts[1].std)
+    return None
+
+
 def get_detections(model, img, templates, rf, img_transforms, prob_thresh=0.65, nms_thresh=0.3, scales=(-2, -1, 0, 1),
-                   device=None, mask_axis="w", return_candidates=False):
+                   device=None, mask_axis="w", return_candidates=False, pyramid_on_gpu=False):
     """evaluation.py:20-87.  Returns (K,5) float64: the reference's (K,4) rows in the same order
     with the score re-attached as column 4 (defect D2: the reference drops it although
     write_results reads x[4], evaluation.py:111).  mask_axis='w' reproduces defect D1
-    (tinyfaces/models/utils.py:44); 'template' masks the template axis instead."""
+    (tinyfaces/models/utils.py:44); 'template' masks the template axis instead.
+    pyramid_on_gpu=True: the uint8 image goes to the device once and every pyramid level is produced there
+    by tf_image_prepare (Pillow-exact BILINEAR resize + ToTensor + Normalize in one pass) instead of PIL + torch on the host;
+    needs img_transforms = Compose([ToTensor(), Normalize(mean, std)]); same detections bit for bit."""
     device = torch.device(device if device is not None else "cuda")
     if device.type != "cuda":
         raise RuntimeError("get_detections: the detector only runs on MI355X (no CPU fallback)")
@@ -38,12 +49,25 @@ def get_detections(model, img, templates, rf, img_transforms, prob_thresh=0.65, 
     min_side = np.min(image.size)
     t_d = torch.as_tensor(np.asarray(templates), dtype=torch.float64).contiguous().to(device)
 
-    # the resize + normalise of :46-53 is host work: do it for every level first, then keep the GPU busy
     levels = []
-    for scale in scales_list:
-        scaled = transforms.resize(image, int(min_side * scale))
-        x = img_transforms(scaled).unsqueeze(0).float()
-        levels.append((scale, x))
+    if pyramid_on_gpu:
+        ms = _normalize_of(img_transforms)
+        if ms is None:
+            raise ValueError("pyramid_on_gpu needs img_transforms = Compose([ToTensor(), Normalize(mean, std)])")
+        u8 = torch.from_numpy(np.array(image, dtype=np.uint8)).to(device)      # (H, W, 3), the only upload of the image
+        w, h = image.size
+        for scale in scales_list:
+            size = int(min_side * scale)                                       # :46 -> transforms.resize(image, int)
+            short, long = (w, h) if w <= h else (h, w)
+            new_short, new_long = size, int(size * long / short)
+            new_w, new_h = (new_short, new_long) if w <= h else (new_long, new_short)
+            levels.append((scale, ops.image_prepare(u8, resized_hw=(new_h, new_w), mean=ms[0], std=ms[1]).unsqueeze(0)))
+    else:
+        # the resize + normalise of :46-53 is host work: do it for every level first, then keep the GPU busy
+        for scale in scales_list:
+            scaled = transforms.resize(image, int(min_side * scale))
+            x = img_transforms(scaled).unsqueeze(0).float()
+            levels.append((scale, x))
     cap = sum(((x.shape[2] + 7) // 8) * ((x.shape[3] + 7) // 8) for _, x in levels) * nt
     dets = torch.empty(max(cap, 1), 5, dtype=torch.float64, device=device)
     count = torch.zeros(1, dtype=torch.int32, device=device)
