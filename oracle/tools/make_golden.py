@@ -313,6 +313,23 @@ def gen_augment(out):
         out[f"a{n}_img"] = res_img
         out[f"a{n}_boxes"] = np.asarray(bb, dtype=np.float64).reshape(-1, 4)
         out[f"a{n}_pos"] = np.int64((cm == 1).sum())      # a checksum of the maps that follow (same random stream)
+    # WIDERFace.load (wider_face.py:65-121) on a hand-made annotation file: empty image (placeholder line), zero-size boxes,
+    # negative numbers, trailing attributes
+    import tempfile
+    ann = ("0--Parade/a.jpg\n3\n10 20 30 40 0 0 0 0 0 0\n-5 7 0 12 1 0 0 1 0 0\n100.5 50 8 9 2 1 1 0 2 1\n"
+           "1--Handshaking/b.jpg\n0\n0 0 0 0 0 0 0 0 0 0 \n"
+           "2--Demo/c.jpg\n2\n1 1 1 1 0 0 0 0 0 0\n300 200 25 0 0 0 0 0 0 0\n")
+    out["ann_text"] = np.array(ann)
+    with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False) as f:
+        f.write(ann)
+    ds2 = object.__new__(WIDERFace)
+    ds2.split = "train"
+    ds2.load(f.name)
+    os.unlink(f.name)
+    out["ann_paths"] = np.array([d["img_path"] for d in ds2.data])
+    for i, d in enumerate(ds2.data):
+        out[f"ann{i}_bboxes"] = np.asarray(d["bboxes"], dtype=np.float64).reshape(-1, 4)
+        out[f"ann{i}_attrs"] = np.stack([d[k] for k in ("blur", "expression", "illumination", "invalid", "occlusion", "pose")]).astype(np.float64)
     # evaluation.py:46: transforms.functional.resize(image, int(min_side * scale)) for scales 2^-1 .. 2^1 of a 180x240 image
     img = synth_image(5, 180, 240)
     for k, s in enumerate((0.5, 2)):

@@ -81,3 +81,38 @@ def test_image_prepare_rejects_bad_windows_and_cpu():
         ops.image_prepare(img.cuda(), crop=(0, 0, 25, 30))             # window taller than the image
     with pytest.raises(RuntimeError):
         ops.image_prepare(img.cuda(), paste=(5, 0), out_hw=(20, 30))   # pasted window leaves the output
+
+
+def test_wider_dataloader_end_to_end(tmp_path):
+    """get_dataloader on a miniature WIDER tree (datasets/__init__.py:11-52, wider_face.py): decode on the host, augmentation
+    and target assignment on the GPU; a batch has the reference's contract and equals the same steps done by hand."""
+    from types import SimpleNamespace
+    from PIL import Image
+    from tinyfaces import transforms
+    from tinyfaces.datasets import get_dataloader
+    from tinyfaces.datasets import augment as da
+    root = tmp_path / "WIDER_train" / "images" / "0--Parade"
+    root.mkdir(parents=True)
+    ann, imgs = "", {}
+    for k, (H, W) in enumerate([(600, 800), (420, 380), (700, 1000)]):
+        name = f"0--Parade/img{k}.png"
+        arr = synth_image(40 + k, H, W)
+        Image.fromarray(arr, "RGB").save(tmp_path / "WIDER_train" / "images" / name)          # PNG: lossless, decode == arr
+        imgs[name] = arr
+        ann += f"{name}\n2\n{50 + 10 * k} {60 + 5 * k} 120 150 0 0 0 0 0 0\n{200 + k} {180 + k} 40 48 0 0 0 0 0 0\n"
+    ann_file = tmp_path / "train.txt"
+    ann_file.write_text(ann)
+    args = SimpleNamespace(batch_size=3, workers=0, dataset_root=str(tmp_path), debug=False)
+    tf = transforms.Compose([transforms.ToTensor(), transforms.Normalize([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])])
+    loader, templates = get_dataloader(ann_file, args, img_transforms=tf, train=False, split="train")
+    assert len(loader) == 1 and templates.shape == (25, 5)
+    np.random.seed(123)
+    (x, cm, rm), = list(loader)
+    assert x.shape == (3, 3, 500, 500) and x.dtype == torch.float32 and x.is_cuda
+    assert cm.shape == (3, 25, 63, 63) and rm.shape == (3, 100, 63, 63) and cm.is_cuda
+    assert set(torch.unique(cm).tolist()) <= {-1.0, 0.0, 1.0} and int((cm == 1).sum()) > 0
+    # by hand, same np.random stream
+    np.random.seed(123)
+    for i, d in enumerate(loader.dataset.data):
+        xi, _, _, _ = da.process_inputs(torch.from_numpy(imgs[d["img_path"]]).cuda(), d["bboxes"])
+        assert torch.equal(xi, x[i]), i

@@ -87,3 +87,21 @@ def test_engine_bucket_ranges_partition_the_flat_gradient():
         bucket_of(name)
     sizes = [(e - s) * 4 / 2**20 for _, s, e in ranges]
     assert all(20 < x < 45 for x in sizes[:3]) and sizes[3] < 10, sizes      # three ~35 MB messages + a small tail
+
+
+def test_wider_annotation_parser_vs_reference_golden(golden, tmp_path):
+    """tinyfaces.datasets.wider_face.parse_annotations == the reference's WIDERFace.load (wider_face.py:65-121) on an annotation
+    file with an empty image (placeholder line), zero-size boxes, negative numbers and attributes."""
+    from tinyfaces.datasets.wider_face import parse_annotations
+    g = golden("augment")
+    f = tmp_path / "ann.txt"
+    f.write_text(str(g["ann_text"]))
+    data = parse_annotations(f, "train")
+    assert [d["img_path"] for d in data] == g["ann_paths"].tolist()
+    for i, d in enumerate(data):
+        assert d["bboxes"].shape == g[f"ann{i}_bboxes"].shape and np.array_equal(d["bboxes"], g[f"ann{i}_bboxes"])
+        attrs = np.stack([d[k] for k in ("blur", "expression", "illumination", "invalid", "occlusion", "pose")])
+        assert np.array_equal(attrs, g[f"ann{i}_attrs"])
+    test = tmp_path / "test.txt"
+    test.write_text("0--Parade/x.jpg\n1--H/y.jpg\n")
+    assert parse_annotations(test, "test") == [{"img_path": "0--Parade/x.jpg"}, {"img_path": "1--H/y.jpg"}]

@@ -1,7 +1,7 @@
 """Call surface of the reference's tinyfaces/datasets/__init__.py (`get_dataloader`).
 
-Dataset file I/O (WIDER images / annotation parsing, tinyfaces/datasets/wider_face.py:65-239) is
-outside the hot path; what this factory adds is the device-side target assignment: batches are
+`datapath` = a WIDER FACE annotation file -> datasets/wider_face.py (parser + JPEG decode on the host, augmentation and
+target assignment on the GPU); `datapath == "synthetic"` -> seeded crops.  Either way batches are
 (img, class_map, regression_map) exactly as WIDERFace.__getitem__ yields them
 (wider_face.py:219-222), but the two maps are produced by the fused HIP dense_overlap kernel
 instead of the 4-deep Python loop running in DataLoader workers."""
@@ -24,6 +24,31 @@ def get_dataloader(datapath, args, num_templates=25, template_file="templates.js
                             train=train)
         loader = data.DataLoader(ds, batch_size=args.batch_size, shuffle=False, num_workers=0, collate_fn=ds.collate)
         return loader, templates
-    raise NotImplementedError(
-        "WIDER FACE file loading (tinyfaces/datasets/wider_face.py) is not part of the accelerated hot path in this "
-        "round; use datapath='synthetic' or feed TargetAssigner with your own (image, boxes) batches.")
+    # datasets/__init__.py:40-52: the WIDER FACE annotation file + image tree
+    from pathlib import Path
+    from .wider_face import WIDERFace
+    ds = WIDERFace(Path(datapath).expanduser(), templates, split=split, img_transforms=img_transforms,
+                   dataset_root=Path(getattr(args, "dataset_root", "")).expanduser(), debug=getattr(args, "debug", False))
+    # decoding runs in the workers (identity collate there); the device half of a batch -- augmentation + targets -- runs in
+    # this process, where the GPU context lives
+    inner = data.DataLoader(ds, batch_size=args.batch_size, shuffle=train, num_workers=getattr(args, "workers", 0),
+                            collate_fn=_identity)
+    return DeviceCollatingLoader(inner, ds.collate), templates
+
+
+def _identity(samples):
+    return samples
+
+
+class DeviceCollatingLoader:
+    """A DataLoader whose worker processes only decode; `collate` (device work) is applied to each batch in the consumer."""
+
+    def __init__(self, inner, collate):
+        self.inner, self.collate, self.dataset = inner, collate, inner.dataset
+
+    def __len__(self):
+        return len(self.inner)
+
+    def __iter__(self):
+        for samples in self.inner:
+            yield self.collate(samples)

@@ -64,7 +64,8 @@ def crop_decisions(img_h, img_w, bboxes, input_size=(500, 500), neg_thresh=0.3, 
     return (crop_y1, crop_x1, crop_h, crop_w), paste, bboxes
 
 
-def process_inputs(image_u8, bboxes, input_size=(500, 500), neg_thresh=0.3, rng=np.random, out=None):
+def process_inputs(image_u8, bboxes, input_size=(500, 500), neg_thresh=0.3, rng=np.random, out=None, mean=ops.IMAGE_MEAN,
+                   std=ops.IMAGE_STD):
     """WIDERFace.process_inputs up to get_heatmaps, for a decoded uint8 (H, W, 3) image that is already on the device.
     Returns (x float32 (3, ih, iw) device tensor = Normalize(ToTensor(augmented image)), bboxes float64 (G', 4),
     paste_box [x1, y1, x2, y2], flip) -- paste_box / flip are what ops.dense_overlap_targets* take for the padding mask."""
@@ -86,7 +87,8 @@ def process_inputs(image_u8, bboxes, input_size=(500, 500), neg_thresh=0.3, rng=
         lx1, lx2 = np.array(bboxes[:, 0]), np.array(bboxes[:, 2])
         bboxes[:, 0] = input_size[1] - lx2 + 1
         bboxes[:, 2] = input_size[1] - lx1 + 1
-    x = ops.image_prepare(image_u8, resized_hw=(rh, rw), crop=crop, paste=(paste[1], paste[0]), flip=flip, out_hw=input_size, out=out)
+    x = ops.image_prepare(image_u8, resized_hw=(rh, rw), crop=crop, paste=(paste[1], paste[0]), flip=flip, out_hw=input_size, mean=mean,
+                          std=std, out=out)
     return x, bboxes, paste, flip
 
 

@@ -1,0 +1,109 @@
+"""WIDER FACE dataset with the reference's constructor and sample contract (tinyfaces/datasets/wider_face.py:13-239), the image
+work moved to the GPU.
+
+  * `load`                 the annotation text format of wider_face.py:65-121: name / count / count x 10 numbers, a dummy line after
+                           a count of 0, |value|, zero-size boxes dropped, (x, y, w, h) -> (x1, y1, x2, y2) with the MATLAB -1.
+  * `__getitem__` (train)  decodes the JPEG on the host (worker-parallel, like the reference) and returns the RAW uint8 image
+                           + its boxes; everything after the decode happens in `collate` on the device: augmentation
+                           (datasets/augment.py -> tf_image_prepare) and target assignment (tf_dense_overlap_targets), so a
+                           batch is (img (B,3,500,500), class_map (B,25,63,63), regression_map (B,100,63,63)) as
+                           wider_face.py:219-222 + the default collate produce.
+  * val / test             image tensor + path, as wider_face.py:224-239.
+np.random is drawn in the reference's per-sample order (scale, crop x/y, paste x/y, flip); the balance sampling inside the
+target kernel uses the device RNG (documented deviation, see ops.dense_overlap_targets)."""
+from pathlib import Path
+
+import numpy as np
+import torch
+from torch.utils.data import dataset
+
+from .. import ops, transforms
+from . import augment
+
+RF = {"size": [859, 859], "stride": [8, 8], "offset": [-1, -1]}      # wider_face.py:53-55
+
+
+def parse_annotations(path, split="train"):
+    """wider_face.py:65-121 as a function: list of per-image dicts (img_path, bboxes (G,4) f64 x1 y1 x2 y2, blur, expression,
+    illumination, invalid, occlusion, pose)."""
+    if split == "test":
+        return [{"img_path": x.strip()} for x in open(path).readlines()]
+    lines = open(path).readlines()
+    data, idx = [], 0
+    while idx < len(lines):
+        img = lines[idx].strip()
+        idx += 1
+        n = int(lines[idx].strip())
+        idx += 1
+        bboxes = np.empty((n, 10))
+        if n == 0:
+            idx += 1                                          # the all-zero placeholder line
+        else:
+            for b in range(n):
+                bboxes[b, :] = [abs(float(x)) for x in lines[idx].strip().split()]
+                idx += 1
+        bboxes = bboxes[~((bboxes[:, 2] == 0) | (bboxes[:, 3] == 0))]
+        bboxes[:, 2] = bboxes[:, 0] + bboxes[:, 2] - 1
+        bboxes[:, 3] = bboxes[:, 1] + bboxes[:, 3] - 1
+        data.append({"img_path": img, "bboxes": bboxes[:, 0:4], "blur": bboxes[:, 4], "expression": bboxes[:, 5],
+                     "illumination": bboxes[:, 6], "invalid": bboxes[:, 7], "occlusion": bboxes[:, 8], "pose": bboxes[:, 9]})
+    return data
+
+
+class WIDERFace(dataset.Dataset):
+    def __init__(self, path, templates, img_transforms=None, dataset_root="", split="train", input_size=(500, 500),
+                 heatmap_size=(63, 63), pos_thresh=0.7, neg_thresh=0.3, pos_fraction=0.5, debug=False, device="cuda", seed=0):
+        super().__init__()
+        self.split = split
+        self.data = parse_annotations(path, split)
+        print("Dataset loaded")
+        print("{0} samples in the {1} dataset".format(len(self.data), self.split))
+        self.templates = templates
+        self.transforms = img_transforms
+        self.dataset_root = Path(dataset_root)
+        self.input_size, self.heatmap_size = input_size, heatmap_size
+        self.pos_thresh, self.neg_thresh, self.pos_fraction = pos_thresh, neg_thresh, pos_fraction
+        self.rf = RF
+        self.debug = debug
+        self.device = torch.device(device)
+        self._step = int(seed) << 20
+
+    def get_all_bboxes(self):
+        return np.vstack([np.empty((0, 4))] + [d["bboxes"] for d in self.data])
+
+    def __len__(self):
+        return len(self.data)
+
+    def _open(self, datum):
+        from PIL import Image
+        image_path = self.dataset_root / "WIDER_{0}".format(self.split) / "images" / datum["img_path"]
+        return Image.open(image_path).convert("RGB")
+
+    def __getitem__(self, index):
+        datum = self.data[index]
+        image = self._open(datum)
+        if self.split == "train":
+            return np.array(image, dtype=np.uint8), datum["bboxes"]
+        if self.split == "val":
+            return (transforms.to_tensor(image) if self.transforms is not None else image), datum["img_path"]
+        return (self.transforms(image) if self.transforms is not None else image), datum["img_path"]
+
+    def collate(self, samples):
+        """Main-process half of a training batch: upload, augment on the GPU, assign targets on the GPU."""
+        if self.split != "train":
+            return samples[0] if len(samples) == 1 else list(zip(*samples))
+        mean, std = ops.IMAGE_MEAN, ops.IMAGE_STD
+        ts = getattr(self.transforms, "transforms", None)
+        if ts is not None and len(ts) == 2 and type(ts[1]).__name__ == "Normalize":
+            mean, std = tuple(float(v) for v in ts[1].mean), tuple(float(v) for v in ts[1].std)
+        B = len(samples)
+        x = torch.empty(B, 3, *self.input_size, dtype=torch.float32, device=self.device)
+        boxes, pastes, flips = [], [], []
+        for i, (img, bb) in enumerate(samples):
+            u8 = torch.from_numpy(img).to(self.device, non_blocking=True)
+            _, b, paste, flip = augment.process_inputs(u8, bb, self.input_size, self.neg_thresh, out=x[i], mean=mean, std=std)
+            boxes.append(b); pastes.append(paste); flips.append(int(flip))
+        self._step += 1
+        cm, rm = ops.dense_overlap_targets(boxes, self.templates, self.heatmap_size, self.rf, paste_boxes=pastes, flips=flips,
+                                           seed=self._step, pos_thresh=self.pos_thresh, neg_thresh=self.neg_thresh, device=self.device)
+        return x, cm, rm
