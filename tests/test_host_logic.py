@@ -105,3 +105,29 @@ def test_wider_annotation_parser_vs_reference_golden(golden, tmp_path):
     test = tmp_path / "test.txt"
     test.write_text("0--Parade/x.jpg\n1--H/y.jpg\n")
     assert parse_annotations(test, "test") == [{"img_path": "0--Parade/x.jpg"}, {"img_path": "1--H/y.jpg"}]
+
+
+def test_wider_val_and_test_splits_yield_image_and_path(tmp_path):
+    """wider_face.py:224-239: val -> (ToTensor(image), path) without normalisation; test -> (transforms(image), path).  Host only."""
+    from types import SimpleNamespace
+    from PIL import Image
+    import torch
+    from tinyfaces import transforms
+    from tinyfaces.datasets import get_dataloader
+    arr = (np.arange(40 * 50 * 3) % 251).astype(np.uint8).reshape(40, 50, 3)
+    for split in ("val", "test"):
+        d = tmp_path / f"WIDER_{split}" / "images" / "3--Riot"
+        d.mkdir(parents=True)
+        Image.fromarray(arr, "RGB").save(d / "p.png")
+    (tmp_path / "val.txt").write_text("3--Riot/p.png\n1\n4 5 10 12 0 0 0 0 0 0\n")
+    (tmp_path / "test.txt").write_text("3--Riot/p.png\n")
+    tf = transforms.Compose([transforms.ToTensor(), transforms.Normalize([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])])
+    args = SimpleNamespace(batch_size=1, workers=0, dataset_root=str(tmp_path), debug=False)
+    loader, templates = get_dataloader(tmp_path / "val.txt", args, img_transforms=tf, train=False, split="val")
+    (img, path), = list(loader)
+    assert path == "3--Riot/p.png" and img.shape == (3, 40, 50) and img.dtype == torch.float32
+    assert torch.equal(img, torch.from_numpy(arr.transpose(2, 0, 1).copy()).float().div(255))
+    assert loader.dataset.rf == {"size": [859, 859], "stride": [8, 8], "offset": [-1, -1]}
+    loader, _ = get_dataloader(tmp_path / "test.txt", args, img_transforms=tf, train=False, split="test")
+    (img, path), = list(loader)
+    assert path == "3--Riot/p.png" and torch.allclose(img, tf(arr))

@@ -1,11 +1,15 @@
 """Evaluation entry point with the reference's flags (evaluate_model.py:17-31) on the MI355X hot path.
-`dataset == "synthetic"` evaluates seeded random images (no WIDER files needed); results are written in the WIDER
-submission format by write_results exactly like evaluate_model.py:47-68."""
+`dataset` = a WIDER val/test annotation file (+ --dataset-root), as in the reference's `make evaluate`, or `synthetic` for seeded
+random images (no WIDER files needed); results are written in the WIDER submission format by write_results exactly like
+evaluate_model.py:47-68.  The pyramid levels are built on the GPU."""
 import argparse
 
 import torch
 
+from types import SimpleNamespace
+
 from tinyfaces import ops, transforms
+from tinyfaces.datasets import get_dataloader
 from tinyfaces.datasets.templates import load_templates
 from tinyfaces.evaluation import get_detections, get_model, write_results
 
@@ -34,10 +38,17 @@ def main():
     templates = load_templates()
     model = get_model(args.checkpoint, num_templates=templates.shape[0])
     tf = transforms.Compose([transforms.ToTensor(), transforms.Normalize([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])])
-    if args.dataset != "synthetic":
-        raise SystemExit("WIDER FACE file loading is out of scope this round: use `synthetic` or call get_detections on your own images")
-    g = torch.Generator().manual_seed(0)
     model = model.to(device).eval()
+    if args.dataset != "synthetic":
+        largs = SimpleNamespace(batch_size=1, workers=args.workers, dataset_root=args.dataset_root or "", debug=args.debug)
+        loader, templates = get_dataloader(args.dataset, largs, train=False, split=args.split, img_transforms=tf)
+        with torch.no_grad(), model.constant_weights():
+            for img, filename in loader:                      # (3, H, W) float in [0, 1] (val) and its path, wider_face.py:224-239
+                dets = get_detections(model, img, templates, loader.dataset.rf, tf, args.prob_thresh, args.nms_thresh, device=device,
+                                      pyramid_on_gpu=True)
+                write_results(dets, filename, args.split, args.results_dir)
+        return
+    g = torch.Generator().manual_seed(0)
     with torch.no_grad(), model.constant_weights():          # the checkpoint does not change between images: pack the weights once
         for i in range(args.num_images):
             img = torch.rand(3, 480, 640, generator=g)
