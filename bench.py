@@ -170,6 +170,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-eval", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--with-augment", action="store_true",
+                    help="SURVEY 8f.1 in the loop: every step also builds its batch from resident 768x1024 uint8 images "
+                         "(resize x0.5/x1/x2, crop, paste, flip, normalise on the GPU + box bookkeeping on the host)")
     ap.add_argument("--eval-only", action="store_true", help="only the configs[1] pyramid leg (for rocprofv3 runs of the eval path)")
     args = ap.parse_args()
 
@@ -211,7 +214,37 @@ def main():
 
     pool = [synthetic_batch(1000 * s + rank, args.batch, device, t_d) for s in range(4)]
 
+    raw = None
+    if args.with_augment:
+        from tinyfaces.datasets import augment as aug
+        from tinyfaces.datasets.synthetic import random_boxes
+        gi = torch.Generator().manual_seed(7 + rank)
+        raw = [(torch.randint(0, 256, (768, 1024, 3), dtype=torch.uint8, generator=gi).to(device),
+                random_boxes(np.random.RandomState(50 + k + 100 * rank)) * np.array([1024 / 500, 768 / 500] * 2)) for k in range(args.batch)]
+        arng = np.random.RandomState(rank)
+
+    in_stream = torch.cuda.Stream(device=device) if raw is not None else None
+
+    def build_batch(i):
+        """Input pipeline of one step on its OWN stream: its small blocking H2D copies (boxes, offsets) then wait for this
+        stream only, not for the training stream that is still busy with the previous step."""
+        with torch.cuda.stream(in_stream):
+            x = torch.empty(args.batch, 3, 500, 500, device=device)
+            boxes, pastes, flips = [], [], []
+            for k, (u8, bb) in enumerate(raw):
+                _, b2, paste, flip = aug.process_inputs(u8, bb, rng=arng, out=x[k])
+                boxes.append(b2); pastes.append(paste); flips.append(int(flip))
+            cm, rm = ops.dense_overlap_targets(boxes, templates, paste_boxes=pastes, flips=flips, seed=i * world + rank, device=device)
+        return x, cm, rm
+
     def step(i):
+        if raw is not None:               # the real input pipeline of a training step, minus the JPEG decode
+            x, cm, rm = build_batch(i)
+            cur = torch.cuda.current_stream()
+            cur.wait_stream(in_stream)
+            for t in (x, cm, rm):
+                t.record_stream(cur)
+            return eng.step(x, cm, rm)
         b = pool[i % len(pool)]
         cm, rm = ops.dense_overlap_targets_device(b["boxes"], b["offs"], b["total"], t_d, paste_d=b["paste"], seed=i * world + rank)
         return eng.step(b["x"], cm, rm)
@@ -251,7 +284,8 @@ def main():
            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": args.dtype, "data": "synthetic",
            "config": {"workload": "configs[2]: bs=12/GPU synthetic 500x500 crops + random boxes; dense_overlap targets on GPU, "
-                                  "ResNet-101 hybrid-head fwd, criterion, bwd, fused SGD" + (", RCCL grad all-reduce" if world > 1 else ""),
+                                  "ResNet-101 hybrid-head fwd, criterion, bwd, fused SGD" + (", RCCL grad all-reduce" if world > 1 else "") +
+                                  (" + GPU augmentation of 768x1024 uint8 images (8f.1) every step" if args.with_augment else ""),
                       "global_batch": args.batch * world, "image": "500x500", "templates": 25, "parallelism": f"dp{world}",
                       "weights": "random init (tamed kaiming), fp32 master + " + args.dtype + " MFMA operands"},
            "loss": {"cls": round(loss_v[0], 3), "reg": round(loss_v[1], 3)},
