@@ -119,6 +119,38 @@ def pmc_traffic(kind):
         return None
 
 
+EPI_NAMES = [(1, "affine"), (2, "res"), (4, "relu"), (8, "stats"), (16, "mask"), (32, "stats2"), (64, "join"), (128, "mask2"), (256, "stats3")]
+
+
+def write_layer_table(_hip, path, steps, dt):
+    """Per layer shape: launches per step, average launch duration (HIP events around every launch), achieved TFLOP/s and GB/s
+    (algorithmic), and the two roofline times of that shape: flops / 2.5 PFLOP/s and bytes / 6.3 TB/s (achievable HBM)."""
+    rows = (C.c_double * (11 * 256))()
+    n = _hip.lib().tf_profile_shapes(rows, 256)
+    out = []
+    for i in range(n):
+        kind, M, N, K, taps, mode, epi, launches, ms, flops, nbytes = [rows[i * 11 + j] for j in range(11)]
+        us = ms * 1e3 / launches
+        f1, b1 = flops / launches, nbytes / launches
+        t_mfma, t_hbm = f1 / 2.5e15 * 1e6, b1 / 6.3e12 * 1e6
+        out.append({"kernel": KIND_NAMES.get(int(kind), str(int(kind))), "op": ["conv", "dgrad", "wgrad"][int(mode)], "M": int(M), "N": int(N), "K": int(K),
+                    "taps": int(taps), "epilogue": "+".join(nm for bit, nm in EPI_NAMES if int(epi) & bit) or "-",
+                    "launches_per_step": round(launches / steps, 2), "avg_us": round(us, 2), "ms_per_step": round(ms / steps, 3),
+                    "tflops": round(f1 / us / 1e6, 1), "gb_s": round(b1 / us / 1e3, 1), "mfma_bound_us": round(t_mfma, 2), "hbm_bound_us": round(t_hbm, 2),
+                    "x_over_roofline": round(us / max(t_mfma, t_hbm), 1)})
+    out.sort(key=lambda r: -r["ms_per_step"])
+    with open(path, "w") as f:
+        json.dump({"note": "HIP events around every launch (perturbs the step by ~10 %); roofline = max(flops / 2.5 PFLOP/s, algorithmic bytes / 6.3 TB/s)",
+                   "ms_per_step_with_events": round(dt / steps * 1e3, 3), "shapes": out}, f, indent=1)
+    md = os.path.splitext(path)[0] + ".md"
+    with open(md, "w") as f:
+        f.write("| op | M | N | K | taps | epilogue | launches/step | avg us | ms/step | TFLOP/s | GB/s | MFMA-bound us | HBM-bound us | x over roofline |\n")
+        f.write("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|\n")
+        for r in out:
+            f.write("| {op} | {M} | {N} | {K} | {taps} | {epilogue} | {launches_per_step} | {avg_us} | {ms_per_step} | {tflops} | {gb_s} | {mfma_bound_us} | "
+                    "{hbm_bound_us} | {x_over_roofline} |\n".format(**r))
+
+
 def bench_eval(model, templates, device, runs=5):
     """configs[1]: 1280x960 image, 3-scale pyramid (480x640, 960x1280, 1920x2560): forward x3 + decode + one NMS."""
     from tinyfaces import ops
@@ -173,6 +205,9 @@ def main():
     ap.add_argument("--with-augment", action="store_true",
                     help="SURVEY 8f.1 in the loop: every step also builds its batch from resident 768x1024 uint8 images "
                          "(resize x0.5/x1/x2, crop, paste, flip, normalise on the GPU + box bookkeeping on the host)")
+    ap.add_argument("--layer-table", default=None, metavar="PATH",
+                    help="bracket EVERY MFMA launch with HIP events (slows the step by ~10 %%) and write the per-layer-shape roofline "
+                         "table (JSON + markdown next to it) instead of sampling 1 launch in 11")
     ap.add_argument("--eval-only", action="store_true", help="only the configs[1] pyramid leg (for rocprofv3 runs of the eval path)")
     args = ap.parse_args()
 
@@ -255,7 +290,7 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     if not args.no_profile:
-        _hip.lib().tf_profile_enable(PROFILE_EVERY)     # HIP events around 1 MFMA launch in PROFILE_EVERY (an event pair costs ~5 us of stream time)
+        _hip.lib().tf_profile_enable(1 if args.layer_table else PROFILE_EVERY)     # HIP events around 1 MFMA launch in PROFILE_EVERY (an event pair costs ~5 us of stream time)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -278,6 +313,8 @@ def main():
             for i in range(n)]
     if rank != 0:
         return
+    if args.layer_table:
+        write_layer_table(_hip, args.layer_table, args.steps, dt)
     ms_per_step = dt / args.steps * 1e3
     value = args.batch * world * args.steps / dt
     out = {"metric": "train img/s @ 500x500 bs=12/GPU", "value": round(value, 2), "unit": "img/s", "n_gpus": world, "steps": args.steps,

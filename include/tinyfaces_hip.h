@@ -334,6 +334,9 @@ int tf_image_prepare(const tf_image_prepare_args* a, void* stream);
  * 12/13 = conv_dma f32/bf16, 14 = wgrad_dma bf16. */
 int tf_profile_enable(int every);   /* 0 = off, 1 = bracket every launch, n = every n-th launch (sampling keeps the timed region undisturbed) */
 int tf_profile_collect(double* host_out, int max_rows);
+/* per layer shape, for the records consumed by the LAST tf_profile_collect: rows of 11 doubles
+ * (kind, M pixels, N output channels, K reduction length, taps, mode (0 fwd, 1 dgrad, 2 wgrad), epilogue flags, launches, total_ms, flops, bytes) */
+int tf_profile_shapes(double* host_out, int max_rows);
 /* test hook: raw lane mapping of ds_read_b64_tr_b16 (see tests/test_gpu_small_ops.py) */
 int tf_probe_tr16(unsigned short* out256, void* stream);
 

@@ -371,7 +371,8 @@ int launch_kind(const tf_conv_args* A, hipStream_t stream) {
     if (A->epi & TF_EPI_JOIN) bytes += 2 * M * A->Cout * es;
     if (A->epi & TF_EPI_MASK2) bytes += M * A->Cout * es;
     if (A->epi & TF_EPI_STATS3) bytes += M * A->Cout * es;
-    tf::ProfScope prof(sizeof(T) == 2 ? 13 : 12, 2.0 * M * A->Cout * Kt, bytes, stream);   // 12 = conv_dma f32, 13 = conv_dma bf16
+    tf::ProfScope prof(sizeof(T) == 2 ? 13 : 12, 2.0 * M * A->Cout * Kt, bytes, stream, k.M, A->Cout, k.Ktot, A->KH * A->KW, A->mode,
+                       A->epi);   // 12 = conv_dma f32, 13 = conv_dma bf16
     hipLaunchKernelGGL((conv_dma_kernel<T, BM, BN, NS, KIND>), dim3(mtiles * k.ntiles), dim3(256), lds, stream, k);
   }
   return hipGetLastError() == hipSuccess ? TF_OK : TF_ERR_LAUNCH;

@@ -8,7 +8,9 @@ namespace tf {
 struct ProfScope {
   int slot;
   hipStream_t stream;
-  ProfScope(int kind, double flops, double bytes, hipStream_t s);   // records the start event when profiling is on
+  // shape: optional GEMM view of the launch (M = pixels, N = output channels, K = reduction length, taps, mode, epilogue flags)
+  // so that tf_profile_shapes can aggregate per layer shape, not only per kernel kind
+  ProfScope(int kind, double flops, double bytes, hipStream_t s, int M = 0, int N = 0, int K = 0, int taps = 0, int mode = 0, int epi = 0);
   ~ProfScope();                                                     // records the stop event
 };
 }  // namespace tf

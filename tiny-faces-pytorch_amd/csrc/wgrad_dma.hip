@@ -186,7 +186,8 @@ int tf_wgrad_dma_launch(const tf_wgrad_args* A, hipStream_t stream) {
   const bool pointwise = ntaps == 1 && A->stride == 1 && A->pad == 0 && A->H == A->OH && A->W == A->OW;
   const double Md = k.M;
   tf::ProfScope prof(14, 2.0 * Md * A->Cout * A->Cin * ntaps,
-                     (Md * A->Cout + (double)A->N * A->H * A->W * A->Cin) * 2 + (double)A->Cout * A->Cin * ntaps * 4, stream);
+                     (Md * A->Cout + (double)A->N * A->H * A->W * A->Cin) * 2 + (double)A->Cout * A->Cin * ntaps * 4, stream, k.M, A->Cout,
+                     A->Cin * ntaps, ntaps, 2, 0);
   if (pointwise) hipLaunchKernelGGL(wgrad_dma_kernel<1>, dim3(tiles * k.splitk), dim3(256), lds, stream, k);
   else           hipLaunchKernelGGL(wgrad_dma_kernel<0>, dim3(tiles * k.splitk), dim3(256), lds, stream, k);
   return hipGetLastError() == hipSuccess ? TF_OK : TF_ERR_LAUNCH;

@@ -121,6 +121,7 @@ _SIGNATURES = {
     "tf_set_stat_rows": (i32, [i32]),
     "tf_get_stat_rows": (i32, []),
     "tf_profile_enable": (i32, [i32]),
+    "tf_profile_shapes": (i32, [C.POINTER(C.c_double), i32]),
     "tf_profile_collect": (i32, [C.POINTER(C.c_double), i32]),
 }
 
