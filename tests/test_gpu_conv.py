@@ -34,7 +34,7 @@ CONV_CASES = [
 
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("case", CONV_CASES)
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 11, 12, 13, 22, 23])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 11, 12, 13, 22, 23, 32])
 def test_conv_forward_plain(dtype, case, tile):
     from tinyfaces import ops
     N, H, W, Cin, Cout, K, s, p = case
@@ -92,7 +92,7 @@ def test_conv_forward_prologue_and_stats(dtype, K, s):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("tile", [0, 11, 12, 13])
+@pytest.mark.parametrize("tile", [0, 11, 12, 13, 32])
 def test_conv_forward_stats_no_prologue(dtype, tile):
     """raw output + (sum, sumsq) partials without a prologue -> the LDS-DMA kernel's column-sum epilogue."""
     from tinyfaces import _hip, ops

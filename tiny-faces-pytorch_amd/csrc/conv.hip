@@ -20,6 +20,7 @@
 //     the same 16-byte LDS reads serve it; it is the 1e-3 parity path, bf16 is the fast path.
 //   * blockIdx is remapped so that each XCD (private L2) owns a contiguous range of tiles:
 //     the channel tiles that re-read one pixel tile stay on one L2.
+#include <cstdlib>
 #include "common.h"
 #include "profile.h"
 
@@ -349,14 +350,22 @@ int launch_conv(const tf_conv_args* A, hipStream_t stream) {
 }
 
 // tile codes: 1/2/3 = register-staged 128x128 / 128x64 / 64x64 (pixels x channels); 11/12/13 = LDS-DMA pipeline with a
-// 3-deep ring, 21/22/23 = 4-deep ring.  0 = auto.
+// 3-deep ring (13: the ring depth then follows K, see tf_conv_dma_launch), 21/22/23 = 4-deep ring, 32 = ring-less 128x64.  0 = auto.
 int pick_tile(const tf_conv_args* a) {
   if (a->tile) return a->tile;
   // measured on the bs=12 500x500 layer shapes (scripts/microbench.py): 128 pixels x 64 channels wins on every
   // layer (more, smaller tiles -> more blocks in flight per CU); 64x64 only when even that leaves CUs idle.
   const long M = (long)a->N * a->OH * a->OW;
   const long t2 = ((M + 127) / 128) * ((a->Cout + 63) / 64);
-  if (!a->pro_scale) return 13;                   // LDS-DMA pipeline, 64x64 tiles, 3-deep ring: fastest on every layer shape
+  if (!a->pro_scale) {
+    // LDS-DMA pipeline.  bf16 convs of <= 4 K-stages (K <= 256 pointwise) are dispatch + epilogue bound: 128-pixel tiles without a
+    // ring halve their block count at the same 4 blocks per CU (+0.6 % on the step, A/B on one box: 1036.6 -> 1043.3 img/s);
+    // everything else 64x64 with the ring depth chosen by K.  The choice lives HERE so that tf_conv_mtiles agrees with the launch.
+    static const bool t12_off = getenv("TINYFACES_T12_SHORTK_OFF") != nullptr;
+    const int nst = a->KH * a->KW * (a->Cin / 64);
+    if (!t12_off && a->dtype == TF_BF16 && nst <= 4) return 32;
+    return 13;
+  }
   return t2 >= 256 ? 2 : 3;                       // producer-BN prologue needs the register-staged kernel
 }
 int tile_bm(int t) { return (t % 10) == 3 ? 64 : 128; }
@@ -394,7 +403,7 @@ extern "C" int tf_conv2d(const tf_conv_args* a, void* stream_) {
   const int t = pick_tile(a);
   if (t >= 10) {
     if (a->pro_scale) return TF_ERR_UNSUPPORTED;
-    return tf_conv_dma_launch(a, t % 10, t >= 20 ? 4 : 3, stream);
+    return tf_conv_dma_launch(a, t % 10, t >= 30 ? 1 : (t >= 20 ? 4 : 3), stream);
   }
   if (a->epi & (TF_EPI_MASK2 | TF_EPI_STATS3)) return TF_ERR_UNSUPPORTED;      // only the LDS-DMA kernel implements them
   if (a->dtype == TF_BF16) {

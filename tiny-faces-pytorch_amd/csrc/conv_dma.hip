@@ -387,14 +387,17 @@ int launch(const tf_conv_args* A, hipStream_t stream) {
 
 }  // namespace
 
-// tile: 1 = 128x128, 2 = 128x64, 3 = 64x64 (pixels x channels); depth: ring stages (3 or 4)
+// tile: 1 = 128x128, 2 = 128x64, 3 = 64x64 (pixels x channels); depth: ring stages (3 or 4; 1 = ring-less 128x64)
 int tf_conv_dma_launch(const tf_conv_args* a, int tile, int depth, hipStream_t stream) {
   // (64x128, 64x256, 128x128x4 and 128x256 tiles were measured and lost to 64x64x3 on every layer shape:
   //  profiles/r01c_microbench_wide_tiles.txt; they were removed again.)
   if (tile > 3) return TF_ERR_UNSUPPORTED;
   if (a->dtype == TF_BF16) {
     if (tile == 1) return launch<tf::bf16_t, 128, 128, 3>(a, stream);
-    if (tile == 2) return depth == 4 ? launch<tf::bf16_t, 128, 64, 4>(a, stream) : launch<tf::bf16_t, 128, 64, 3>(a, stream);
+    if (tile == 2) {
+      if (depth == 1) return launch<tf::bf16_t, 128, 64, 1>(a, stream);       // tile code 32: ring-less, short K (see pick_tile)
+      return depth == 4 ? launch<tf::bf16_t, 128, 64, 4>(a, stream) : launch<tf::bf16_t, 128, 64, 3>(a, stream);
+    }
     if (depth == 3) {
       // convs of up to 16 K-stages (every 1x1 of the trunk, K <= 1024) are dispatch + prologue + epilogue bound rather than
       // K-loop bound: a 2-deep ring is 32 KiB of LDS, so five blocks fit a CU instead of three and more of those phases
