@@ -131,3 +131,78 @@ def test_wider_val_and_test_splits_yield_image_and_path(tmp_path):
     loader, _ = get_dataloader(tmp_path / "test.txt", args, img_transforms=tf, train=False, split="test")
     (img, path), = list(loader)
     assert path == "3--Riot/p.png" and torch.allclose(img, tf(arr))
+
+
+def _wider_case(rng, n_img=6):
+    gt, keep, preds = {"ev": {}}, {"ev": {}}, {"ev": {}}
+    for k in range(n_img):
+        G = rng.randint(0, 6)
+        xy = rng.uniform(0, 300, (G, 2)); wh = rng.uniform(10, 80, (G, 2))
+        g = np.column_stack([xy, wh])
+        kp = np.nonzero(rng.rand(G) > 0.3)[0]
+        N = rng.randint(0, 9)
+        rows = []
+        for _ in range(N):
+            if G and rng.rand() < 0.6:                        # a jittered copy of a ground-truth box
+                b = g[rng.randint(G)] + rng.uniform(-6, 6, 4)
+            else:
+                b = np.concatenate([rng.uniform(0, 300, 2), rng.uniform(10, 80, 2)])
+            rows.append(np.concatenate([b, [rng.rand()]]))
+        p = np.array(rows).reshape(-1, 5)
+        p = p[np.argsort(-p[:, 4], kind="stable")]
+        gt["ev"][f"i{k}"], keep["ev"][f"i{k}"], preds["ev"][f"i{k}"] = g, kp, p
+    return preds, gt, keep
+
+
+def test_wider_evaluator_hand_cases_and_bruteforce():
+    """tinyfaces.wider_eval (the MATLAB eval_tools protocol, parity unpinned): exact on hand-computable cases and equal to a
+    brute-force per-threshold re-derivation (thresholded detection sets evaluated from scratch) on random cases."""
+    from tinyfaces import wider_eval as we
+    # one image, two kept faces, perfect detections -> AP 1; one missed -> AP 0.5; ignored face never hurts precision
+    gt = {"e": {"a": np.array([[10, 10, 20, 20], [100, 100, 30, 30.0]])}}
+    keep = {"e": {"a": np.array([0, 1])}}
+    perfect = {"e": {"a": np.array([[10, 10, 20, 20, 1.0], [100, 100, 30, 30, 0.5]])}}
+    assert abs(we.evaluate_setting(we.norm_scores(perfect), gt, keep)[0] - 1.0) < 1e-12
+    half = {"e": {"a": np.array([[10, 10, 20, 20, 1.0], [300, 300, 30, 30, 0.5]])}}
+    ap_half = we.evaluate_setting(we.norm_scores(half), gt, keep)[0]
+    assert abs(ap_half - 0.5) < 1e-12
+    keep_one = {"e": {"a": np.array([0])}}                   # second face ignored: its detection is dropped, not a false positive
+    assert abs(we.evaluate_setting(we.norm_scores(perfect), gt, keep_one)[0] - 1.0) < 1e-12
+    assert we.voc_ap(np.array([0.5, 1.0]), np.array([1.0, 0.5])) == 0.75
+
+    def brute(preds, gt, keep, T=we.THRESH_NUM):
+        pr, faces = np.zeros((T, 2)), 0
+        for name, g in gt["ev"].items():
+            faces += len(keep["ev"][name])
+            p = preds["ev"][name]
+            if g.shape[0] == 0 or p.shape[0] == 0:
+                continue
+            mask = np.zeros(g.shape[0], bool); mask[keep["ev"][name]] = True
+            for t in range(T):
+                sel = p[p[:, 4] >= 1 - (t + 1) / T]
+                if sel.shape[0] == 0:
+                    continue
+                pred_recall, proposal = we.image_evaluation(sel, g, mask)       # greedy matching restarted on the thresholded prefix
+                pr[t, 0] += int((proposal == 1).sum()); pr[t, 1] += pred_recall[-1]
+        prec = np.divide(pr[:, 1], pr[:, 0], out=np.zeros(T), where=pr[:, 0] > 0)
+        return we.voc_ap(pr[:, 1] / max(faces, 1), prec)
+
+    rng = np.random.RandomState(0)
+    for _ in range(5):
+        preds, gt2, keep2 = _wider_case(rng)
+        preds = we.norm_scores(preds)
+        ap, curve = we.evaluate_setting(preds, gt2, keep2)
+        assert 0.0 <= ap <= 1.0 and curve.shape == (we.THRESH_NUM, 2)
+        assert np.all(np.diff(curve[:, 1]) >= -1e-12)                           # recall never decreases as the threshold drops
+        assert abs(ap - brute(preds, gt2, keep2)) < 1e-12
+
+
+def test_wider_evaluator_reads_write_results_tree(tmp_path):
+    from tinyfaces import wider_eval as we
+    from tinyfaces.evaluation import write_results
+    dets = np.array([[10.0, 20.0, 29.0, 49.0, 0.25], [5.0, 5.0, 14.0, 14.0, 0.9]])       # x1 y1 x2 y2 score
+    write_results(dets, "0--Parade/0_Parade_x_1.jpg", "val", results_dir=tmp_path)
+    p = we.read_predictions(tmp_path)
+    rows = p["0--Parade"]["0_Parade_x_1"]
+    assert rows.shape == (2, 5) and rows[0, 4] == 0.9 and rows[1, 4] == 0.25          # sorted by score
+    assert rows[0, :4].tolist() == [5.0, 5.0, 10.0, 10.0]                               # x y w h with the +1 of evaluation.py:108-109
