@@ -2,7 +2,7 @@
 result files `write_results` produces (tinyfaces/evaluation.py:90-114) -- the step the reference delegates to the external
 MATLAB/Octave `eval_tools` (Makefile:20-21, README.md:49).
 
-PARITY UNPINNED: eval_tools is third-party MATLAB code that is neither in /root/reference nor runnable here, and the WIDER
+PARITY UNPINNED: eval_tools is third-party MATLAB code that is neither part of the reference repository nor runnable here, and the WIDER
 ground-truth .mat files are not available offline.  This module restates the published protocol (eval_tools: wider_eval.m,
 evaluation.m, image_evaluation / image_pr_info / dataset_pr_info, norm_score.m, boxoverlap.m, VOCap.m):
   * scores min-max normalised over the whole prediction set;
