@@ -14,20 +14,22 @@ from tinyfaces.datasets.templates import load_templates
 from tinyfaces.evaluation import get_detections, get_model, write_results
 
 
-def arguments():
+# the reference's command line (evaluate_model.py:17-31) + one addition for the synthetic data set
+FLAGS = [
+    ("dataset", {}), ("--split", dict(default="val")), ("--dataset-root", {}),
+    ("--checkpoint", dict(default="", help="The path to the model checkpoint")),
+    ("--prob_thresh", dict(type=float, default=0.03)), ("--nms_thresh", dict(type=float, default=0.3)),
+    ("--workers", dict(default=8, type=int)), ("--batch_size", dict(default=1, type=int)),
+    ("--results_dir", dict(default=None)), ("--debug", dict(action="store_true")),
+    ("--num-images", dict(default=4, type=int, help="synthetic dataset only")),
+]
+
+
+def arguments(argv=None):
     parser = argparse.ArgumentParser("Model Evaluator")
-    parser.add_argument("dataset")
-    parser.add_argument("--split", default="val")
-    parser.add_argument("--dataset-root")
-    parser.add_argument("--checkpoint", help="The path to the model checkpoint", default="")
-    parser.add_argument("--prob_thresh", type=float, default=0.03)
-    parser.add_argument("--nms_thresh", type=float, default=0.3)
-    parser.add_argument("--workers", default=8, type=int)
-    parser.add_argument("--batch_size", default=1, type=int)
-    parser.add_argument("--results_dir", default=None)
-    parser.add_argument("--debug", action="store_true")
-    parser.add_argument("--num-images", default=4, type=int, help="synthetic dataset only")
-    return parser.parse_args()
+    for name, kw in FLAGS:
+        parser.add_argument(name, **kw)
+    return parser.parse_args(argv)
 
 
 def main():
@@ -51,7 +53,7 @@ def main():
     g = torch.Generator().manual_seed(0)
     with torch.no_grad(), model.constant_weights():          # the checkpoint does not change between images: pack the weights once
         for i in range(args.num_images):
-            img = torch.rand(3, 480, 640, generator=g)
+            img = torch.rand(3, 960, 1280, generator=g)          # wide enough for the 2^-2 level: the W-axis mask of defect D1 needs W' >= 25
             dets = get_detections(model, img, templates, ops.RF, tf, args.prob_thresh, args.nms_thresh, device=device)
             write_results(dets, f"synthetic/img_{i}.jpg", args.split, args.results_dir)
             print(f"img_{i}: {dets.shape[0]} detections")

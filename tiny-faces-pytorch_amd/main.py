@@ -5,7 +5,8 @@
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 main.py synthetic synthetic   # data parallel
 
 Additions (existing flags keep their names and defaults): --fused / --no-fused (TrainEngine vs torch.optim.SGD through
-autograd), --dtype bf16|fp32, --synthetic-len.  Everything else is main.py:39-104."""
+autograd), --dtype bf16|fp32, --synthetic-len.  The schedule is the reference's: SGD(momentum, weight decay), StepLR(20),
+a checkpoint every --save-every epochs (main.py:39-104)."""
 import argparse
 from pathlib import Path
 
@@ -18,69 +19,81 @@ from tinyfaces.engine import TrainEngine
 from tinyfaces.models.loss import DetectionCriterion
 from tinyfaces.models.model import DetectionModel
 
+NUM_TEMPLATES = 25
+LR_STEP = 20            # StepLR(step_size=20, gamma=0.1), main.py:81-83
 
-def arguments():
+# the reference's command line (name, argparse keyword arguments), then this repo's additions
+REFERENCE_FLAGS = [
+    ("traindata", {}), ("valdata", {}),
+    ("--dataset-root", dict(default="")), ("--dataset", dict(default="WIDERFace")),
+    ("--lr", dict(default=1e-4, type=float)), ("--weight-decay", dict(default=0.0005, type=float)), ("--momentum", dict(default=0.9, type=float)),
+    ("--batch_size", dict(default=12, type=int)), ("--workers", dict(default=8, type=int)),
+    ("--start-epoch", dict(default=0, type=int)), ("--epochs", dict(default=50, type=int)), ("--save-every", dict(default=10, type=int)),
+    ("--resume", dict(default="", help="checkpoint path (the reference declares it store_true but uses it as a path, main.py:33,74)")),
+    ("--debug", dict(action="store_true")),
+]
+EXTRA_FLAGS = [
+    ("--fused", dict(dest="fused", action="store_true", default=True)), ("--no-fused", dict(dest="fused", action="store_false")),
+    ("--dtype", dict(default="bf16", choices=["bf16", "fp32"])), ("--synthetic-len", dict(dest="synthetic_len", default=240, type=int)),
+]
+
+
+def arguments(argv=None):
     parser = argparse.ArgumentParser()
-    parser.add_argument("traindata")
-    parser.add_argument("valdata")
-    parser.add_argument("--dataset-root", default="")
-    parser.add_argument("--dataset", default="WIDERFace")
-    parser.add_argument("--lr", default=1e-4, type=float)
-    parser.add_argument("--weight-decay", default=0.0005, type=float)
-    parser.add_argument("--momentum", default=0.9, type=float)
-    parser.add_argument("--batch_size", default=12, type=int)
-    parser.add_argument("--workers", default=8, type=int)
-    parser.add_argument("--start-epoch", default=0, type=int)
-    parser.add_argument("--epochs", default=50, type=int)
-    parser.add_argument("--save-every", default=10, type=int)
-    parser.add_argument("--resume", default="", help="checkpoint path (the reference declares it store_true but uses it as a path, main.py:33,74)")
-    parser.add_argument("--debug", action="store_true")
-    parser.add_argument("--fused", dest="fused", action="store_true", default=True)
-    parser.add_argument("--no-fused", dest="fused", action="store_false")
-    parser.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    parser.add_argument("--synthetic-len", dest="synthetic_len", default=240, type=int)
-    return parser.parse_args()
+    for name, kw in REFERENCE_FLAGS + EXTRA_FLAGS:
+        parser.add_argument(name, **kw)
+    return parser.parse_args(argv)
+
+
+def lr_at(base_lr, epoch):
+    return base_lr * 0.1 ** (epoch // LR_STEP)
+
+
+def run_fused_epoch(engine, loss_fn, loader, epoch, device, base_lr):
+    engine.set_lr(lr_at(base_lr, epoch))
+    total = len(loader)
+    for idx, batch in enumerate(loader):
+        engine.step(*(t.float().to(device, non_blocking=True) for t in batch))
+        if parallel.rank() == 0:
+            loss_fn.flush_meters()
+            trainer.print_state(idx, epoch, total, loss_fn.class_average.average, loss_fn.reg_average.average)
 
 
 def main():
     args = arguments()
-    parallel.init_from_env()
-    num_templates = 25
-    normalize = transforms.Normalize(mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225])
-    img_transforms = transforms.Compose([transforms.ToTensor(), normalize])
-    train_loader, _ = get_dataloader(args.traindata, args, num_templates, img_transforms=img_transforms)
-    model = DetectionModel(num_objects=1, num_templates=num_templates).set_compute_dtype(args.dtype)
-    loss_fn = DetectionCriterion(num_templates, seed=parallel.rank(), lazy_meters=True)
-    weights_dir = Path("weights")
     if not torch.cuda.is_available():
         raise SystemExit("this build of the tiny-faces hot path runs on MI355X only (no CPU fallback)")
+    parallel.init_from_env()
     device = torch.device("cuda", torch.cuda.current_device())
-    start_epoch = args.start_epoch
+    preprocess = transforms.Compose([transforms.ToTensor(), transforms.Normalize(mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225])])
+    train_loader, _ = get_dataloader(args.traindata, args, NUM_TEMPLATES, img_transforms=preprocess)
+    model = DetectionModel(num_objects=1, num_templates=NUM_TEMPLATES).set_compute_dtype(args.dtype)
+    loss_fn = DetectionCriterion(NUM_TEMPLATES, seed=parallel.rank(), lazy_meters=True)
+
+    first_epoch = args.start_epoch
     if args.resume:
-        ckpt = torch.load(args.resume, map_location="cpu")
-        model.load_state_dict(ckpt["model"])
-        start_epoch = start_epoch or ckpt["epoch"]
+        state = torch.load(args.resume, map_location="cpu")
+        model.load_state_dict(state["model"])
+        first_epoch = first_epoch or state["epoch"]
+
+    engine = optimizer = scheduler = None
     if args.fused:
         engine = TrainEngine(model, loss_fn, lr=args.lr, momentum=args.momentum, weight_decay=args.weight_decay, device=device)
-        optimizer = None
     else:
         optimizer = optim.SGD(model.learnable_parameters(args.lr), lr=args.lr, momentum=args.momentum, weight_decay=args.weight_decay)
-        scheduler = optim.lr_scheduler.StepLR(optimizer, step_size=20, last_epoch=start_epoch - 1)
-    for epoch in range(start_epoch, args.epochs):
-        if args.fused:
-            engine.set_lr(args.lr * (0.1 ** (epoch // 20)))                    # StepLR(step_size=20), main.py:81-83
-            for idx, (img, class_map, regression_map) in enumerate(train_loader):
-                engine.step(img.float().to(device, non_blocking=True), class_map.float().to(device), regression_map.float().to(device))
-                if parallel.rank() == 0:
-                    loss_fn.flush_meters()
-                    trainer.print_state(idx, epoch, len(train_loader), loss_fn.class_average.average, loss_fn.reg_average.average)
+        scheduler = optim.lr_scheduler.StepLR(optimizer, step_size=LR_STEP, last_epoch=first_epoch - 1)
+
+    for epoch in range(first_epoch, args.epochs):
+        if engine is not None:
+            run_fused_epoch(engine, loss_fn, train_loader, epoch, device, args.lr)
         else:
             trainer.train(model, loss_fn, optimizer, train_loader, epoch, device=device)
             scheduler.step()
-        if (epoch + 1) % args.save_every == 0 and parallel.rank() == 0:
-            trainer.save_checkpoint({"epoch": epoch + 1, "batch_size": train_loader.batch_size, "model": model.state_dict(),
-                                     "optimizer": optimizer.state_dict() if optimizer else {}},
-                                    filename="checkpoint_{0}.pth".format(epoch + 1), save_path=weights_dir)
+        done = epoch + 1
+        if done % args.save_every == 0 and parallel.rank() == 0:
+            snapshot = {"epoch": done, "batch_size": getattr(train_loader, "batch_size", args.batch_size), "model": model.state_dict(),
+                        "optimizer": optimizer.state_dict() if optimizer is not None else {}}
+            trainer.save_checkpoint(snapshot, filename=f"checkpoint_{done}.pth", save_path=Path("weights"))
 
 
 if __name__ == "__main__":

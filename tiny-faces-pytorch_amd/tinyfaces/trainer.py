@@ -9,40 +9,43 @@ import torch
 
 from . import parallel
 
+_LOSS_FMT = "\tloss_cls: {:.6f}\tloss_reg: {:.6f}"
+
 
 def print_state(idx, epoch, size, loss_cls, loss_reg):
-    """trainer.py:9-17 (same line format)."""
-    if epoch >= 0:
-        message = "Epoch: [{0}][{1}/{2}]\t".format(epoch, idx, size)
-    else:
-        message = "Val: [{0}/{1}]\t".format(idx, size)
-    print(message + '\tloss_cls: {loss_cls:.6f}' '\tloss_reg: {loss_reg:.6f}'.format(loss_cls=loss_cls, loss_reg=loss_reg))
+    """One progress line in the reference's format (trainer.py:9-17): training lines carry the epoch, validation lines
+    (epoch < 0) do not."""
+    head = f"Epoch: [{epoch}][{idx}/{size}]\t" if epoch >= 0 else f"Val: [{idx}/{size}]\t"
+    print(head + _LOSS_FMT.format(loss_cls, loss_reg))
 
 
 def save_checkpoint(state, filename="checkpoint.pth", save_path="weights"):
-    """trainer.py:20-26."""
-    if not Path(save_path).exists():
-        Path(save_path).mkdir()
-    torch.save(state, str(Path(save_path, filename)))
+    """trainer.py:20-26: `state` goes to <save_path>/<filename>; the directory is created on first use."""
+    target = Path(save_path)
+    target.mkdir(exist_ok=True)
+    torch.save(state, str(target / filename))
+
+
+def _is_logging_rank():
+    return parallel.rank() == 0 or not parallel.is_distributed()
 
 
 def train(model, loss_fn, optimizer, dataloader, epoch, device):
-    """trainer.py:68-90."""
-    model = model.to(device)
-    model.train()
-    reducer = parallel.reducer_for(model)
-    for idx, (img, class_map, regression_map) in enumerate(dataloader):
-        x = img.float().to(device, non_blocking=True)
-        class_map_var = class_map.float().to(device, non_blocking=True)
-        regression_map_var = regression_map.float().to(device, non_blocking=True)
-        output = model(x)
-        loss = loss_fn(output, class_map_var, regression_map_var)
+    """One epoch with the reference's step order (trainer.py:68-90): forward, criterion, zero_grad, backward, [all-reduce],
+    optimizer step, progress line."""
+    net = model.to(device).train()
+    reducer = parallel.reducer_for(net)
+    n_batches = len(dataloader)
+    for step, batch in enumerate(dataloader):
+        image, cls_target, reg_target = (t.float().to(device, non_blocking=True) for t in batch)
+        loss = loss_fn(net(image), cls_target, reg_target)
         optimizer.zero_grad()
         loss.backward()
         if reducer is not None:
             reducer.average_gradients()
         optimizer.step()
-        if not parallel.is_distributed() or parallel.rank() == 0:
-            if hasattr(loss_fn, "flush_meters"):
-                loss_fn.flush_meters()
-            print_state(idx, epoch, len(dataloader), loss_fn.class_average.average, loss_fn.reg_average.average)
+        if _is_logging_rank():
+            flush = getattr(loss_fn, "flush_meters", None)
+            if flush is not None:
+                flush()
+            print_state(step, epoch, n_batches, loss_fn.class_average.average, loss_fn.reg_average.average)
