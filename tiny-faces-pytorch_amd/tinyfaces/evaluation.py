@@ -82,6 +82,9 @@ def get_detections(model, img, templates, rf, img_transforms, prob_thresh=0.65, 
                                prob_thresh, scale, dets, count, rf)
     n = int(count.item())
     assert n <= dets.shape[0]
+    if n > ops.NMS_MAX_BOXES:
+        raise RuntimeError(f"get_detections: {n} candidates above prob_thresh={prob_thresh} exceed the {ops.NMS_MAX_BOXES} boxes one NMS call "
+                           "takes (64 KiB of LDS for the suppression bitmap); a trained detector keeps a few thousand -- untrained weights?")
     cand = dets[:n]
     keep = ops.nms(cand[:, :4].contiguous(), cand[:, 4].contiguous(), nms_thresh)      # :80-84
     result = cand[keep].cpu().numpy()

@@ -202,6 +202,7 @@ def criterion_fwd_bwd(output, class_map, regression_map, n_templates=25, reg_wei
 
 
 # --------------------------------------------------------------------------- SGD
+NMS_MAX_BOXES = 524160                                   # csrc/nms.hip: (n/64 + 2) 8-byte words must fit 64 KiB of LDS
 IMAGE_MEAN, IMAGE_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)        # main.py:44-46
 
 
