@@ -206,3 +206,18 @@ def test_wider_evaluator_reads_write_results_tree(tmp_path):
     rows = p["0--Parade"]["0_Parade_x_1"]
     assert rows.shape == (2, 5) and rows[0, 4] == 0.9 and rows[1, 4] == 0.25          # sorted by score
     assert rows[0, :4].tolist() == [5.0, 5.0, 10.0, 10.0]                               # x y w h with the +1 of evaluation.py:108-109
+
+
+def test_bench_reads_committed_pmc_traffic():
+    """bench.py's roofline.traffic comes from the committed rocprofv3 --pmc passes: the file must parse and give a per-launch byte
+    count of the dominant kernel that is of the order of its algorithmic bytes (tens of MB), never silently zero."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    t = bench.pmc_traffic(13)
+    assert t is not None and 2e7 < t < 3e8
+    assert bench.pmc_traffic(14) is not None                     # wgrad_dma rows exist too
+    assert bench.pmc_traffic(5) is None                          # a kernel kind with no pattern: None, not an exception

@@ -70,6 +70,19 @@ class TrainEngine:
             raise RuntimeError(f"tf_detnet_set_grad_events failed: {rc}")
         self._overlap = dict(ranges=ranges, events=events, comm=torch.cuda.Stream(device=self.device), keep=(blocks, handles))
 
+    def close(self):
+        """Detach the gradient-ready events from the executor (they are owned by this engine: the executor must not record
+        handles that are about to be destroyed)."""
+        if self._overlap is not None:
+            lib().tf_detnet_set_grad_events(None, None, 0)
+            self._overlap = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def set_lr(self, lr):
         self.lr = lr
 
