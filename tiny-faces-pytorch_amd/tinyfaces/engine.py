@@ -21,6 +21,9 @@ from . import ops, parallel
 from ._hip import lib
 
 
+_events_owner = None        # id() of the engine whose events are currently registered with the executor (process-wide state)
+
+
 class TrainEngine:
     def __init__(self, model, criterion, lr=1e-4, momentum=0.9, weight_decay=5e-4, device="cuda", bucket_mb=32):
         self.device = torch.device(device)
@@ -68,13 +71,18 @@ class TrainEngine:
         rc = lib().tf_detnet_set_grad_events(blocks, handles, len(ranges))
         if rc != 0:
             raise RuntimeError(f"tf_detnet_set_grad_events failed: {rc}")
+        global _events_owner
+        _events_owner = id(self)
         self._overlap = dict(ranges=ranges, events=events, comm=torch.cuda.Stream(device=self.device), keep=(blocks, handles))
 
     def close(self):
         """Detach the gradient-ready events from the executor (they are owned by this engine: the executor must not record
         handles that are about to be destroyed)."""
+        global _events_owner
         if self._overlap is not None:
-            lib().tf_detnet_set_grad_events(None, None, 0)
+            if _events_owner == id(self):                     # a newer engine may have registered its own events since
+                lib().tf_detnet_set_grad_events(None, None, 0)
+                _events_owner = None
             self._overlap = None
 
     def __del__(self):
@@ -90,6 +98,8 @@ class TrainEngine:
         """Per bucket: the communication stream waits for the executor's gradient-ready event, then the all-reduce is
         issued from it (RCCL's own stream orders itself after the issuing stream); the compute stream only waits at
         the end.  Without the events (not set up): few large buckets after the whole backward pass."""
+        if self._overlap is not None and _events_owner != id(self):
+            raise RuntimeError("another TrainEngine registered its gradient-ready events with the executor: one distributed engine per process")
         if self._overlap is not None:
             ov, works = self._overlap, []
             for (_, start, end), ev in zip(ov["ranges"], ov["events"]):
