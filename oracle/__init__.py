@@ -17,6 +17,9 @@ Pinning status (see DESIGN.md "Oracle"):
     golden vectors in tests/golden/ were produced by importing the reference's own
     source in the build container (oracle/tools/make_golden.py) and the restatements
     here are asserted equal to them.
+  * the training augmentation in front of the path (oracle/augment.py: WIDERFace.process_inputs, DataProcessor.crop_image)
+    is PINNED the same way (tests/golden/augment.npz), and the PIL BILINEAR resize underneath it -- third-party Pillow 12.2,
+    which IS installed -- is asserted bit-equal to Pillow itself (tests/test_oracle_augment.py).
   * torchvision-owned arithmetic (resnet101 trunk, ops.nms, transforms) is a
     restatement of third-party torchvision 0.18 whose source is not in /root/reference
     and which is not installed here: PARITY UNPINNED at that boundary.  The trunk is
