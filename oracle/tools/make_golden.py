@@ -337,7 +337,25 @@ def gen_augment(out):
         out[f"r{k}_img"] = np.array(r)
 
 
-GENERATORS = {"targets": gen_targets, "decode": gen_decode, "criterion": gen_criterion, "nms": gen_nms,
+def gen_clustering(out):
+    """tinyfaces/clustering: centralize_bbox + compute_distances (cluster.py:13-37) and the reference's own k-medoids
+    (k_medoids.py, option 'local') under a fixed np.random seed."""
+    from tinyfaces.clustering.cluster import centralize_bbox, compute_distances
+    from tinyfaces.clustering.k_medoids import kMedoids
+    rng = np.random.RandomState(5)
+    boxes = random_boxes(rng, 90, size=800)
+    out["boxes"] = boxes
+    with redirect_stdout(io.StringIO()):
+        shapes = centralize_bbox(boxes)
+        dist = compute_distances(shapes)
+    out["shapes"], out["dist"] = shapes, dist
+    for k in (3, 7):
+        np.random.seed(40 + k)
+        med, member = kMedoids(dist, k)
+        out[f"k{k}_medoids"], out[f"k{k}_member"] = np.asarray(med, dtype=np.int64), np.asarray(member, dtype=np.int64)
+
+
+GENERATORS = {"clustering": gen_clustering, "targets": gen_targets, "decode": gen_decode, "criterion": gen_criterion, "nms": gen_nms,
               "model": gen_model, "detections": gen_detections, "trainer": gen_trainer, "augment": gen_augment}
 
 

@@ -221,3 +221,23 @@ def test_bench_reads_committed_pmc_traffic():
     assert t is not None and 2e7 < t < 3e8
     assert bench.pmc_traffic(14) is not None                     # wgrad_dma rows exist too
     assert bench.pmc_traffic(5) is None                          # a kernel kind with no pattern: None, not an exception
+
+
+def test_template_clustering_vs_reference_golden(golden):
+    """tinyfaces.clustering == the reference's centralize_bbox / compute_distances / local kMedoids under the same
+    np.random seed (tests/golden/clustering.npz)."""
+    from tinyfaces import clustering as cl
+    g = golden("clustering")
+    shapes = cl.centralize_bbox(g["boxes"])
+    assert np.array_equal(shapes, g["shapes"])
+    dist = cl.compute_distances(shapes)
+    assert np.allclose(dist, g["dist"], rtol=0, atol=1e-15)
+    for k in (3, 7):
+        med, member = cl.k_medoids(g["dist"], k, rng=np.random.RandomState(40 + k))
+        assert np.array_equal(med, g[f"k{k}_medoids"]) and np.array_equal(member, g[f"k{k}_member"])
+    res = cl.compute_kmedoids(g["boxes"], 1, option="local", indices=4, max_clusters=5, rng=np.random.RandomState(0))
+    assert [len(r) for r in res[:4]] == [0, 0, 0, 0] and [r["n_clusters"] for r in res[4:]] == [4, 5]
+    assert all(len(r["medoids"]) == r["n_clusters"] for r in res[4:])
+    import pytest
+    with pytest.raises(NotImplementedError):
+        cl.compute_kmedoids(g["boxes"], 1, option="pyclustering")
