@@ -355,7 +355,27 @@ def gen_clustering(out):
         out[f"k{k}_medoids"], out[f"k{k}_member"] = np.asarray(med, dtype=np.int64), np.asarray(member, dtype=np.int64)
 
 
-GENERATORS = {"clustering": gen_clustering, "targets": gen_targets, "decode": gen_decode, "criterion": gen_criterion, "nms": gen_nms,
+def gen_cli(out):
+    """The command lines of the reference's entry scripts (main.py:18-36, evaluate_model.py:17-31): every option with its default
+    as argparse resolves them for a minimal positional-only invocation."""
+    import importlib.util
+    import json
+
+    def defaults(path, argv):
+        spec = importlib.util.spec_from_file_location("ref_cli_" + os.path.basename(path)[:-3], path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        old = sys.argv
+        sys.argv = [path] + argv
+        try:
+            return vars(mod.arguments())
+        finally:
+            sys.argv = old
+    out["main"] = np.array(json.dumps(defaults(os.path.join(refstub.REFERENCE_ROOT, "main.py"), ["TRAIN", "VAL"]), sort_keys=True))
+    out["evaluate_model"] = np.array(json.dumps(defaults(os.path.join(refstub.REFERENCE_ROOT, "evaluate_model.py"), ["DATA"]), sort_keys=True))
+
+
+GENERATORS = {"cli": gen_cli, "clustering": gen_clustering, "targets": gen_targets, "decode": gen_decode, "criterion": gen_criterion, "nms": gen_nms,
               "model": gen_model, "detections": gen_detections, "trainer": gen_trainer, "augment": gen_augment}
 
 

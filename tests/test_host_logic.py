@@ -241,3 +241,32 @@ def test_template_clustering_vs_reference_golden(golden):
     import pytest
     with pytest.raises(NotImplementedError):
         cl.compute_kmedoids(g["boxes"], 1, option="pyclustering")
+
+
+def test_entry_script_flags_match_the_reference(golden):
+    """main.py / evaluate_model.py accept the reference's command line: same option names, same defaults (tests/golden/cli.npz holds
+    what the reference's own argparse resolves).  One documented deviation: --resume takes a path (the reference declares it
+    store_true but reads it as a path, main.py:33,74), so its empty default is '' instead of False."""
+    import importlib.util
+    import json
+    import os
+    g = golden("cli")
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tiny-faces-pytorch_amd")
+
+    def ours(script, argv):
+        spec = importlib.util.spec_from_file_location("our_cli_" + script[:-3], os.path.join(pkg, script))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return vars(mod.arguments(argv))
+    ref = json.loads(str(g["main"]))
+    got = ours("main.py", ["TRAIN", "VAL"])
+    for k, v in ref.items():
+        if k == "resume":
+            assert got[k] == "" and v is False
+        else:
+            assert got[k] == v, k
+    assert set(got) - set(ref) == {"fused", "dtype", "synthetic_len"}
+    ref = json.loads(str(g["evaluate_model"]))
+    got = ours("evaluate_model.py", ["DATA"])
+    assert {k: got[k] for k in ref} == ref
+    assert set(got) - set(ref) == {"num_images"}
