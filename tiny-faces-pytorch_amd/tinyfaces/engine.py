@@ -37,6 +37,7 @@ class TrainEngine:
         self.lr, self.momentum, self.weight_decay = lr, momentum, weight_decay
         self.bucket_elems = int(bucket_mb * (1 << 20) // 4)
         self.steps = 0
+        self.skip_allreduce = False          # measurement knob (bench.py): a step without the exchange, to size what the overlap hides
         self._overlap = None
         if parallel.is_distributed():
             self._setup_overlap()
@@ -127,7 +128,7 @@ class TrainEngine:
                                                c.max_neg, c._pos_keep, c._neg_keep, c._next_seed())
         gflat = m._run_backward(x, grad, persistent=True)
         scale = 1.0
-        if parallel.is_distributed():
+        if parallel.is_distributed() and not self.skip_allreduce:
             self._allreduce(gflat)
             scale = 1.0 / parallel.world_size()          # average over ranks, folded into the SGD kernel
         for s, e, mult in self.groups:
