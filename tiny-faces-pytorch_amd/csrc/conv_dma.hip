@@ -15,6 +15,7 @@
 //     store AND for the residual / mask operands, all epilogue math on 8 consecutive channels.
 // Used whenever no producer-BN prologue has to be applied on the fly (eval forward, every
 // data-gradient, conv1 / downsample / heads in training); conv.hip keeps the prologue path.
+#include <cstdio>
 #include <cstdlib>
 #include "common.h"
 #include "profile.h"
@@ -355,7 +356,15 @@ int launch_kind(const tf_conv_args* A, hipStream_t stream) {
   k.ntiles = (A->Cout + BN - 1) / BN; k.mode = A->mode; k.epi = A->epi;
   const int mtiles = (k.M + BM - 1) / BM;
   k.mtiles = mtiles; k.srows = tf_get_stat_rows();
-  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("TF_CONV_DBG"); dbg = e ? atoi(e) : 0; } k.dbg = dbg; }
+  {
+    static int dbg = -1;
+    if (dbg < 0) {
+      const char* e = getenv("TF_CONV_DBG");
+      dbg = e ? atoi(e) : 0;
+      if (dbg) fprintf(stderr, "tinyfaces: TF_CONV_DBG=%d -- timing-ablation mode, convolution RESULTS ARE INVALID\n", dbg);
+    }
+    k.dbg = dbg;
+  }
   size_t lds = (size_t)NS * (BM + BN) * 128;
   const size_t stg = (size_t)BM * (BN + 4) * 4;
   if (stg > lds) lds = stg;
