@@ -124,13 +124,13 @@ def test_wider_val_and_test_splits_yield_image_and_path(tmp_path):
     tf = transforms.Compose([transforms.ToTensor(), transforms.Normalize([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])])
     args = SimpleNamespace(batch_size=1, workers=0, dataset_root=str(tmp_path), debug=False)
     loader, templates = get_dataloader(tmp_path / "val.txt", args, img_transforms=tf, train=False, split="val")
-    (img, path), = list(loader)
-    assert path == "3--Riot/p.png" and img.shape == (3, 40, 50) and img.dtype == torch.float32
-    assert torch.equal(img, torch.from_numpy(arr.transpose(2, 0, 1).copy()).float().div(255))
+    (img, path), = list(loader)                 # batched like torch's default collate: (1,3,H,W) + [path] (evaluate_model.py:60-68)
+    assert path == ["3--Riot/p.png"] and img.shape == (1, 3, 40, 50) and img.dtype == torch.float32
+    assert torch.equal(img[0], torch.from_numpy(arr.transpose(2, 0, 1).copy()).float().div(255))
     assert loader.dataset.rf == {"size": [859, 859], "stride": [8, 8], "offset": [-1, -1]}
     loader, _ = get_dataloader(tmp_path / "test.txt", args, img_transforms=tf, train=False, split="test")
     (img, path), = list(loader)
-    assert path == "3--Riot/p.png" and torch.allclose(img, tf(arr))
+    assert path[0] == "3--Riot/p.png" and torch.allclose(img[0], tf(arr))
 
 
 def _wider_case(rng, n_img=6):
@@ -265,7 +265,7 @@ def test_entry_script_flags_match_the_reference(golden):
             assert got[k] == "" and v is False
         else:
             assert got[k] == v, k
-    assert set(got) - set(ref) == {"fused", "dtype", "synthetic_len"}
+    assert set(got) - set(ref) == {"fused", "dtype", "synthetic_len", "seed", "pretrained"}
     ref = json.loads(str(g["evaluate_model"]))
     got = ours("evaluate_model.py", ["DATA"])
     assert {k: got[k] for k in ref} == ref

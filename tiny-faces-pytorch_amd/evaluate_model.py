@@ -8,9 +8,8 @@ import torch
 
 from types import SimpleNamespace
 
-from tinyfaces import ops, transforms
+from tinyfaces import transforms
 from tinyfaces.datasets import get_dataloader
-from tinyfaces.datasets.templates import load_templates
 from tinyfaces.evaluation import get_detections, get_model, write_results
 
 
@@ -32,31 +31,38 @@ def arguments(argv=None):
     return parser.parse_args(argv)
 
 
+def dataloader(args):
+    """evaluate_model.py:34-45."""
+    tf = transforms.Compose([transforms.ToTensor(), transforms.Normalize([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])])
+    largs = SimpleNamespace(batch_size=args.batch_size, workers=args.workers, dataset_root=args.dataset_root or "", debug=args.debug,
+                            synthetic_len=args.num_images)
+    return get_dataloader(args.dataset, largs, train=False, split=args.split, img_transforms=tf)
+
+
+def run(model, val_loader, templates, prob_thresh, nms_thresh, device, split, results_dir=None, debug=False):
+    """evaluate_model.py:48-68, statement for statement: `img[0]` / `filename[0]` undo the batch axis the loader adds.  The
+    only addition is the keyword that builds the pyramid levels on the GPU (same detections bit for bit)."""
+    dets = None
+    for _, (img, filename) in enumerate(val_loader):
+        dets = get_detections(model, img[0], templates, val_loader.dataset.rf, val_loader.dataset.transforms, prob_thresh, nms_thresh,
+                              device=device, pyramid_on_gpu=True)
+        write_results(dets, filename[0], split, results_dir)
+        if debug:
+            print(f"{filename[0]}: {dets.shape[0]} detections")
+    return dets
+
+
 def main():
     args = arguments()
     if not torch.cuda.is_available():
         raise SystemExit("this build of the tiny-faces hot path runs on MI355X only (no CPU fallback)")
     device = torch.device("cuda:0")
-    templates = load_templates()
+    val_loader, templates = dataloader(args)
     model = get_model(args.checkpoint, num_templates=templates.shape[0])
-    tf = transforms.Compose([transforms.ToTensor(), transforms.Normalize([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])])
     model = model.to(device).eval()
-    if args.dataset != "synthetic":
-        largs = SimpleNamespace(batch_size=1, workers=args.workers, dataset_root=args.dataset_root or "", debug=args.debug)
-        loader, templates = get_dataloader(args.dataset, largs, train=False, split=args.split, img_transforms=tf)
-        with torch.no_grad(), model.constant_weights():
-            for img, filename in loader:                      # (3, H, W) float in [0, 1] (val) and its path, wider_face.py:224-239
-                dets = get_detections(model, img, templates, loader.dataset.rf, tf, args.prob_thresh, args.nms_thresh, device=device,
-                                      pyramid_on_gpu=True)
-                write_results(dets, filename, args.split, args.results_dir)
-        return
-    g = torch.Generator().manual_seed(0)
     with torch.no_grad(), model.constant_weights():          # the checkpoint does not change between images: pack the weights once
-        for i in range(args.num_images):
-            img = torch.rand(3, 960, 1280, generator=g)          # wide enough for the 2^-2 level: the W-axis mask of defect D1 needs W' >= 25
-            dets = get_detections(model, img, templates, ops.RF, tf, args.prob_thresh, args.nms_thresh, device=device)
-            write_results(dets, f"synthetic/img_{i}.jpg", args.split, args.results_dir)
-            print(f"img_{i}: {dets.shape[0]} detections")
+        run(model, val_loader, templates, args.prob_thresh, args.nms_thresh, device, args.split, results_dir=args.results_dir,
+            debug=args.debug or args.dataset == "synthetic")
 
 
 if __name__ == "__main__":

@@ -35,6 +35,9 @@ REFERENCE_FLAGS = [
 EXTRA_FLAGS = [
     ("--fused", dict(dest="fused", action="store_true", default=True)), ("--no-fused", dict(dest="fused", action="store_false")),
     ("--dtype", dict(default="bf16", choices=["bf16", "fp32"])), ("--synthetic-len", dict(dest="synthetic_len", default=240, type=int)),
+    ("--seed", dict(default=0, type=int, help="synthetic data / sampling seed (each rank derives its own from it)")),
+    ("--pretrained", dict(default="", help="local torchvision-format resnet101 state_dict (.pth) for the trunk: the reference starts "
+                                           "from ResNet101_Weights.IMAGENET1K_V1 (model.py:13-14), which it downloads; there is no network here")),
 ]
 
 
@@ -59,6 +62,22 @@ def run_fused_epoch(engine, loss_fn, loader, epoch, device, base_lr):
             trainer.print_state(idx, epoch, total, loss_fn.class_average.average, loss_fn.reg_average.average)
 
 
+def load_pretrained_trunk(model, path):
+    """The reference's default `pretrained_weights=ResNet101_Weights.IMAGENET1K_V1` (model.py:13-14,20) from a local file:
+    a torchvision resnet101 state_dict (keys `conv1.weight`, `layer1.0...`, `fc.*`; `layer4.*` is dropped like model.py:23)
+    or a checkpoint of this package / the reference (`{"model": {...}}` with `model.`-prefixed keys)."""
+    sd = torch.load(path, map_location="cpu")
+    sd = sd.get("model", sd)
+    if any(k.startswith("model.") for k in sd):
+        missing, unexpected = model.load_state_dict(sd, strict=False)
+    else:
+        sd = {k: v for k, v in sd.items() if not k.startswith("layer4.")}
+        missing, unexpected = model.model.load_state_dict(sd, strict=False)
+    if unexpected:
+        raise SystemExit(f"--pretrained {path}: unexpected keys {list(unexpected)[:5]} ... (not a resnet101 state_dict?)")
+    return missing
+
+
 def main():
     args = arguments()
     if not torch.cuda.is_available():
@@ -68,22 +87,38 @@ def main():
     preprocess = transforms.Compose([transforms.ToTensor(), transforms.Normalize(mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225])])
     train_loader, _ = get_dataloader(args.traindata, args, NUM_TEMPLATES, img_transforms=preprocess)
     model = DetectionModel(num_objects=1, num_templates=NUM_TEMPLATES).set_compute_dtype(args.dtype)
-    loss_fn = DetectionCriterion(NUM_TEMPLATES, seed=parallel.rank(), lazy_meters=True)
+    loss_fn = DetectionCriterion(NUM_TEMPLATES, seed=args.seed * parallel.world_size() + parallel.rank(), lazy_meters=True)
 
     first_epoch = args.start_epoch
-    if args.resume:
+    state = None
+    if args.resume:                                              # main.py:73-79 (there `--resume` is a flag used as a path: defect D3)
         state = torch.load(args.resume, map_location="cpu")
         model.load_state_dict(state["model"])
         first_epoch = first_epoch or state["epoch"]
+    elif args.pretrained:
+        load_pretrained_trunk(model, args.pretrained)
+    elif parallel.rank() == 0:
+        print("WARNING: training starts from RANDOM (kaiming) weights. The reference starts from ImageNet ResNet-101 "
+              "(model.py:13-14); its lr / schedule will not reproduce its results from scratch. Pass --pretrained <resnet101.pth>.")
 
     engine = optimizer = scheduler = None
     if args.fused:
         engine = TrainEngine(model, loss_fn, lr=args.lr, momentum=args.momentum, weight_decay=args.weight_decay, device=device)
+        if state is not None:
+            engine.load_optimizer_state_dict(state.get("optimizer"))      # momentum buffers (a torch.optim.SGD state_dict)
     else:
         optimizer = optim.SGD(model.learnable_parameters(args.lr), lr=args.lr, momentum=args.momentum, weight_decay=args.weight_decay)
+        if state is not None and state.get("optimizer", {}).get("param_groups"):
+            optimizer.load_state_dict(state["optimizer"])                 # main.py:76
+        for mult, g in zip((1.0, 0.1, 1.0, 0.0), optimizer.param_groups):
+            g.setdefault("initial_lr", args.lr * mult)                    # StepLR(last_epoch >= 0) requires it (main.py:81-83)
         scheduler = optim.lr_scheduler.StepLR(optimizer, step_size=LR_STEP, last_epoch=first_epoch - 1)
 
     for epoch in range(first_epoch, args.epochs):
+        if hasattr(train_loader, "set_epoch"):
+            train_loader.set_epoch(epoch)                                 # reshuffle the rank shards
+        elif hasattr(getattr(train_loader, "sampler", None), "set_epoch"):
+            train_loader.sampler.set_epoch(epoch)
         if engine is not None:
             run_fused_epoch(engine, loss_fn, train_loader, epoch, device, args.lr)
         else:
@@ -91,8 +126,10 @@ def main():
             scheduler.step()
         done = epoch + 1
         if done % args.save_every == 0 and parallel.rank() == 0:
-            snapshot = {"epoch": done, "batch_size": getattr(train_loader, "batch_size", args.batch_size), "model": model.state_dict(),
-                        "optimizer": optimizer.state_dict() if optimizer is not None else {}}
+            if engine is not None:
+                engine.set_lr(lr_at(args.lr, done))                       # what StepLR would have left in the param groups
+            snapshot = {"epoch": done, "batch_size": train_loader.batch_size, "model": model.state_dict(),          # main.py:97-102
+                        "optimizer": optimizer.state_dict() if optimizer is not None else engine.optimizer_state_dict(base_lr=args.lr)}
             trainer.save_checkpoint(snapshot, filename=f"checkpoint_{done}.pth", save_path=Path("weights"))
 
 

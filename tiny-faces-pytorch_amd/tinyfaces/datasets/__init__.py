@@ -17,11 +17,18 @@ def get_dataloader(datapath, args, num_templates=25, template_file="templates.js
                    split="train"):
     """datasets/__init__.py:11-52.  `datapath == "synthetic"` (or a path that does not exist with
     args.synthetic set) yields seeded 500x500 crops + random boxes (BASELINE.json configs[2]);
-    returns (loader, templates ndarray 25x5) like the reference."""
+    returns (loader, templates ndarray 25x5) like the reference.
+
+    Data parallel (one process per GPU, tinyfaces/parallel.py): every rank walks ITS shard of the data -- a
+    DistributedSampler for annotation files, a rank-dependent seed for the synthetic crops -- so an epoch is one pass over
+    the data whatever the world size and no two ranks ever differentiate the same images."""
+    from .. import parallel
     templates = load_templates(num_templates)
+    world, rank = (parallel.world_size(), parallel.rank()) if parallel.is_distributed() else (1, 0)
     if str(datapath) == "synthetic" or getattr(args, "synthetic", False):
-        ds = SyntheticCrops(templates, length=getattr(args, "synthetic_len", 256), seed=getattr(args, "seed", 0),
-                            train=train)
+        length = getattr(args, "synthetic_len", 256)
+        ds = SyntheticCrops(templates, length=max(1, length // world), seed=getattr(args, "seed", 0) * world + rank,
+                            train=train, img_transforms=img_transforms)
         loader = data.DataLoader(ds, batch_size=args.batch_size, shuffle=False, num_workers=0, collate_fn=ds.collate)
         return loader, templates
     # datasets/__init__.py:40-52: the WIDER FACE annotation file + image tree
@@ -31,8 +38,9 @@ def get_dataloader(datapath, args, num_templates=25, template_file="templates.js
                    dataset_root=Path(getattr(args, "dataset_root", "")).expanduser(), debug=getattr(args, "debug", False))
     # decoding runs in the workers (identity collate there); the device half of a batch -- augmentation + targets -- runs in
     # this process, where the GPU context lives
-    inner = data.DataLoader(ds, batch_size=args.batch_size, shuffle=train, num_workers=getattr(args, "workers", 0),
-                            collate_fn=_identity)
+    sampler = data.distributed.DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=train) if world > 1 else None
+    inner = data.DataLoader(ds, batch_size=args.batch_size, shuffle=train and sampler is None, sampler=sampler,
+                            num_workers=getattr(args, "workers", 0), collate_fn=_identity)
     return DeviceCollatingLoader(inner, ds.collate), templates
 
 
@@ -41,10 +49,18 @@ def _identity(samples):
 
 
 class DeviceCollatingLoader:
-    """A DataLoader whose worker processes only decode; `collate` (device work) is applied to each batch in the consumer."""
+    """A DataLoader whose worker processes only decode; `collate` (device work) is applied to each batch in the consumer.
+    It answers everything the reference's callers ask a `torch.utils.data.DataLoader` for: `len()`, iteration,
+    `.batch_size` (main.py:99), `.dataset` (`.rf`, `.transforms`: evaluate_model.py:63-64), `.sampler`."""
 
     def __init__(self, inner, collate):
         self.inner, self.collate, self.dataset = inner, collate, inner.dataset
+        self.batch_size, self.sampler, self.num_workers = inner.batch_size, inner.sampler, inner.num_workers
+
+    def set_epoch(self, epoch):
+        """Reshuffle the rank shards (DistributedSampler.set_epoch); a no-op in a single process."""
+        if hasattr(self.sampler, "set_epoch"):
+            self.sampler.set_epoch(epoch)
 
     def __len__(self):
         return len(self.inner)

@@ -38,12 +38,17 @@ class TargetAssigner:
 
 
 class SyntheticCrops(data.Dataset):
-    def __init__(self, templates, length=256, seed=0, train=True, device="cuda"):
+    """train=True: (img, boxes) -> collate -> (img, class_map, regression_map) batches like WIDERFace's training samples
+    (wider_face.py:219-222).  train=False: the val contract of wider_face.py:224-233 -- an image tensor in [0, 1] of
+    `val_size` and its (made-up) relative path; collate adds the batch axis / list exactly like torch's default collate."""
+
+    def __init__(self, templates, length=256, seed=0, train=True, device="cuda", val_size=(960, 1280), img_transforms=None):
         self.templates, self.length, self.seed, self.train = templates, length, seed, train
         self.assigner = TargetAssigner(templates, seed=seed)
         self.device = device
         self.rf = ops.RF
-        self.transforms = None
+        self.transforms = img_transforms
+        self.val_size = val_size
 
     def __len__(self):
         return self.length
@@ -51,10 +56,14 @@ class SyntheticCrops(data.Dataset):
     def __getitem__(self, i):
         rng = np.random.RandomState(self.seed * 7919 + i)
         g = torch.Generator().manual_seed(self.seed * 7919 + i)
+        if not self.train:
+            return torch.rand(3, *self.val_size, generator=g), f"synthetic/img_{i}.jpg"
         img = torch.randn(3, *INPUT_SIZE, generator=g)
         return img, random_boxes(rng)
 
     def collate(self, batch):
+        if not self.train:
+            return torch.stack([b[0] for b in batch]), [b[1] for b in batch]
         imgs = torch.stack([b[0] for b in batch])
         boxes = [b[1] for b in batch]
         if not torch.cuda.is_available():

@@ -92,7 +92,13 @@ class WIDERFace(dataset.Dataset):
     def collate(self, samples):
         """Main-process half of a training batch: upload, augment on the GPU, assign targets on the GPU."""
         if self.split != "train":
-            return samples[0] if len(samples) == 1 else list(zip(*samples))
+            # what torch's default collate makes of [(img (3,H,W), path)] (wider_face.py:224-239 through the DataLoader of
+            # datasets/__init__.py:46-50): a batch axis on the images, a list of the paths -- evaluate_model.py:60-68 reads
+            # img[0] / filename[0].  Images of different sizes do not stack there either (batch_size 1 is the reference's use).
+            imgs, paths = zip(*samples)
+            if all(isinstance(i, torch.Tensor) for i in imgs):
+                return torch.stack(list(imgs)), list(paths)
+            return list(imgs), list(paths)
         mean, std = ops.IMAGE_MEAN, ops.IMAGE_STD
         ts = getattr(self.transforms, "transforms", None)
         if ts is not None and len(ts) == 2 and type(ts[1]).__name__ == "Normalize":

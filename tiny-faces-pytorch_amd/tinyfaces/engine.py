@@ -95,6 +95,65 @@ class TrainEngine:
     def set_lr(self, lr):
         self.lr = lr
 
+    # ---- checkpoint interop with torch.optim.SGD (main.py:67-76,97-102) ------------------------------------------------
+    def _group_params(self):
+        """[(lr multiplier, [(state_dict key, nn.Parameter)])] in the order of DetectionModel.learnable_parameters
+        (model.py:67-87), i.e. the parameter numbering torch.optim.SGD(model.learnable_parameters(lr)) uses."""
+        m = self.model
+        name_of = {id(p): k for k, p in m.named_parameters()}
+        mults = (1.0, 0.1, 1.0, 0.0)
+        return [(mult, [(name_of[id(p)], p) for p in g["params"]]) for mult, g in zip(mults, m.learnable_parameters(1.0))]
+
+    def optimizer_state_dict(self, base_lr=None):
+        """The engine's SGD state in the format of `torch.optim.SGD(model.learnable_parameters(lr), ...).state_dict()`, so that
+        the reference's resume path (`optimizer.load_state_dict(checkpoint['optimizer'])`, main.py:76) accepts a checkpoint
+        written by the fused trainer: one `momentum_buffer` per trained parameter (a slice of the flat momentum buffer), the
+        four parameter groups with lr / initial_lr (StepLR needs it when constructed with last_epoch >= 0, main.py:81-83)."""
+        base_lr = self.lr if base_lr is None else base_lr
+        seg = self.model._segments
+        state, groups, idx = {}, [], 0
+        for mult, params in self._group_params():
+            ids = []
+            for k, p in params:
+                if k in seg and mult != 0.0 and self.steps > 0:
+                    o, n = seg[k]
+                    state[idx] = {"momentum_buffer": self.flat_m[o:o + n].view_as(p).detach().clone().cpu()}
+                ids.append(idx)
+                idx += 1
+            groups.append({"lr": self.lr * mult, "momentum": self.momentum, "dampening": 0, "weight_decay": self.weight_decay,
+                           "nesterov": False, "maximize": False, "foreach": None, "differentiable": False, "fused": None,
+                           "initial_lr": base_lr * mult, "params": ids})
+        return {"state": state, "param_groups": groups}
+
+    def load_optimizer_state_dict(self, sd):
+        """Inverse of optimizer_state_dict: also accepts the state_dict of a real torch.optim.SGD built from
+        model.learnable_parameters (the reference's own checkpoints, main.py:97-102).  Parameters without a
+        momentum_buffer (never stepped, `model.fc.*`, lr-0 upsample) start from zero like torch does."""
+        if not sd or not sd.get("param_groups"):
+            return False
+        seg = self.model._segments
+        flat = [kp for _, params in self._group_params() for kp in params]
+        ids = [i for g in sd["param_groups"] for i in g["params"]]
+        if len(ids) != len(flat):
+            raise ValueError(f"optimizer state has {len(ids)} parameters, the model has {len(flat)}")
+        self.flat_m.zero_()
+        loaded = 0
+        for i, (k, p) in zip(ids, flat):
+            st = sd["state"].get(i)
+            buf = None if st is None else st.get("momentum_buffer")
+            if buf is None or k not in seg:
+                continue
+            o, n = seg[k]
+            if buf.numel() != n:
+                raise ValueError(f"momentum_buffer of {k}: {buf.numel()} elements, expected {n}")
+            self.flat_m[o:o + n].copy_(buf.reshape(-1).to(self.flat_m.device, torch.float32))
+            loaded += 1
+        g0 = sd["param_groups"][0]
+        self.momentum = float(g0.get("momentum", self.momentum))
+        self.weight_decay = float(g0.get("weight_decay", self.weight_decay))
+        self.steps = max(self.steps, 1 if loaded else 0)
+        return True
+
     def _allreduce(self, gflat):
         """Per bucket: the communication stream waits for the executor's gradient-ready event, then the all-reduce is
         issued from it (RCCL's own stream orders itself after the issuing stream); the compute stream only waits at
@@ -136,6 +195,6 @@ class TrainEngine:
                 continue                                  # score4_upsample: lr 0 (model.py:84) -> nothing to do
             ops.sgd_step(self.flat_p[s:e], gflat[s:e], self.flat_m[s:e], self.lr * mult, self.momentum, self.weight_decay, scale)
         self.steps += 1
-        if hasattr(c, "_pending"):
-            c._pending.append((loss2, x.shape[0]))
+        if hasattr(c, "_pending") and (parallel.rank() == 0 or not parallel.is_distributed()):
+            c._pending.append((loss2, x.shape[0]))       # only the logging rank ever flushes the meters
         return loss2

@@ -121,7 +121,18 @@ class DetectionModel(nn.Module):
         self._ready_key = None           # (workspace ptr, dtype, table key) whose packed eval weights sit in the workspace
         if isinstance(pretrained_weights, (str, os.PathLike)):           # no network here: a local file only
             sd = torch.load(pretrained_weights, map_location="cpu")
-            self.load_state_dict(sd.get("model", sd), strict=False)
+            sd = sd.get("model", sd)
+            if any(k.startswith("model.") for k in sd):
+                self.load_state_dict(sd, strict=False)
+            else:                                                        # a bare torchvision resnet101 state_dict
+                self.model.load_state_dict({k: v for k, v in sd.items() if not k.startswith("layer4.")}, strict=False)
+        elif pretrained_weights is not None:
+            # the reference's default (ResNet101_Weights.IMAGENET1K_V1, model.py:13-14) is a download: impossible here.  Say so
+            # loudly instead of silently training from random weights with the reference's schedule.
+            import warnings
+            warnings.warn(f"DetectionModel: pretrained_weights={pretrained_weights!r} is not a local file -- ignored, the trunk "
+                          "keeps its RANDOM kaiming initialisation (no network to download ImageNet weights). Pass a path to a "
+                          "torchvision resnet101 state_dict instead.", RuntimeWarning, stacklevel=2)
 
     # ---- reference surface ---------------------------------------------------------------
     def _init_bilinear(self):

@@ -49,3 +49,5 @@ def train(model, loss_fn, optimizer, dataloader, epoch, device):
             if flush is not None:
                 flush()
             print_state(step, epoch, n_batches, loss_fn.class_average.average, loss_fn.reg_average.average)
+        elif getattr(loss_fn, "_pending", None):
+            loss_fn._pending.clear()            # lazy meters are only ever read on the logging rank: do not pin device scalars elsewhere
