@@ -14,7 +14,7 @@
  *     unless stated; stateless and therefore thread-safe per stream;
  *   - return 0 (TF_OK) or a negative TF_ERR_* code; no exceptions cross the boundary.
  *   - activations of the network kernels are NHWC ("pixels x channels" matrices), dtype
- *     TF_F32 or TF_BF16; maps handed to / from the reference call surface are NCHW float32.
+ *     TF_F32, TF_BF16 or (inference) TF_F16; maps handed to / from the reference call surface are NCHW float32.
  */
 #ifndef TINYFACES_HIP_H
 #define TINYFACES_HIP_H
@@ -34,6 +34,7 @@ extern "C" {
 
 #define TF_F32 0
 #define TF_BF16 1
+#define TF_F16 2      /* IEEE half operands, fp32 accumulation: inference only (BASELINE.json configs[4]); the training entry points refuse it */
 
 int tf_version(void);
 /* number of exported symbols a binding must resolve; names via tf_symbol_name(i) */
@@ -76,6 +77,17 @@ int tf_dense_overlap_iou(const double* boxes, int G, const double* templates, in
 size_t tf_nms_workspace_bytes(int n);
 int tf_nms_f64(const double* boxes /*[n][4]*/, const double* scores /*[n]*/, int n, double iou_thresh,
                int64_t* keep_out /*[n]*/, int32_t* num_keep, void* ws, size_t ws_bytes, void* stream);
+/* Batched multi-scale form (BASELINE.json configs[4]): S <= TF_NMS_MAX_SEGMENTS independent candidate lists -- the multi-scale
+ * candidates of each image of an evaluation batch (the reference runs evaluation.py:80-84 once per image), or one list per pyramid
+ * level -- laid out back to back; segment s = rows [host_seg_offsets[s], host_seg_offsets[s+1]) (HOST int32 array, [0] == 0).
+ * One NMS per segment with the semantics of tf_nms_f64, all of them in the same three launches.  The survivors of segment s are
+ * written to keep_out[host_seg_offsets[s] ...] as indices into the CONCATENATED input (descending score inside the segment),
+ * num_keep[s] (device) their count.  Largest segment <= 524 160 boxes.  ws: tf_nms_batched_workspace_bytes(). */
+#define TF_NMS_MAX_SEGMENTS 64
+size_t tf_nms_batched_workspace_bytes(const int32_t* host_seg_offsets, int num_segments);
+int tf_nms_f64_batched(const double* boxes /*[n][4]*/, const double* scores /*[n]*/, const int32_t* host_seg_offsets /*[S+1]*/,
+                       int num_segments, double iou_thresh, int64_t* keep_out /*[n]*/, int32_t* num_keep /*[S]*/,
+                       void* ws, size_t ws_bytes, void* stream);
 
 /* ---- score map -> boxes: sigmoid + threshold + ORDERED compaction + refinement ------
  * Replaces evaluation.py:61-78 + get_bboxes / regression_refinement

@@ -227,6 +227,50 @@ def test_pack_weights_tiled_equals_elementwise_pack(dtype):
             assert torch.equal(ot.view(-1), reft.view(-1)), (co, ci, k, "t")
 
 
+REAL_CASES = [
+    # the layer shapes of the bs=12 500x500 training step that bench.py times (N, H, W, Cin, Cout, K, stride, pad)
+    (12, 125, 125, 64, 256, 1, 1, 0),      # layer1 conv3 / downsample: M = 187 500, K = 64 (one K-stage, 5 860-block grids)
+    (12, 125, 125, 256, 64, 1, 1, 0),      # layer1 conv1
+    (12, 125, 125, 64, 64, 3, 1, 1),       # layer1 conv2
+    (12, 125, 125, 128, 128, 3, 2, 1),     # layer2.0 conv2 (stride 2): M = 47 628
+    (12, 63, 63, 128, 512, 1, 1, 0),       # layer2 conv3
+    (12, 32, 32, 1024, 256, 1, 1, 0),      # layer3 conv1: M = 12 288, 16 K-stages
+    (12, 32, 32, 256, 256, 3, 1, 1),       # layer3 conv2: 36 K-stages
+    (12, 32, 32, 256, 1024, 1, 1, 0),      # layer3 conv3 (and, transposed, the hand-over data gradient)
+    (1, 1, 750000, 192, 64, 1, 1, 0),      # the stem GEMM over the im2col matrix: M = 750 000
+]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", REAL_CASES)
+def test_conv_real_layer_shapes(dtype, case):
+    """Forward, data gradient and weight gradient at the shapes the benchmark runs (auto tile / split-K), vs torch-CPU fp32 fed
+    the same rounded operands.  Covers what the small cases cannot: multi-thousand-block grids, the XCD remap at grid sizes that
+    are not multiples of 8, split-K chunking and the folded statistic rows at M = 187 500."""
+    from tinyfaces import _hip, ops
+    N, H, W, Cin, Cout, K, s, p = case
+    g = _g(hash(case) % 1000)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = (torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5)
+    xr, wr = q(x, dtype).requires_grad_(True), q(w, dtype).requires_grad_(True)
+    ref = F.conv2d(xr, wr, stride=s, padding=p)
+    gy = torch.randn(ref.shape, generator=g)
+    ref.backward(q(gy, dtype))
+    xd, gyd = to_nhwc(x, dtype), to_nhwc(gy, dtype)
+    y, st = ops.conv2d_nhwc(xd, ops.pack_weight(w.cuda(), dtype), Cout, K, K, s, p, epi=_hip.EPI_STATS, want_stats=True)
+    d = err(from_nhwc(y), ref.detach())
+    n = ref.numel() / Cout
+    d1 = err(st.sum(0).cpu()[0] / n, ref.detach().mean(dim=(0, 2, 3)))
+    gx = ops.conv2d_nhwc(gyd, ops.pack_weight(w.cuda(), dtype, transpose=True), Cin, K, K, s, p, mode=1, out_hw=(H, W))
+    dg = err(from_nhwc(gx), xr.grad)
+    dw = ops.conv2d_wgrad(xd, gyd, Cin, Cout, K, K, s, p)
+    dwe = err(dw.cpu(), wr.grad)
+    report(f"conv_real[{dtype},{case}]", fwd_rel=d[2], mean_abs=d1[0], dgrad_rel=dg[2], wgrad_rel=dwe[2])
+    assert d[2] < TOL[dtype] and d1[0] < 2e-3
+    assert dg[2] < TOL[dtype]
+    assert dwe[2] < (1e-4 if dtype == torch.float32 else 3e-3)
+
+
 WG_CASES = [
     # N, H, W, Cin, Cout, K, stride
     (1, 9, 7, 64, 64, 1, 1),

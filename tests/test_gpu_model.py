@@ -1,7 +1,9 @@
 """-m gpu: the whole detector through the reference call surface (DetectionModel, DetectionCriterion,
 get_detections, trainer.train) vs the golden vectors produced by the reference's own source and
 vs the CPU oracle.  Tolerance from BASELINE.json north_star: cls/reg maps within 1e-3 in fp32;
-identical NMS-surviving boxes on fixed-seed inputs.  The bf16 fast path is held to 3e-2."""
+identical NMS-surviving boxes on fixed-seed inputs.  The bf16 fast path is held to 5e-3 on eval maps (measured 2.2e-3)
+and 3e-2 on training-mode maps of the tiny fixtures (batch statistics over <= 400 pixels amplify the operand rounding;
+measured 1.3e-2).  The benchmarked sizes are checked in tests/test_gpu_fullsize.py."""
 import io
 from contextlib import redirect_stdout
 
@@ -62,7 +64,7 @@ def test_eval_forward_vs_reference_golden(golden, models, ci, dtype):
     d = err(y, g[f"{tag}_y"])
     report(f"model_eval[{ci},{dtype}]", maxabs=d[0], maxref=d[1])
     assert y.shape == g[f"{tag}_y"].shape
-    assert d[0] < (1e-3 if dtype == torch.float32 else 3e-2)
+    assert d[0] < (1e-3 if dtype == torch.float32 else 5e-3)
 
 
 def _oracle_train_pass(dtype_o, x, gy):
@@ -110,21 +112,38 @@ def test_train_forward_backward_vs_reference_golden(golden, ci, dtype):
     rh, rt, cs = np.array(rh), np.array(rt), np.array(cs)
     head = max(err(params[k].grad.cpu().numpy(), g[f"{tag}_grad::{k}"])[2] for k in ("score_res4.bias",)
                if f"{tag}_grad::{k}" in g.files)
+    # every parameter gradient the reference fixture stores (torch-fp32 of the reference's own model.py): relative error and
+    # cosine against it.  (The fixture's `gx` has no counterpart: the training step never asks for the input gradient,
+    # trainer.py:72-87 feeds a tensor that does not require grad, and conv1 computes no data gradient here.)
+    gold = {k.split("::")[1]: g[k] for k in g.files if k.startswith(f"{tag}_grad::")}
+    g_rel, g_cos = {}, {}
+    for k, ref_g in gold.items():
+        a = params[k].grad.cpu().double().numpy().ravel()
+        b = ref_g.astype(np.float64).ravel()
+        g_rel[k] = float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+        g_cos[k] = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
     sd = m.state_dict()
     drm = err(sd["model.bn1.running_mean"].cpu().numpy(), g[f"{tag}_rm::model.bn1.running_mean"])
     drv = err(sd["model.layer3.5.bn2.running_var"].cpu().numpy(), g[f"{tag}_rv::model.layer3.5.bn2.running_var"])
     report(f"model_train[{ci},{dtype}]", y_maxabs=dy[0], hip_med=np.median(rh), hip_p90=np.quantile(rh, .9), hip_max=rh.max(),
            t32_med=np.median(rt), t32_p90=np.quantile(rt, .9), t32_max=rt.max(), cos_min=cs.min(), cos_med=np.median(cs),
-           head=head, rm=drm[0], rv=drv[0])
-    assert len(rh) == 286
+           head=head, rm=drm[0], rv=drv[0], golden_rel=str({k: round(v, 6) for k, v in g_rel.items()}),
+           golden_cos_min=min(g_cos.values()))
+    assert len(rh) == 286 and len(gold) >= 3
     if dtype == torch.float32:
         assert dy[0] < 1e-3                                               # north_star: maps within 1e-3 in fp32
         assert head < 1e-4
+        assert min(g_cos.values()) > 0.999, g_cos                         # all golden gradients, not one
+        for k, v in g_rel.items():
+            # a stored tensor may sit behind ReLU boundaries (see the docstring): bounded by what torch-fp32 itself does there
+            t32 = float((p32[k].grad.double() - p64[k].grad).abs().max() / (p64[k].grad.abs().max() + 1e-30))
+            assert v <= 4 * t32 + 2e-3, (k, v, t32)
         assert np.median(rh) <= 4 * np.median(rt) + 1e-4 and np.quantile(rh, .9) <= 4 * np.quantile(rt, .9) + 1e-3
         assert cs.min() > 0.999
         assert drm[0] < 1e-4 and drv[0] < 1e-3
     else:
-        assert dy[0] < 5e-2 and head < 2e-2
+        assert dy[0] < 3e-2 and head < 5e-3
+        assert min(g_cos.values()) > 0.9, g_cos
         assert cs.min() > 0.9 and np.median(cs) > 0.95
         assert drm[0] < 5e-3 and drv[0] < 2e-2
     assert int(sd["model.bn1.num_batches_tracked"]) == 1
@@ -141,18 +160,19 @@ def test_get_detections_vs_reference_golden(golden, models):
     templates = golden("targets")["templates"]
     tf = transforms.Compose([transforms.ToTensor(), transforms.Normalize([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])])
     m.set_compute_dtype(torch.float32)
-    dets = get_detections(m, torch.from_numpy(g["img"]), templates, RF, tf, prob_thresh=float(g["thr"]), nms_thresh=0.3,
-                          scales=tuple(g["scales"].tolist()), device="cuda")
+    from oracle.nms import nms as onms
+    dets, cand, keep = get_detections(m, torch.from_numpy(g["img"]), templates, RF, tf, prob_thresh=float(g["thr"]), nms_thresh=0.3,
+                                      scales=tuple(g["scales"].tolist()), device="cuda", return_candidates=True)
     ref = g["dets_ref_K4"]
     same = dets.shape[0] == ref.shape[0]
     d = err(dets[:, :4], ref)[0] if same else -1
-    # order-insensitive overlap for the report (threshold-borderline candidates may differ in fp32)
-    common = len(set(map(tuple, np.round(dets[:, :4], 2))) & set(map(tuple, np.round(ref, 2))))
-    report("get_detections", k=dets.shape[0], kref=ref.shape[0], maxabs=d, common=common)
-    assert dets.shape[1] == 5
-    assert common >= 0.98 * ref.shape[0]
-    if same:
-        assert np.allclose(dets[:, :4], ref, rtol=1e-3, atol=2e-2)
+    report("get_detections", k=dets.shape[0], kref=ref.shape[0], maxabs=d, candidates=cand.shape[0])
+    # north_star: identical NMS-surviving boxes -- same count, same order, same rows as the reference's own output ...
+    assert dets.shape == (ref.shape[0], 5)
+    assert np.allclose(dets[:, :4], ref, rtol=0, atol=1e-3), d
+    # ... and the surviving INDICES are those of the restated torchvision kernel on the same candidate list
+    assert np.array_equal(keep, onms(cand[:, :4], cand[:, 4], 0.3))
+    assert np.array_equal(dets, cand[keep])
 
 
 def test_get_detections_pyramid_on_gpu_is_identical(golden, models):

@@ -4,7 +4,7 @@
 static const char* const kSymbols[] = {
     "tf_version", "tf_symbol_count", "tf_symbol_name",
     "tf_targets_workspace_bytes", "tf_dense_overlap_targets", "tf_dense_overlap_iou",
-    "tf_nms_workspace_bytes", "tf_nms_f64",
+    "tf_nms_workspace_bytes", "tf_nms_f64", "tf_nms_batched_workspace_bytes", "tf_nms_f64_batched",
     "tf_decode_workspace_bytes", "tf_decode_compact",
     "tf_criterion_workspace_bytes", "tf_criterion_fwd_bwd",
     "tf_sgd_step", "tf_image_prepare",
@@ -18,7 +18,7 @@ static const char* const kSymbols[] = {
     "tf_probe_tr16", "tf_set_stat_rows", "tf_get_stat_rows", "tf_profile_enable", "tf_profile_collect", "tf_profile_shapes",
 };
 
-extern "C" int tf_version(void) { return 100; }
+extern "C" int tf_version(void) { return 200; }
 static int g_stat_rows = 8;
 extern "C" int tf_set_stat_rows(int rows) { g_stat_rows = rows <= 0 ? (1 << 30) : (rows > TF_STAT_ROWS ? TF_STAT_ROWS : rows); return TF_OK; }
 extern "C" int tf_get_stat_rows(void) { return g_stat_rows; }

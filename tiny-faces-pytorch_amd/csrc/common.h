@@ -40,6 +40,21 @@ template <> struct Elem<bf16_t> {
   __device__ static __forceinline__ void store(bf16_t* p, float v) { p->v = f32_to_bf16(v); }
 };
 
+// IEEE half (configs[4]: fp16 MFMA operands for the hard-setting evaluation): round-to-nearest-even, overflow -> inf like torch
+struct f16_t { uint16_t v; };
+__device__ __forceinline__ float f16_to_f32(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+__device__ __forceinline__ uint16_t f32_to_f16(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) { return (uint32_t)f32_to_f16(lo) | ((uint32_t)f32_to_f16(hi) << 16); }
+template <> struct Elem<f16_t> {
+  static constexpr int kPer16B = 8;
+  __device__ static __forceinline__ float load(const f16_t* p) { return f16_to_f32(p->v); }
+  __device__ static __forceinline__ void store(f16_t* p, float v) { p->v = f32_to_f16(v); }
+};
+// two floats -> one 32-bit word of the 2-byte storage type
+template <typename T> __device__ __forceinline__ uint32_t pack2(float lo, float hi);
+template <> __device__ __forceinline__ uint32_t pack2<bf16_t>(float lo, float hi) { return pack_bf16x2(lo, hi); }
+template <> __device__ __forceinline__ uint32_t pack2<f16_t>(float lo, float hi) { return pack_f16x2(lo, hi); }
+
 // unpack a 16-byte register into floats and back
 template <typename T> __device__ __forceinline__ void unpack16(const uint4& r, float* f);
 template <> __device__ __forceinline__ void unpack16<float>(const uint4& r, float* f) {
@@ -51,12 +66,22 @@ template <> __device__ __forceinline__ void unpack16<bf16_t>(const uint4& r, flo
   f[4] = __uint_as_float(r.z << 16); f[5] = __uint_as_float(r.z & 0xffff0000u);
   f[6] = __uint_as_float(r.w << 16); f[7] = __uint_as_float(r.w & 0xffff0000u);
 }
+template <> __device__ __forceinline__ void unpack16<f16_t>(const uint4& r, float* f) {
+  f[0] = f16_to_f32((uint16_t)r.x); f[1] = f16_to_f32((uint16_t)(r.x >> 16));
+  f[2] = f16_to_f32((uint16_t)r.y); f[3] = f16_to_f32((uint16_t)(r.y >> 16));
+  f[4] = f16_to_f32((uint16_t)r.z); f[5] = f16_to_f32((uint16_t)(r.z >> 16));
+  f[6] = f16_to_f32((uint16_t)r.w); f[7] = f16_to_f32((uint16_t)(r.w >> 16));
+}
 template <typename T> __device__ __forceinline__ uint4 pack16(const float* f);
 template <> __device__ __forceinline__ uint4 pack16<float>(const float* f) {
   return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
 }
 template <> __device__ __forceinline__ uint4 pack16<bf16_t>(const float* f) {
   return make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
+}
+
+template <> __device__ __forceinline__ uint4 pack16<f16_t>(const float* f) {
+  return make_uint4(pack_f16x2(f[0], f[1]), pack_f16x2(f[2], f[3]), pack_f16x2(f[4], f[5]), pack_f16x2(f[6], f[7]));
 }
 
 __device__ __forceinline__ double wave_sum(double v) {

@@ -363,7 +363,7 @@ int pick_tile(const tf_conv_args* a) {
     // everything else 64x64 with the ring depth chosen by K.  The choice lives HERE so that tf_conv_mtiles agrees with the launch.
     static const bool t12_off = getenv("TINYFACES_T12_SHORTK_OFF") != nullptr;
     const int nst = a->KH * a->KW * (a->Cin / 64);
-    if (!t12_off && a->dtype == TF_BF16 && nst <= 4) return 32;
+    if (!t12_off && a->dtype != TF_F32 && nst <= 4) return 32;
     return 13;
   }
   return t2 >= 256 ? 2 : 3;                       // producer-BN prologue needs the register-staged kernel
@@ -383,8 +383,9 @@ extern "C" int tf_conv_mtiles(const tf_conv_args* a) {
 extern "C" int tf_conv2d(const tf_conv_args* a, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!a || !a->x || !a->w || !a->y) return TF_ERR_ARG;
-  const int kch = a->dtype == TF_BF16 ? 64 : 32;
-  if (a->dtype != TF_BF16 && a->dtype != TF_F32) return TF_ERR_UNSUPPORTED;
+  const int kch = a->dtype == TF_F32 ? 32 : 64;
+  if (a->dtype != TF_BF16 && a->dtype != TF_F32 && a->dtype != TF_F16) return TF_ERR_UNSUPPORTED;
+  if (a->dtype == TF_F16 && (a->pro_scale || (a->tile && a->tile < 10))) return TF_ERR_UNSUPPORTED;   // fp16: the LDS-DMA kernel only
   if (a->Cin % kch != 0 || a->ldy % 4 != 0 || a->ldy < a->Cout) return TF_ERR_ARG;
   if (a->stride != 1 && a->stride != 2) return TF_ERR_UNSUPPORTED;
   if ((a->epi & (TF_EPI_STATS | TF_EPI_STATS2 | TF_EPI_STATS3)) && !a->stat_out) return TF_ERR_ARG;

@@ -60,6 +60,26 @@ template <> struct MmaD<tf::bf16_t> {
     }
   }
 };
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <> struct MmaD<tf::f16_t> {              // BASELINE.json configs[4]: fp16 MFMA (v_mfma_f32_16x16x32_f16), same fragment layout as bf16
+  static constexpr int KCH = 64;
+  template <int NF, int MF>
+  __device__ static __forceinline__ void stage(const char* xs, const char* ws, int xrow0, int wrow0, f32x4 (&acc)[NF][MF]) {
+    const int l = threadIdx.x & 63, r = l & 15, g = l >> 4;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      f16x8 xf[MF], wf[NF];
+#pragma unroll
+      for (int m = 0; m < MF; ++m) xf[m] = *reinterpret_cast<const f16x8*>(xs + lds_off(xrow0 + m * 16 + r, ks * 4 + g));
+#pragma unroll
+      for (int n = 0; n < NF; ++n) wf[n] = *reinterpret_cast<const f16x8*>(ws + lds_off(wrow0 + n * 16 + r, ks * 4 + g));
+#pragma unroll
+      for (int n = 0; n < NF; ++n)
+#pragma unroll
+        for (int m = 0; m < MF; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[n], xf[m], acc[n][m], 0, 0, 0);
+    }
+  }
+};
 template <> struct MmaD<float> {
   static constexpr int KCH = 32;
   template <int NF, int MF>
@@ -380,8 +400,8 @@ int launch_kind(const tf_conv_args* A, hipStream_t stream) {
     if (A->epi & TF_EPI_JOIN) bytes += 2 * M * A->Cout * es;
     if (A->epi & TF_EPI_MASK2) bytes += M * A->Cout * es;
     if (A->epi & TF_EPI_STATS3) bytes += M * A->Cout * es;
-    tf::ProfScope prof(sizeof(T) == 2 ? 13 : 12, 2.0 * M * A->Cout * Kt, bytes, stream, k.M, A->Cout, k.Ktot, A->KH * A->KW, A->mode,
-                       A->epi);   // 12 = conv_dma f32, 13 = conv_dma bf16
+    tf::ProfScope prof(A->dtype == TF_F32 ? 12 : (A->dtype == TF_BF16 ? 13 : 15), 2.0 * M * A->Cout * Kt, bytes, stream, k.M, A->Cout, k.Ktot,
+                       A->KH * A->KW, A->mode, A->epi);   // 12 = conv_dma f32, 13 = conv_dma bf16, 15 = conv_dma f16
     hipLaunchKernelGGL((conv_dma_kernel<T, BM, BN, NS, KIND>), dim3(mtiles * k.ntiles), dim3(256), lds, stream, k);
   }
   return hipGetLastError() == hipSuccess ? TF_OK : TF_ERR_LAUNCH;
@@ -394,6 +414,29 @@ int launch(const tf_conv_args* A, hipStream_t stream) {
   return A->mode == 0 ? launch_kind<T, BM, BN, NS, 0>(A, stream) : launch_kind<T, BM, BN, NS, 2>(A, stream);
 }
 
+// the 2-byte operand types (bf16, fp16) share every tile / ring-depth decision
+template <typename T>
+int launch_half(const tf_conv_args* a, int tile, int depth, hipStream_t stream) {
+  if (tile == 1) return launch<T, 128, 128, 3>(a, stream);
+  if (tile == 2) {
+    if (depth == 1) return launch<T, 128, 64, 1>(a, stream);       // tile code 32: ring-less, short K (see pick_tile)
+    return depth == 4 ? launch<T, 128, 64, 4>(a, stream) : launch<T, 128, 64, 3>(a, stream);
+  }
+  if (depth == 3) {
+    // convs of up to 16 K-stages (every 1x1 of the trunk, K <= 1024) are dispatch + prologue + epilogue bound rather than
+    // K-loop bound: a 2-deep ring is 32 KiB of LDS, so five blocks fit a CU instead of three and more of those phases
+    // overlap.  A/B on one box, img/s: 956 (3-deep everywhere), 989 (<= 4 stages), 996 (<= 8), 1008 (<= 16), 1001 (all).
+    static const int ns2_max = [] { const char* e = getenv("TINYFACES_NS2_MAXSTAGES"); return e ? atoi(e) : 16; }();
+    const int nst = a->KH * a->KW * (a->Cin / 64);
+    // ... and no ring at all up to 4 stages (17 KiB of LDS, 8 blocks/CU): 1007 -> 1013 img/s
+    static const int ns1_max = [] { const char* e = getenv("TINYFACES_NS1_MAXSTAGES"); return e ? atoi(e) : 4; }();
+    if (nst <= ns1_max) return launch<T, 64, 64, 1>(a, stream);
+    if (nst <= ns2_max) return launch<T, 64, 64, 2>(a, stream);
+    return launch<T, 64, 64, 3>(a, stream);
+  }
+  return launch<T, 64, 64, 4>(a, stream);
+}
+
 }  // namespace
 
 // tile: 1 = 128x128, 2 = 128x64, 3 = 64x64 (pixels x channels); depth: ring stages (3 or 4; 1 = ring-less 128x64)
@@ -401,26 +444,8 @@ int tf_conv_dma_launch(const tf_conv_args* a, int tile, int depth, hipStream_t s
   // (64x128, 64x256, 128x128x4 and 128x256 tiles were measured and lost to 64x64x3 on every layer shape:
   //  profiles/r01c_microbench_wide_tiles.txt; they were removed again.)
   if (tile > 3) return TF_ERR_UNSUPPORTED;
-  if (a->dtype == TF_BF16) {
-    if (tile == 1) return launch<tf::bf16_t, 128, 128, 3>(a, stream);
-    if (tile == 2) {
-      if (depth == 1) return launch<tf::bf16_t, 128, 64, 1>(a, stream);       // tile code 32: ring-less, short K (see pick_tile)
-      return depth == 4 ? launch<tf::bf16_t, 128, 64, 4>(a, stream) : launch<tf::bf16_t, 128, 64, 3>(a, stream);
-    }
-    if (depth == 3) {
-      // convs of up to 16 K-stages (every 1x1 of the trunk, K <= 1024) are dispatch + prologue + epilogue bound rather than
-      // K-loop bound: a 2-deep ring is 32 KiB of LDS, so five blocks fit a CU instead of three and more of those phases
-      // overlap.  A/B on one box, img/s: 956 (3-deep everywhere), 989 (<= 4 stages), 996 (<= 8), 1008 (<= 16), 1001 (all).
-      static const int ns2_max = [] { const char* e = getenv("TINYFACES_NS2_MAXSTAGES"); return e ? atoi(e) : 16; }();
-      const int nst = a->KH * a->KW * (a->Cin / 64);
-      // ... and no ring at all up to 4 stages (17 KiB of LDS, 8 blocks/CU): 1007 -> 1013 img/s
-      static const int ns1_max = [] { const char* e = getenv("TINYFACES_NS1_MAXSTAGES"); return e ? atoi(e) : 4; }();
-      if (nst <= ns1_max) return launch<tf::bf16_t, 64, 64, 1>(a, stream);
-      if (nst <= ns2_max) return launch<tf::bf16_t, 64, 64, 2>(a, stream);
-      return launch<tf::bf16_t, 64, 64, 3>(a, stream);
-    }
-    return launch<tf::bf16_t, 64, 64, 4>(a, stream);
-  }
+  if (a->dtype == TF_BF16) return launch_half<tf::bf16_t>(a, tile, depth, stream);
+  if (a->dtype == TF_F16) return launch_half<tf::f16_t>(a, tile, depth, stream);
   if (tile == 1) return launch<float, 128, 128, 3>(a, stream);
   if (tile == 2) return launch<float, 128, 64, 3>(a, stream);
   return launch<float, 64, 64, 4>(a, stream);

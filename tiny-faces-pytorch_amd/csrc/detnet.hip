@@ -118,7 +118,7 @@ const Arch& arch() {
 }
 
 inline int down2(int n) { return (n - 1) / 2 + 1; }   // every stride-2 stage of the trunk: ceil(n/2)
-inline size_t esize(int dtype) { return dtype == TF_BF16 ? 2 : 4; }
+inline size_t esize(int dtype) { return dtype == TF_F32 ? 4 : 2; }
 inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Arena {
@@ -408,7 +408,8 @@ extern "C" size_t tf_detnet_param_region_bytes(int dtype, int nout, int training
 extern "C" int tf_detnet_forward(int dtype, int training, const float* x, int N, int H, int W, int nout, void* const* params, float eps,
                                  float mom, float* out, void* ws, size_t ws_bytes, int flags, void* stream_) {
   if (!x || !params || !out || !ws || nout <= 0 || nout > kHeadLd) return TF_ERR_ARG;
-  if (dtype != TF_BF16 && dtype != TF_F32) return TF_ERR_UNSUPPORTED;
+  if (dtype != TF_BF16 && dtype != TF_F32 && dtype != TF_F16) return TF_ERR_UNSUPPORTED;
+  if (dtype == TF_F16 && training) return TF_ERR_UNSUPPORTED;       // fp16 operands: the inference graph only (BASELINE.json configs[4])
   const Arch& A = arch();
   Plan P; Arena ar(ws, ws_bytes);
   build_plan(P, ar, dtype, N, H, W, nout, training);
@@ -598,6 +599,7 @@ extern "C" int tf_detnet_set_dual_stream(int on) { g_force_single = !on; return 
 extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W, int nout, void* const* params, void* const* grads,
                                   const float* gout, void* grad_flat, size_t grad_flat_bytes, void* ws, size_t ws_bytes, void* stream_) {
   if (!x || !params || !grads || !gout || !ws) return TF_ERR_ARG;
+  if (dtype != TF_BF16 && dtype != TF_F32) return TF_ERR_UNSUPPORTED;
   const Arch& A = arch();
   Plan P; Arena ar(ws, ws_bytes);
   build_plan(P, ar, dtype, N, H, W, nout, 1);

@@ -81,8 +81,8 @@ __global__ void __launch_bounds__(256) pack2_kernel(const Pack2Jobs jobs, int nj
   auto store4 = [](T* p, float a, float b, float c_, float d) {
     if constexpr (sizeof(T) == 2) {
       uint2 q;
-      q.x = tf::pack_bf16x2(a, b);
-      q.y = tf::pack_bf16x2(c_, d);
+      q.x = tf::pack2<T>(a, b);
+      q.y = tf::pack2<T>(c_, d);
       *reinterpret_cast<uint2*>(p) = q;
     } else {
       *reinterpret_cast<float4*>(p) = make_float4(a, b, c_, d);
@@ -621,6 +621,7 @@ inline unsigned grid_for(size_t total) {
   do {                                                          \
     if ((dtype) == TF_BF16) { using T = tf::bf16_t; __VA_ARGS__; } \
     else if ((dtype) == TF_F32) { using T = float; __VA_ARGS__; }  \
+    else if ((dtype) == TF_F16) { using T = tf::f16_t; __VA_ARGS__; } \
     else return TF_ERR_UNSUPPORTED;                             \
   } while (0)
 
@@ -677,7 +678,7 @@ extern "C" int tf_pack_weights_tiled(int dtype, const tf_pack2_job* host_jobs, i
 extern "C" int tf_stem_im2col(const float* x_nchw, int N, int H, int W, int dtype, void* col, int ldc, void* stream) {
   if (!x_nchw || !col || ldc < 147 || ldc % 8) return TF_ERR_ARG;
   const int OH = (H + 6 - 7) / 2 + 1, OW = (W + 6 - 7) / 2 + 1;
-  const size_t total = (size_t)N * OH * OW * (ldc / (dtype == TF_BF16 ? 8 : 4));
+  const size_t total = (size_t)N * OH * OW * (ldc / (dtype == TF_F32 ? 4 : 8));
   (void)total;
   const unsigned tiles = (unsigned)N * ((OH + kI2cT - 1) / kI2cT) * ((OW + kI2cT - 1) / kI2cT);
   DISPATCH_T(dtype, hipLaunchKernelGGL(stem_im2col_kernel<T>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, x_nchw, N, H, W, OH, OW, (T*)col,
@@ -690,7 +691,7 @@ extern "C" int tf_maxpool_fwd(int dtype, const void* x, int N, int H, int W, int
                               uint8_t* argmax, void* stream) {
   if (!x || !y || C % 8) return TF_ERR_ARG;
   const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
-  const size_t total = (size_t)N * OH * OW * (C / (dtype == TF_BF16 ? 8 : 4));
+  const size_t total = (size_t)N * OH * OW * (C / (dtype == TF_F32 ? 4 : 8));
   DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const T*)x, N, H, W, C,
                                        scale, shift, (T*)y, argmax, OH, OW));
   TF_CHECK_LAUNCH();
@@ -701,7 +702,7 @@ extern "C" int tf_maxpool_bwd(int dtype, const void* g, const uint8_t* argmax, c
                               int H, int W, int C, void* gz, void* stream) {
   if (!g || !argmax || !x || !scale || !shift || !gz || C % 8) return TF_ERR_ARG;
   const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
-  const size_t total = (size_t)N * H * W * (C / (dtype == TF_BF16 ? 8 : 4));
+  const size_t total = (size_t)N * H * W * (C / (dtype == TF_F32 ? 4 : 8));
   DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const T*)g, argmax,
                                        (const T*)x, scale, shift, N, H, W, C, OH, OW, (T*)gz));
   TF_CHECK_LAUNCH();
@@ -710,7 +711,7 @@ extern "C" int tf_maxpool_bwd(int dtype, const void* g, const uint8_t* argmax, c
 
 // rows handled by one colstats block: aim at ~1024 blocks (chip-filling), multiple of the rows in flight
 static int colstats_rows(int M, int C, int dtype) {
-  const int eps = dtype == TF_BF16 ? 8 : 4;
+  const int eps = dtype == TF_F32 ? 4 : 8;
   int rt = 256 / (C / eps);
   if (rt < 1) rt = 1;
   int rows = (M + 1023) / 1024;
@@ -725,7 +726,7 @@ extern "C" int tf_colstats_blocks(int M, int C, int dtype) {       // partial RO
 
 extern "C" int tf_colstats(int dtype, const void* g, const void* y, const void* a, const void* b, int M, int C, int ld, float* partial,
                            void* stream) {
-  const int eps = dtype == TF_BF16 ? 8 : 4;
+  const int eps = dtype == TF_F32 ? 4 : 8;
   if (!g || !partial || C % eps || C / eps > 256 || 256 % (C / eps)) return TF_ERR_ARG;
   const int nk = b ? 3 : (a ? 2 : 1);
   const int rt = 256 / (C / eps);
@@ -773,7 +774,7 @@ extern "C" int tf_bn_bwd_finalize(const float* partial, int nblk, int nk, int ki
 extern "C" int tf_bn_bwd_apply(int dtype, const void* g, const void* y, const void* x, const float* cA, const float* cB, const float* cD,
                                int64_t M, int C, void* out, void* stream) {
   if (!g || !x || !out || C % 8) return TF_ERR_ARG;
-  const size_t total = (size_t)M * (C / (dtype == TF_BF16 ? 8 : 4));
+  const size_t total = (size_t)M * (C / (dtype == TF_F32 ? 4 : 8));
   DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const T*)g, (const T*)y,
                                        (const T*)x, cA, cB, cD, (size_t)M, C, (T*)out));
   TF_CHECK_LAUNCH();
@@ -783,7 +784,7 @@ extern "C" int tf_bn_bwd_apply(int dtype, const void* g, const void* y, const vo
 extern "C" int tf_bn_add_relu(int dtype, const void* x, const float* s1, const float* h1, const void* r, const float* s2, const float* h2,
                               int64_t M, int C, void* y, void* stream) {
   if (!x || !r || !y || !s1 || !h1 || C % 8) return TF_ERR_ARG;
-  const size_t total = (size_t)M * (C / (dtype == TF_BF16 ? 8 : 4));
+  const size_t total = (size_t)M * (C / (dtype == TF_F32 ? 4 : 8));
   if (s2 && h2) {
     DISPATCH_T(dtype, hipLaunchKernelGGL((bn_add_relu_kernel<T, true>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const T*)x, s1,
                                          h1, (const T*)r, s2, h2, (size_t)M, C, (T*)y));
@@ -797,7 +798,7 @@ extern "C" int tf_bn_add_relu(int dtype, const void* x, const float* s1, const f
 
 extern "C" int tf_bn_relu(int dtype, const void* x, const float* scale, const float* shift, int64_t M, int C, void* y, void* stream) {
   if (!x || !y || !scale || !shift || C % 8) return TF_ERR_ARG;
-  const size_t total = (size_t)M * (C / (dtype == TF_BF16 ? 8 : 4));
+  const size_t total = (size_t)M * (C / (dtype == TF_F32 ? 4 : 8));
   DISPATCH_T(dtype, hipLaunchKernelGGL(bn_relu_kernel<T>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const T*)x, scale, shift,
                                        (size_t)M, C, (T*)y));
   TF_CHECK_LAUNCH();

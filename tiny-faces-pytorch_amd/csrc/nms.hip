@@ -8,17 +8,33 @@
 //   3 scan        one workgroup walks the 64-box chunks in order: wave 0 resolves the chunk's
 //                 diagonal 64x64 block in registers (readlane broadcast), then all waves OR the
 //                 kept rows into the running `removed` bit-vector held in LDS.
+//
+// Batched form (tf_nms_f64_batched, configs[4] "batched multi-scale NMS"): S independent candidate lists (one per image of an
+// evaluation batch, or one per pyramid level) in ONE set of three launches: segment s owns boxes [off[s], off[s+1]); blockIdx.y /
+// .z selects the segment, so the serial scans of different segments run side by side on different CUs instead of back to back.
 #include "common.h"
 
 namespace {
 
+constexpr int kMaxSeg = TF_NMS_MAX_SEGMENTS;
+struct Segs {                     // passed by value as a kernel argument: no H2D copy, no device-side table to keep alive
+  int off[kMaxSeg + 1];           // box offsets
+  unsigned long long moff[kMaxSeg];   // offset (in 64-bit words) of the segment's bit matrix
+};
+
 // rank[i] = #{j : s_j > s_i or (s_j == s_i and j < i)} == position of i in the stable descending argsort
 // (evaluation.py:84 -> torchvision nms sorts by score; ties keep input order).  32 boxes x 8 column slices per block:
 // lanes with the same slice read the same LDS word (broadcast), so a wave touches two addresses per step.
-__global__ void __launch_bounds__(256) nms_rank_kernel(const double* __restrict__ scores, const double* __restrict__ boxes,
-                                                       int n, int* __restrict__ order, double* __restrict__ sboxes) {
+__global__ void __launch_bounds__(256) nms_rank_kernel(const double* __restrict__ scores_all, const double* __restrict__ boxes_all,
+                                                       const Segs sg, int* __restrict__ order_all, double* __restrict__ sboxes_all) {
   __shared__ double tile[2048];
   __shared__ int part[8][32];
+  const int base = sg.off[blockIdx.y], n = sg.off[blockIdx.y + 1] - base;
+  if ((int)blockIdx.x * 32 >= n) return;                 // block-uniform: the grid is sized for the largest segment
+  const double* scores = scores_all + base;
+  const double* boxes = boxes_all + 4 * (size_t)base;
+  int* order = order_all + base;
+  double* sboxes = sboxes_all + 4 * (size_t)base;
   const int li = threadIdx.x & 31, p = threadIdx.x >> 5;
   const int i = blockIdx.x * 32 + li;
   const double si = i < n ? scores[i] : 0.0;
@@ -47,10 +63,13 @@ __global__ void __launch_bounds__(256) nms_rank_kernel(const double* __restrict_
   }
 }
 
-__global__ void __launch_bounds__(64) nms_mask_kernel(const double* __restrict__ sboxes, int n, double thr, int nwords,
-                                                      unsigned long long* __restrict__ mask) {
+__global__ void __launch_bounds__(64) nms_mask_kernel(const double* __restrict__ sboxes_all, const Segs sg, double thr,
+                                                      unsigned long long* __restrict__ mask_all) {
+  const int base = sg.off[blockIdx.z], n = sg.off[blockIdx.z + 1] - base, nwords = (n + 63) / 64;
   const int rb = blockIdx.y, cb = blockIdx.x;
-  if (cb < rb) return;                       // lower triangle never read
+  if (cb < rb || cb >= nwords) return;       // lower triangle never read; grid sized for the largest segment
+  const double* sboxes = sboxes_all + 4 * (size_t)base;
+  unsigned long long* mask = mask_all + sg.moff[blockIdx.z];
   __shared__ double cbox[64][4];
   __shared__ double carea[64];
   const int t = threadIdx.x;
@@ -88,9 +107,18 @@ __global__ void __launch_bounds__(64) nms_mask_kernel(const double* __restrict__
 // range) pair has its own thread): the trailing threads fetch the 13 rows of chunk c while wave 0 is still resolving it and
 // only select + OR them once its keep bits are known, so the push carries no memory latency either.
 template <bool PREFETCH>
-__global__ void __launch_bounds__(1024) nms_scan_kernel(const unsigned long long* __restrict__ mask, const int* __restrict__ order,
-                                                        int n, int nwords, int64_t* __restrict__ keep, int* __restrict__ num_keep) {
+__global__ void __launch_bounds__(1024) nms_scan_kernel(const unsigned long long* __restrict__ mask_all, const int* __restrict__ order_all,
+                                                        const Segs sg, int nw_lo, int nw_hi, int64_t* __restrict__ keep_all,
+                                                        int* __restrict__ num_keep_all) {
   extern __shared__ unsigned long long removed[];   // nwords + 2: [nwords] / [nwords+1] = keep bits of even / odd chunks
+  const int base = sg.off[blockIdx.x], n = sg.off[blockIdx.x + 1] - base, nwords = (n + 63) / 64;
+  // the two instantiations split the segments by size (nw_lo < nwords <= nw_hi); an empty segment keeps nothing
+  if (n == 0) { if (threadIdx.x == 0 && nw_lo < 0) num_keep_all[blockIdx.x] = 0; return; }
+  if (nwords <= nw_lo || nwords > nw_hi) return;
+  const unsigned long long* mask = mask_all + sg.moff[blockIdx.x];
+  const int* order = order_all + base;
+  int64_t* keep = keep_all + base;
+  int* num_keep = num_keep_all + blockIdx.x;
   for (int w = threadIdx.x; w < nwords + 2; w += blockDim.x) removed[w] = 0;
   __syncthreads();
   int kcount = 0;                                    // meaningful in wave 0 only
@@ -137,7 +165,7 @@ __global__ void __launch_bounds__(1024) nms_scan_kernel(const unsigned long long
         cand &= ~(d | (1ull << b));
       }
       const bool mine = (kb >> lane) & 1ull;
-      if (mine) keep[kcount + __popcll(kb & ((1ull << lane) - 1ull))] = (int64_t)oi;
+      if (mine) keep[kcount + __popcll(kb & ((1ull << lane) - 1ull))] = (int64_t)(base + oi);   // index into the concatenated input
       kcount += __popcll(kb);
       // rows kept in this chunk -> removed[c+1] (the only word the next resolve needs from this chunk)
       if (mine && next && c + 1 < nwords) atomicOr(&removed[c + 1], next);     // LDS atomics: cheaper than a 64-bit wave OR-reduction
@@ -189,31 +217,76 @@ __global__ void __launch_bounds__(1024) nms_scan_kernel(const unsigned long long
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-extern "C" size_t tf_nms_workspace_bytes(int n) {
-  if (n <= 0) return 256;
-  size_t nwords = (size_t)(n + 63) / 64;
-  return align256((size_t)n * 4) + align256((size_t)n * 32) + align256((size_t)n * nwords * 8) + 256;
+static size_t nms_mask_words(const int* off, int S, unsigned long long* moff) {
+  size_t words = 0;
+  for (int s = 0; s < S; ++s) {
+    const size_t n = (size_t)(off[s + 1] - off[s]);
+    if (moff) moff[s] = words;
+    words += n * ((n + 63) / 64);
+  }
+  return words;
 }
 
-extern "C" int tf_nms_f64(const double* boxes, const double* scores, int n, double iou_thresh,
-                          int64_t* keep_out, int32_t* num_keep, void* ws, size_t ws_bytes, void* stream_) {
+extern "C" size_t tf_nms_batched_workspace_bytes(const int32_t* host_seg_offsets, int num_segments) {
+  if (!host_seg_offsets || num_segments <= 0) return 256;
+  const size_t n = (size_t)host_seg_offsets[num_segments];
+  return align256(n * 4) + align256(n * 32) + align256(nms_mask_words(host_seg_offsets, num_segments, nullptr) * 8) + 256;
+}
+
+extern "C" size_t tf_nms_workspace_bytes(int n) {
+  if (n <= 0) return 256;
+  const int32_t off[2] = {0, n};
+  return tf_nms_batched_workspace_bytes(off, 1);
+}
+
+extern "C" int tf_nms_f64_batched(const double* boxes, const double* scores, const int32_t* host_seg_offsets, int num_segments,
+                                  double iou_thresh, int64_t* keep_out, int32_t* num_keep, void* ws, size_t ws_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (n < 0 || !num_keep) return TF_ERR_ARG;
-  if (n == 0) return hipMemsetAsync(num_keep, 0, 4, stream) == hipSuccess ? TF_OK : TF_ERR_LAUNCH;
+  const int S = num_segments;
+  if (!host_seg_offsets || S <= 0 || S > kMaxSeg || !num_keep || host_seg_offsets[0] != 0) return TF_ERR_ARG;
+  Segs sg;
+  int nmax = 0;
+  for (int s = 0; s < S; ++s) {
+    const int ns = host_seg_offsets[s + 1] - host_seg_offsets[s];
+    if (ns < 0) return TF_ERR_ARG;
+    if (ns > nmax) nmax = ns;
+  }
+  for (int s = 0; s <= kMaxSeg; ++s) sg.off[s] = host_seg_offsets[s < S ? s : S];
+  for (int s = 0; s < kMaxSeg; ++s) sg.moff[s] = 0;
+  const size_t words = nms_mask_words(host_seg_offsets, S, sg.moff);
+  const int n = host_seg_offsets[S];
+  if (n == 0) return hipMemsetAsync(num_keep, 0, 4 * (size_t)S, stream) == hipSuccess ? TF_OK : TF_ERR_LAUNCH;
   if (!boxes || !scores || !keep_out) return TF_ERR_ARG;
-  if (!ws || ws_bytes < tf_nms_workspace_bytes(n)) return TF_ERR_WORKSPACE;
-  const int nwords = (n + 63) / 64;
-  if ((size_t)(nwords + 2) * 8 > 64 * 1024) return TF_ERR_UNSUPPORTED;   // n <= 524k
+  if (!ws || ws_bytes < tf_nms_batched_workspace_bytes(host_seg_offsets, S)) return TF_ERR_WORKSPACE;
+  const int nwmax = (nmax + 63) / 64;
+  if ((size_t)(nwmax + 2) * 8 > 64 * 1024) return TF_ERR_UNSUPPORTED;   // largest segment <= 524k boxes
   char* w = (char*)ws;
   int* order = (int*)w;                 w += align256((size_t)n * 4);
   double* sboxes = (double*)w;          w += align256((size_t)n * 32);
   unsigned long long* mask = (unsigned long long*)w;
-  hipLaunchKernelGGL(nms_rank_kernel, dim3((n + 31) / 32), dim3(256), 0, stream, scores, boxes, n, order, sboxes);
-  hipLaunchKernelGGL(nms_mask_kernel, dim3(nwords, nwords), dim3(64), 0, stream, sboxes, n, iou_thresh, nwords, mask);
-  if (nwords <= 192)
-    hipLaunchKernelGGL(nms_scan_kernel<true>, dim3(1), dim3(1024), (size_t)(nwords + 2) * 8, stream, mask, order, n, nwords, keep_out, num_keep);
-  else
-    hipLaunchKernelGGL(nms_scan_kernel<false>, dim3(1), dim3(1024), (size_t)(nwords + 2) * 8, stream, mask, order, n, nwords, keep_out, num_keep);
+  (void)words;
+  hipLaunchKernelGGL(nms_rank_kernel, dim3((nmax + 31) / 32, S), dim3(256), 0, stream, scores, boxes, sg, order, sboxes);
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(nwmax, nwmax, S), dim3(64), 0, stream, sboxes, sg, iou_thresh, mask);
+  // segments of <= 192 words (12 288 boxes) take the prefetching scan, larger ones the sweeping scan; a launch whose
+  // size class is empty is skipped.  nw_lo = -1 also makes that launch the one that zeroes the count of empty segments.
+  bool any_small = false, any_large = false;
+  for (int s = 0; s < S; ++s) {
+    const int nw = (host_seg_offsets[s + 1] - host_seg_offsets[s] + 63) / 64;
+    if (nw <= 192) any_small = true; else any_large = true;
+  }
+  const size_t lds = (size_t)(nwmax + 2) * 8;
+  if (any_small)
+    hipLaunchKernelGGL(nms_scan_kernel<true>, dim3(S), dim3(1024), (size_t)((nwmax < 192 ? nwmax : 192) + 2) * 8, stream, mask, order, sg, -1, 192,
+                       keep_out, num_keep);
+  if (any_large)
+    hipLaunchKernelGGL(nms_scan_kernel<false>, dim3(S), dim3(1024), lds, stream, mask, order, sg, any_small ? 192 : -1, 1 << 30, keep_out, num_keep);
   TF_CHECK_LAUNCH();
   return TF_OK;
+}
+
+extern "C" int tf_nms_f64(const double* boxes, const double* scores, int n, double iou_thresh,
+                          int64_t* keep_out, int32_t* num_keep, void* ws, size_t ws_bytes, void* stream_) {
+  if (n < 0) return TF_ERR_ARG;
+  const int32_t off[2] = {0, n};
+  return tf_nms_f64_batched(boxes, scores, off, 1, iou_thresh, keep_out, num_keep, ws, ws_bytes, stream_);
 }

@@ -12,7 +12,7 @@ import torch  # noqa: F401  (must be imported before the .so is mapped)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtinyfaces_hip.so")
 
-TF_F32, TF_BF16 = 0, 1
+TF_F32, TF_BF16, TF_F16 = 0, 1, 2
 EPI_AFFINE, EPI_RES, EPI_RELU, EPI_STATS, EPI_MASK, EPI_STATS2, EPI_JOIN, EPI_MASK2, EPI_STATS3 = 1, 2, 4, 8, 16, 32, 64, 128, 256
 ERRORS = {-1: "TF_ERR_ARG", -2: "TF_ERR_LAUNCH", -3: "TF_ERR_UNSUPPORTED", -4: "TF_ERR_WORKSPACE"}
 
@@ -77,6 +77,8 @@ _SIGNATURES = {
     "tf_dense_overlap_iou": (i32, [vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
     "tf_nms_workspace_bytes": (sz, [i32]),
     "tf_nms_f64": (i32, [vp, vp, i32, f64, vp, vp, vp, sz, vp]),
+    "tf_nms_batched_workspace_bytes": (sz, [C.POINTER(i32), i32]),
+    "tf_nms_f64_batched": (i32, [vp, vp, C.POINTER(i32), i32, f64, vp, vp, vp, sz, vp]),
     "tf_decode_workspace_bytes": (sz, [i32, i32, i32]),
     "tf_decode_compact": (i32, [vp, i32, i32, i32, vp, i32, vp, vp, f32, f64, i32, i32, i32, i32, vp, vp, i32, vp, sz, vp]),
     "tf_criterion_workspace_bytes": (sz, [i32, i32, i32, i32]),
@@ -173,8 +175,10 @@ def tf_dtype(dtype):
         return TF_F32
     if dtype in (torch.bfloat16, "bf16", TF_BF16):
         return TF_BF16
+    if dtype in (torch.float16, "fp16", "f16", TF_F16):       # inference only (BASELINE.json configs[4])
+        return TF_F16
     raise ValueError(f"unsupported compute dtype {dtype}")
 
 
 def torch_dtype(tfd):
-    return torch.float32 if tfd == TF_F32 else torch.bfloat16
+    return {TF_F32: torch.float32, TF_BF16: torch.bfloat16, TF_F16: torch.float16}[tfd]

@@ -29,26 +29,11 @@ def _normalize_of(img_transforms):
     return None
 
 
-def get_detections(model, img, templates, rf, img_transforms, prob_thresh=0.65, nms_thresh=0.3, scales=(-2, -1, 0, 1),
-                   device=None, mask_axis="w", return_candidates=False, pyramid_on_gpu=False):
-    """evaluation.py:20-87.  Returns (K,5) float64: the reference's (K,4) rows in the same order
-    with the score re-attached as column 4 (defect D2: the reference drops it although
-    write_results reads x[4], evaluation.py:111).  mask_axis='w' reproduces defect D1
-    (tinyfaces/models/utils.py:44); 'template' masks the template axis instead.
-    pyramid_on_gpu=True (SURVEY.md 8f.3): the uint8 image goes to the device once and every pyramid level is produced there
-    by tf_image_prepare (Pillow-exact BILINEAR resize + ToTensor + Normalize in one pass) instead of PIL + torch on the host;
-    needs img_transforms = Compose([ToTensor(), Normalize(mean, std)]); same detections bit for bit."""
-    device = torch.device(device if device is not None else "cuda")
-    if device.type != "cuda":
-        raise RuntimeError("get_detections: the detector only runs on MI355X (no CPU fallback)")
-    model = model.to(device)
-    model.eval()
-    nt = templates.shape[0]
+def _pyramid_levels(img, scales, img_transforms, pyramid_on_gpu, device):
+    """evaluation.py:37-53: [(scale, normalised (1,3,H,W) tensor)] for every pyramid level of one image."""
     scales_list = [2 ** x for x in scales]
     image = transforms.to_pil_image(img)                                  # :40
     min_side = np.min(image.size)
-    t_d = torch.as_tensor(np.asarray(templates), dtype=torch.float64).contiguous().to(device)
-
     levels = []
     if pyramid_on_gpu:
         ms = _normalize_of(img_transforms)
@@ -68,18 +53,46 @@ def get_detections(model, img, templates, rf, img_transforms, prob_thresh=0.65, 
             scaled = transforms.resize(image, int(min_side * scale))
             x = img_transforms(scaled).unsqueeze(0).float()
             levels.append((scale, x))
-    cap = sum(((x.shape[2] + 7) // 8) * ((x.shape[3] + 7) // 8) for _, x in levels) * nt
-    dets = torch.empty(max(cap, 1), 5, dtype=torch.float64, device=device)
+    return levels
+
+
+def _level_capacity(levels, nt):
+    return sum(((x.shape[2] + 7) // 8) * ((x.shape[3] + 7) // 8) for _, x in levels) * nt
+
+
+def _decode_levels(model, levels, templates, t_d, rf, prob_thresh, mask_axis, dets, count, device):
+    """Forward + sigmoid / threshold / ordered compaction / refinement of every level, appended to dets[count...]."""
+    for scale, x in levels:
+        out = model(x.to(device, non_blocking=True))                  # (1, 5nt, H', W')
+        _, _, H, W = out.shape
+        vx, vt = ops.template_masks(templates, scale, W, mask_axis)
+        ops.decode_compact(out[0], t_d, torch.from_numpy(vx).to(device), torch.from_numpy(vt).to(device),
+                           prob_thresh, scale, dets, count, rf)
+
+
+def get_detections(model, img, templates, rf, img_transforms, prob_thresh=0.65, nms_thresh=0.3, scales=(-2, -1, 0, 1),
+                   device=None, mask_axis="w", return_candidates=False, pyramid_on_gpu=False):
+    """evaluation.py:20-87.  Returns (K,5) float64: the reference's (K,4) rows in the same order
+    with the score re-attached as column 4 (defect D2: the reference drops it although
+    write_results reads x[4], evaluation.py:111).  mask_axis='w' reproduces defect D1
+    (tinyfaces/models/utils.py:44); 'template' masks the template axis instead.
+    pyramid_on_gpu=True (SURVEY.md 8f.3): the uint8 image goes to the device once and every pyramid level is produced there
+    by tf_image_prepare (Pillow-exact BILINEAR resize + ToTensor + Normalize in one pass) instead of PIL + torch on the host;
+    needs img_transforms = Compose([ToTensor(), Normalize(mean, std)]); same detections bit for bit."""
+    device = torch.device(device if device is not None else "cuda")
+    if device.type != "cuda":
+        raise RuntimeError("get_detections: the detector only runs on MI355X (no CPU fallback)")
+    model = model.to(device)
+    model.eval()
+    nt = templates.shape[0]
+    t_d = torch.as_tensor(np.asarray(templates), dtype=torch.float64).contiguous().to(device)
+    levels = _pyramid_levels(img, scales, img_transforms, pyramid_on_gpu, device)
+    dets = torch.empty(max(_level_capacity(levels, nt), 1), 5, dtype=torch.float64, device=device)
     count = torch.zeros(1, dtype=torch.int32, device=device)
     biggest = max(levels, key=lambda l: l[1].shape[2] * l[1].shape[3])[1]
     # weights are constant across the pyramid (and across images when the caller already opened a session): pack once
     with torch.no_grad(), model.constant_weights(reserve=(1, biggest.shape[2], biggest.shape[3])):
-        for scale, x in levels:
-            out = model(x.to(device, non_blocking=True))                  # (1, 5nt, H', W')
-            _, _, H, W = out.shape
-            vx, vt = ops.template_masks(templates, scale, W, mask_axis)
-            ops.decode_compact(out[0], t_d, torch.from_numpy(vx).to(device), torch.from_numpy(vt).to(device),
-                               prob_thresh, scale, dets, count, rf)
+        _decode_levels(model, levels, templates, t_d, rf, prob_thresh, mask_axis, dets, count, device)
     n = int(count.item())
     assert n <= dets.shape[0]
     if n > ops.NMS_MAX_BOXES:
@@ -91,6 +104,39 @@ def get_detections(model, img, templates, rf, img_transforms, prob_thresh=0.65, 
     if return_candidates:
         return result, cand.cpu().numpy(), keep.cpu().numpy()
     return result
+
+
+def get_detections_batch(model, imgs, templates, rf, img_transforms, prob_thresh=0.65, nms_thresh=0.3, scales=(-2, -1, 0, 1),
+                         device=None, mask_axis="w", pyramid_on_gpu=False):
+    """`[get_detections(model, img, ...) for img in imgs]` (evaluation.py:20-87 once per image, as evaluate_model.py:60-68 does) with
+    the per-image NMS calls batched: every image's multi-scale candidates go into ONE device list, the per-image segments are
+    suppressed by ONE tf_nms_f64_batched call (three launches whatever the number of images; BASELINE.json configs[4]) and the
+    only host synchronisation of the whole batch is the read of the candidate counts.  Row for row identical to the loop."""
+    device = torch.device(device if device is not None else "cuda")
+    if device.type != "cuda":
+        raise RuntimeError("get_detections_batch: the detector only runs on MI355X (no CPU fallback)")
+    imgs = list(imgs)
+    if not 1 <= len(imgs) <= ops.NMS_MAX_SEGMENTS:
+        raise ValueError(f"get_detections_batch: 1..{ops.NMS_MAX_SEGMENTS} images per call, got {len(imgs)}")
+    model = model.to(device)
+    model.eval()
+    nt = templates.shape[0]
+    t_d = torch.as_tensor(np.asarray(templates), dtype=torch.float64).contiguous().to(device)
+    per_image = [_pyramid_levels(img, scales, img_transforms, pyramid_on_gpu, device) for img in imgs]
+    dets = torch.empty(max(sum(_level_capacity(lv, nt) for lv in per_image), 1), 5, dtype=torch.float64, device=device)
+    count = torch.zeros(1, dtype=torch.int32, device=device)
+    marks = torch.zeros(len(imgs) + 1, dtype=torch.int32, device=device)
+    biggest = max((l[1] for lv in per_image for l in lv), key=lambda x: x.shape[2] * x.shape[3])
+    with torch.no_grad(), model.constant_weights(reserve=(1, biggest.shape[2], biggest.shape[3])):
+        for i, levels in enumerate(per_image):
+            _decode_levels(model, levels, templates, t_d, rf, prob_thresh, mask_axis, dets, count, device)
+            marks[i + 1:i + 2].copy_(count, non_blocking=True)        # segment boundary, recorded on the stream
+    offs = marks.tolist()                                             # the one sync
+    if max(b - a for a, b in zip(offs, offs[1:])) > ops.NMS_MAX_BOXES:
+        raise RuntimeError(f"get_detections_batch: an image has more than {ops.NMS_MAX_BOXES} candidates above prob_thresh={prob_thresh}")
+    cand = dets[:offs[-1]]
+    keeps = ops.nms_batched(cand[:, :4].contiguous(), cand[:, 4].contiguous(), offs, nms_thresh)
+    return [cand[k].cpu().numpy() for k in keeps]
 
 
 def write_results(dets, img_path, split, results_dir=None):

@@ -155,7 +155,8 @@ class DetectionModel(nn.Module):
                 {"params": self.score4_upsample.parameters(), "lr": 0}]
 
     def set_compute_dtype(self, dtype):
-        """torch.float32 (exact-fp32 MFMA, parity path) or torch.bfloat16 (fast path)."""
+        """torch.float32 (exact-fp32 MFMA, parity path), torch.bfloat16 (fast path, training and inference) or torch.float16
+        (fp16 MFMA operands, inference only: the hard-setting evaluation of BASELINE.json configs[4])."""
         self.compute_dtype = _hip.tf_dtype(dtype)
         return self
 

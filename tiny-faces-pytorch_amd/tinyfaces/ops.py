@@ -135,6 +135,34 @@ def nms(boxes, scores, iou_threshold):
     return keep[: int(cnt.item())]
 
 
+NMS_MAX_SEGMENTS = 64                                     # TF_NMS_MAX_SEGMENTS (include/tinyfaces_hip.h)
+
+
+def nms_batched(boxes, scores, seg_offsets, iou_threshold):
+    """S independent NMS problems in one call (BASELINE.json configs[4]: batched multi-scale NMS): segment s = rows
+    [seg_offsets[s], seg_offsets[s+1]) of `boxes` / `scores` (float64, device) -- the multi-scale candidate list of image s of an
+    evaluation batch (one evaluation.py:80-84 per image), or one list per pyramid level.  Returns a list of S int64 tensors: the kept
+    indices INTO THE CONCATENATED INPUT of each segment, in descending-score order (torchvision.ops.nms semantics per segment)."""
+    require_gpu(boxes, "nms_batched")
+    offs = [int(o) for o in seg_offsets]
+    S = len(offs) - 1
+    if S < 1 or S > NMS_MAX_SEGMENTS or offs[0] != 0 or any(b < a for a, b in zip(offs, offs[1:])) or offs[-1] != boxes.shape[0]:
+        raise ValueError(f"nms_batched: bad segment offsets {offs[:4]}... for {boxes.shape[0]} boxes (1..{NMS_MAX_SEGMENTS} segments)")
+    boxes = boxes.to(torch.float64).contiguous()
+    scores = scores.to(torch.float64).contiguous()
+    n = offs[-1]
+    keep = torch.empty(max(n, 1), dtype=torch.int64, device=boxes.device)
+    cnt = torch.zeros(S, dtype=torch.int32, device=boxes.device)
+    host = (C.c_int32 * (S + 1))(*offs)
+    wsb = lib().tf_nms_batched_workspace_bytes(host, S)
+    ws = _workspace("nms", wsb, boxes.device)
+    with torch.cuda.device(boxes.device):
+        check(lib().tf_nms_f64_batched(ptr(boxes), ptr(scores), host, S, float(iou_threshold), ptr(keep), ptr(cnt), ptr(ws), wsb, stream()),
+              "tf_nms_f64_batched")
+    counts = cnt.tolist()
+    return [keep[offs[s]: offs[s] + counts[s]] for s in range(S)]
+
+
 # --------------------------------------------------------------------------- decode
 def template_masks(templates, scale, width, mask_axis="w"):
     """Validity masks reproducing tinyfaces/models/utils.py:17-44.  mask_axis='w' is the
