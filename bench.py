@@ -85,8 +85,8 @@ def cpu_baseline(bs=1, steps=1):
         boxes = [random_boxes(rng) for _ in range(bs)]
         t0 = time.perf_counter()
         maps = [otgt.get_heatmaps(b.copy(), t, pad) for b in boxes]
-        cm = torch.from_numpy(np.stack([c.transpose(2, 0, 1) for c, _, _ in maps])).float()
-        rm = torch.from_numpy(np.stack([r.transpose(2, 0, 1) for _, r, _ in maps])).float()
+        cm = torch.from_numpy(np.ascontiguousarray(np.stack([c.transpose(2, 0, 1) for c, _, _ in maps]))).float()
+        rm = torch.from_numpy(np.ascontiguousarray(np.stack([r.transpose(2, 0, 1) for _, r, _ in maps]))).float()
         out = m(x)
         r = ocrit.criterion(out, cm, rm)
         opt.zero_grad()

@@ -53,7 +53,7 @@ def criterion(output, class_map, regression_map, n_templates=25, reg_weight=1,
     reference mutates it in place); regression_map (B,4nt,H,W) f32.
     Returns dict(total, cls, reg, class_map_final, grad, records)."""
     output = output.detach().clone().requires_grad_(want_grad)
-    class_map = class_map.clone()
+    class_map = class_map.clone().contiguous()      # balance_sampling edits lab[b].reshape(-1) in place: needs a C-ordered view
     classification = output[:, 0:n_templates]
     regression = output[:, n_templates:]
     # hard negative mining (loss.py:59-63)

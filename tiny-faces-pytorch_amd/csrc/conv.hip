@@ -350,7 +350,9 @@ int launch_conv(const tf_conv_args* A, hipStream_t stream) {
 }
 
 // tile codes: 1/2/3 = register-staged 128x128 / 128x64 / 64x64 (pixels x channels); 11/12/13 = LDS-DMA pipeline with a
-// 3-deep ring (13: the ring depth then follows K, see tf_conv_dma_launch), 21/22/23 = 4-deep ring, 32 = ring-less 128x64.  0 = auto.
+// 3-deep ring (13: the ring depth then follows K, see tf_conv_dma_launch), 21/22/23 = 4-deep ring, 32 = ring-less 128x64;
+// x4/x5/x6 = LDS-DMA pipeline on 32x32x16 fragments, 128x128 / 128x64 / 64x128, ring depth 3 (14..16), ring-less (34..36) or 2 (44..46).
+// 0 = auto.
 int pick_tile(const tf_conv_args* a) {
   if (a->tile) return a->tile;
   // measured on the bs=12 500x500 layer shapes (scripts/microbench.py): 128 pixels x 64 channels wins on every
@@ -368,7 +370,7 @@ int pick_tile(const tf_conv_args* a) {
   }
   return t2 >= 256 ? 2 : 3;                       // producer-BN prologue needs the register-staged kernel
 }
-int tile_bm(int t) { return (t % 10) == 3 ? 64 : 128; }
+int tile_bm(int t) { return ((t % 10) == 3 || (t % 10) == 6) ? 64 : 128; }
 
 }  // namespace
 
@@ -404,7 +406,7 @@ extern "C" int tf_conv2d(const tf_conv_args* a, void* stream_) {
   const int t = pick_tile(a);
   if (t >= 10) {
     if (a->pro_scale) return TF_ERR_UNSUPPORTED;
-    return tf_conv_dma_launch(a, t % 10, t >= 30 ? 1 : (t >= 20 ? 4 : 3), stream);
+    return tf_conv_dma_launch(a, t % 10, t >= 40 ? 2 : (t >= 30 ? 1 : (t >= 20 ? 4 : 3)), stream);
   }
   if (a->epi & (TF_EPI_MASK2 | TF_EPI_STATS3)) return TF_ERR_UNSUPPORTED;      // only the LDS-DMA kernel implements them
   if (a->dtype == TF_BF16) {

@@ -17,6 +17,7 @@
 // data-gradient, conv1 / downsample / heads in training); conv.hip keeps the prologue path.
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include "common.h"
 #include "profile.h"
 
@@ -104,6 +105,39 @@ template <> struct MmaD<float> {
   }
 };
 
+// ---- 32x32x16 fragments (bf16 / fp16): a wave owns MF x NF fragments of 32 pixels x 32 channels (64 x 64 for the 128 x 128 block
+// tile).  Per 16-deep k-step a wave reads MF + NF fragments (1 KiB each) for MF*NF MFMAs of 16 384 MACs: 16 MACs per LDS byte at
+// 2 x 2 fragments, twice the 16x16x32 / 32 x 32-wave-tile form above -- the LDS read port is what bounded that form
+// (profiles/r01d_conv_dma_pipeline_ablation.txt).  Lane l holds row l & 31 and the 8 k-values of 16-byte slot 2*ks + (l >> 5); the
+// XOR swizzle h(row) is conflict-free for this read pattern too (checked exhaustively over the four ds_read_b128 lane groups).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <typename T> struct Mma32;
+template <> struct Mma32<tf::bf16_t> {
+  typedef bf16x8 frag;
+  __device__ static __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct Mma32<tf::f16_t> {
+  typedef f16x8 frag;
+  __device__ static __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+template <typename T, int NF, int MF>
+__device__ __forceinline__ void stage32(const char* xs, const char* ws, int xrow0, int wrow0, f32x16 (&acc)[NF][MF]) {
+  typedef typename Mma32<T>::frag frag;
+  const int l = threadIdx.x & 63, r = l & 31, h = l >> 5;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    frag xf[MF], wf[NF];
+#pragma unroll
+    for (int m = 0; m < MF; ++m) xf[m] = *reinterpret_cast<const frag*>(xs + lds_off(xrow0 + m * 32 + r, ks * 2 + h));
+#pragma unroll
+    for (int n = 0; n < NF; ++n) wf[n] = *reinterpret_cast<const frag*>(ws + lds_off(wrow0 + n * 32 + r, ks * 2 + h));
+#pragma unroll
+    for (int n = 0; n < NF; ++n)
+#pragma unroll
+      for (int m = 0; m < MF; ++m) acc[n][m] = Mma32<T>::mma(wf[n], xf[m], acc[n][m]);
+  }
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // 16-byte DMA: global (per-lane address) -> LDS (wave-uniform base + lane*16)
@@ -119,12 +153,16 @@ __device__ __forceinline__ void dma16(const void* gsrc, void* lds_wave_base) {
 // caps the 2-deep / ring-less variants at 4 blocks per CU).  Measured on one box: 4 and 5 waves tie (1034 img/s), 6 waves
 // spill 32-92 bytes and lose 8 %; a software-pipelined fragment loop (reads of stage s+1 under the MFMAs of stage s) added
 // +0.2 % -- at 4-5 blocks per CU the other blocks already cover a wave's LDS latency, so the simple stage() stays.
-template <typename T, int BM, int BN, int NS, int KIND>
-__global__ void __launch_bounds__(256, 5) conv_dma_kernel(const DmaK a) {
+// MMA = 16: 16x16 fragments (fp32: 16x16x4, bf16/fp16: 16x16x32), up to five blocks of waves per SIMD;
+// MMA = 32: 32x32x16 fragments (bf16/fp16), accumulators of a 64 x 64 wave tile = 64 registers -> two waves per SIMD
+//           (__launch_bounds__(256, 2): up to 256 VGPR+AGPR per lane, no spills; profiles/r02*_kernel_resources.txt)
+template <typename T, int BM, int BN, int NS, int KIND, int MMA = 16>
+__global__ void __launch_bounds__(256, MMA == 32 ? 2 : 5) conv_dma_kernel(const DmaK a) {
   constexpr int KCH = MmaD<T>::KCH;
   constexpr int EPS = tf::Elem<T>::kPer16B;
   constexpr int XR = BM / 32, WR = BN / 32;
-  constexpr int WM = BM / 2, WN = BN / 2, MF = WM / 16, NF = WN / 16;
+  constexpr int WM = BM / 2, WN = BN / 2, MF = WM / MMA, NF = WN / MMA;
+  static_assert(MMA == 16 || (sizeof(T) == 2 && WM % 32 == 0 && WN % 32 == 0), "32x32x16 fragments: 2-byte operands, 32-multiples");
   constexpr int XBYTES = BM * 128, WBYTES = BN * 128, BUF = XBYTES + WBYTES;
   constexpr int L = XR + WR;                        // DMA instructions per thread per stage
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -203,12 +241,17 @@ __global__ void __launch_bounds__(256, 5) conv_dma_kernel(const DmaK a) {
     if (KIND != 1 && ++is_c == a.cpt) { is_c = 0; if (++is_kw == a.KW) { is_kw = 0; ++is_kh; } }
   };
 
-  f32x4 acc[NF][MF];
+  typedef typename std::conditional<MMA == 32, f32x16, f32x4>::type acc_t;
+  acc_t acc[NF][MF];
 #pragma unroll
   for (int n = 0; n < NF; ++n)
 #pragma unroll
-    for (int m = 0; m < MF; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < MF; ++m) acc[n][m] = acc_t(0.f);
   const int wave = tid >> 6, wm = wave & 1, wn = wave >> 1;
+  auto compute = [&](const char* xs) {
+    if constexpr (MMA == 32) stage32<T, NF, MF>(xs, xs + XBYTES, wm * WM, wn * WN, acc);
+    else MmaD<T>::template stage<NF, MF>(xs, xs + XBYTES, wm * WM, wn * WN, acc);
+  };
 
   const int nst = a.nstages;
   if constexpr (NS == 1) {
@@ -219,7 +262,7 @@ __global__ void __launch_bounds__(256, 5) conv_dma_kernel(const DmaK a) {
       issue();
       wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();
-      MmaD<T>::template stage<NF, MF>(smem, smem + XBYTES, wm * WM, wn * WN, acc);
+      compute(smem);
     }
   } else {
 #pragma unroll
@@ -235,7 +278,7 @@ __global__ void __launch_bounds__(256, 5) conv_dma_kernel(const DmaK a) {
     __builtin_amdgcn_s_barrier();                   // everyone's pieces of stage st landed; ring slot (st-1)%NS is free
     if (st + NS - 1 < nst && !(a.dbg & 1)) issue();
     const char* xs = smem + cs * BUF;
-    if (!(a.dbg & 2)) MmaD<T>::template stage<NF, MF>(xs, xs + XBYTES, wm * WM, wn * WN, acc);
+    if (!(a.dbg & 2)) compute(xs);
     if (++cs == NS) cs = 0;
   }
   }
@@ -245,7 +288,18 @@ __global__ void __launch_bounds__(256, 5) conv_dma_kernel(const DmaK a) {
   // ---------------- epilogue, phase 1: accumulators -> fp32 [BM][BN+4] tile in LDS
   constexpr int PITCH = BN + 4;
   float* stg = reinterpret_cast<float*>(smem);
-  {
+  if constexpr (MMA == 32) {
+    // 32x32 accumulator: lane l holds pixel l & 31, channels 8*g + 4*(l >> 5) + {0..3} for g = 0..3 (registers 4g .. 4g+3)
+    const int l = tid & 63, pr = l & 31, h = l >> 5;
+#pragma unroll
+    for (int n = 0; n < NF; ++n)
+#pragma unroll
+      for (int m = 0; m < MF; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<f32x4*>(stg + (wm * WM + m * 32 + pr) * PITCH + wn * WN + n * 32 + g * 8 + h * 4) =
+              f32x4{acc[n][m][4 * g], acc[n][m][4 * g + 1], acc[n][m][4 * g + 2], acc[n][m][4 * g + 3]};
+  } else {
     const int l = tid & 63, pr = l & 15, g = l >> 4;
 #pragma unroll
     for (int n = 0; n < NF; ++n)
@@ -361,7 +415,7 @@ __global__ void __launch_bounds__(256, 5) conv_dma_kernel(const DmaK a) {
   }
 }
 
-template <typename T, int BM, int BN, int NS, int KIND>
+template <typename T, int BM, int BN, int NS, int KIND, int MMA = 16>
 int launch_kind(const tf_conv_args* A, hipStream_t stream) {
   constexpr int KCH = MmaD<T>::KCH;
   DmaK k;
@@ -390,7 +444,7 @@ int launch_kind(const tf_conv_args* A, hipStream_t stream) {
   if (stg > lds) lds = stg;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<T, BM, BN, NS, KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<T, BM, BN, NS, KIND, MMA>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   {
@@ -402,21 +456,25 @@ int launch_kind(const tf_conv_args* A, hipStream_t stream) {
     if (A->epi & TF_EPI_STATS3) bytes += M * A->Cout * es;
     tf::ProfScope prof(A->dtype == TF_F32 ? 12 : (A->dtype == TF_BF16 ? 13 : 15), 2.0 * M * A->Cout * Kt, bytes, stream, k.M, A->Cout, k.Ktot,
                        A->KH * A->KW, A->mode, A->epi);   // 12 = conv_dma f32, 13 = conv_dma bf16, 15 = conv_dma f16
-    hipLaunchKernelGGL((conv_dma_kernel<T, BM, BN, NS, KIND>), dim3(mtiles * k.ntiles), dim3(256), lds, stream, k);
+    hipLaunchKernelGGL((conv_dma_kernel<T, BM, BN, NS, KIND, MMA>), dim3(mtiles * k.ntiles), dim3(256), lds, stream, k);
   }
   return hipGetLastError() == hipSuccess ? TF_OK : TF_ERR_LAUNCH;
 }
 
-template <typename T, int BM, int BN, int NS>
+template <typename T, int BM, int BN, int NS, int MMA = 16>
 int launch(const tf_conv_args* A, hipStream_t stream) {
   const bool pointwise = A->KH == 1 && A->KW == 1 && A->stride == 1 && A->pad == 0 && A->H == A->OH && A->W == A->OW;
-  if (pointwise) return launch_kind<T, BM, BN, NS, 1>(A, stream);
-  return A->mode == 0 ? launch_kind<T, BM, BN, NS, 0>(A, stream) : launch_kind<T, BM, BN, NS, 2>(A, stream);
+  if (pointwise) return launch_kind<T, BM, BN, NS, 1, MMA>(A, stream);
+  return A->mode == 0 ? launch_kind<T, BM, BN, NS, 0, MMA>(A, stream) : launch_kind<T, BM, BN, NS, 2, MMA>(A, stream);
 }
 
 // the 2-byte operand types (bf16, fp16) share every tile / ring-depth decision
 template <typename T>
 int launch_half(const tf_conv_args* a, int tile, int depth, hipStream_t stream) {
+  // tiles 4..6: 32x32x16 fragments (64 x 64 / 64 x 32 / 32 x 64 wave tiles), ring depth 1..3
+  if (tile == 4) return depth == 1 ? launch<T, 128, 128, 1, 32>(a, stream) : depth == 2 ? launch<T, 128, 128, 2, 32>(a, stream) : launch<T, 128, 128, 3, 32>(a, stream);
+  if (tile == 5) return depth == 1 ? launch<T, 128, 64, 1, 32>(a, stream) : depth == 2 ? launch<T, 128, 64, 2, 32>(a, stream) : launch<T, 128, 64, 3, 32>(a, stream);
+  if (tile == 6) return depth == 1 ? launch<T, 64, 128, 1, 32>(a, stream) : depth == 2 ? launch<T, 64, 128, 2, 32>(a, stream) : launch<T, 64, 128, 3, 32>(a, stream);
   if (tile == 1) return launch<T, 128, 128, 3>(a, stream);
   if (tile == 2) {
     if (depth == 1) return launch<T, 128, 64, 1>(a, stream);       // tile code 32: ring-less, short K (see pick_tile)
@@ -443,7 +501,7 @@ int launch_half(const tf_conv_args* a, int tile, int depth, hipStream_t stream) 
 int tf_conv_dma_launch(const tf_conv_args* a, int tile, int depth, hipStream_t stream) {
   // (64x128, 64x256, 128x128x4 and 128x256 tiles were measured and lost to 64x64x3 on every layer shape:
   //  profiles/r01c_microbench_wide_tiles.txt; they were removed again.)
-  if (tile > 3) return TF_ERR_UNSUPPORTED;
+  if (tile > 6 || (tile > 3 && a->dtype == TF_F32)) return TF_ERR_UNSUPPORTED;
   if (a->dtype == TF_BF16) return launch_half<tf::bf16_t>(a, tile, depth, stream);
   if (a->dtype == TF_F16) return launch_half<tf::f16_t>(a, tile, depth, stream);
   if (tile == 1) return launch<float, 128, 128, 3>(a, stream);
