@@ -542,3 +542,149 @@ def test_upsample_add_crop_fwd_bwd(dtype, hw):
     report(f"upsample[{dtype},{hw}]", fwd_maxabs=d[0], g3=d3[2], g4=d4[2])
     assert d[0] < 1e-5 and d3[2] < TOL[dtype] and d4[2] < TOL[dtype]
     assert float(from_nhwc(g3)[:, C:].abs().max()) == 0
+
+
+# ------------------------------------------------------------------ 32x32x16-fragment tiles of the LDS-DMA kernel (round 2)
+MMA32_TILES = [14, 15, 16, 34, 35, 36, 44, 45, 46]       # 128x128 / 128x64 / 64x128, ring depth 3 / none / 2
+HALF = [torch.bfloat16, torch.float16]
+TOL_H = {torch.bfloat16: 6e-3, torch.float16: 1e-3}
+
+
+@pytest.mark.parametrize("dtype", HALF)
+@pytest.mark.parametrize("case", CONV_CASES + [(2, 40, 44, 256, 256, 3, 1, 1), (1, 50, 50, 1024, 256, 1, 1, 0)])
+@pytest.mark.parametrize("tile", MMA32_TILES)
+def test_conv_mma32_forward_and_dgrad(dtype, case, tile):
+    """Forward and data gradient on 32x32x16 fragments (64x64 / 64x32 / 32x64 wave tiles): every gather kind, edge tiles in M
+    and N, ring depths 1-3, against torch-CPU fp32 fed the same rounded operands."""
+    from tinyfaces import ops
+    N, H, W, Cin, Cout, K, s, p = case
+    g = _g(hash(case) % 1000)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5
+    xr = q(x, dtype).requires_grad_(True)
+    ref = F.conv2d(xr, q(w, dtype), stride=s, padding=p)
+    gy = torch.randn(ref.shape, generator=g)
+    ref.backward(q(gy, dtype))
+    y = ops.conv2d_nhwc(to_nhwc(x, dtype), ops.pack_weight(w.cuda(), dtype), Cout, K, K, s, p, tile=tile)
+    d = err(from_nhwc(y)[:, :Cout], ref.detach())
+    gx = ops.conv2d_nhwc(to_nhwc(gy, dtype), ops.pack_weight(w.cuda(), dtype, transpose=True), Cin, K, K, s, p, mode=1, out_hw=(H, W), tile=tile)
+    dg = err(from_nhwc(gx), xr.grad)
+    report(f"conv_mma32[{dtype},{case},t{tile}]", fwd_rel=d[2], dgrad_rel=dg[2])
+    assert d[2] < TOL_H[dtype] and dg[2] < TOL_H[dtype]
+
+
+@pytest.mark.parametrize("tile", MMA32_TILES)
+def test_conv_mma32_epilogues(tile):
+    """Every epilogue of the executor on the new tiles: STATS (training forward), AFFINE+RES+RELU with a padded head (eval),
+    MASK+STATS2 and JOIN (data gradients), RES+MASK2+STATS3 (the hand-over)."""
+    from tinyfaces import _hip, ops
+    dtype = torch.bfloat16
+    g = _g(41 + tile)
+    # STATS
+    N, H, W, Cin, Cout = 2, 19, 23, 256, 128
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    ref = F.conv2d(q(x, dtype), q(w, dtype), padding=1)
+    y, st = ops.conv2d_nhwc(to_nhwc(x, dtype), ops.pack_weight(w.cuda(), dtype), Cout, 3, 3, 1, 1, epi=_hip.EPI_STATS, want_stats=True, tile=tile)
+    n = ref.numel() / Cout
+    ssum = st.sum(0).cpu()
+    assert err(from_nhwc(y), ref)[2] < TOL[dtype]
+    assert err(ssum[0] / n, ref.mean(dim=(0, 2, 3)))[0] < 2e-3 and err(ssum[1] / n, (ref ** 2).mean(dim=(0, 2, 3)))[2] < 2e-3
+    # eval epilogue, Cout = 125 in 128 columns
+    N, H, W, Cin, Cout = 2, 13, 17, 512, 125
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5
+    sc, sh = torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g)
+    res = torch.randn(N, 128, H, W, generator=g)
+    ref = torch.relu(F.conv2d(q(x, dtype), q(w, dtype)) * sc[:Cout].view(1, -1, 1, 1) + sh[:Cout].view(1, -1, 1, 1) + q(res, dtype)[:, :Cout])
+    y = ops.conv2d_nhwc(to_nhwc(x, dtype), ops.pack_weight(w.cuda(), dtype), Cout, 1, 1, 1, 0, ldy=128,
+                        epi=_hip.EPI_AFFINE | _hip.EPI_RES | _hip.EPI_RELU, epi_scale=sc.cuda(), epi_shift=sh.cuda(), aux=to_nhwc(res, dtype), tile=tile)
+    assert err(from_nhwc(y)[:, :Cout], ref)[2] < TOL[dtype]
+    # MASK + STATS2, JOIN
+    N, H, W, C1, C2 = 2, 16, 18, 256, 64
+    gy = torch.randn(N, C1, H, W, generator=g)
+    w = torch.randn(C1, C2, 1, 1, generator=g) / C2 ** 0.5
+    craw = torch.randn(N, C2, H, W, generator=g)
+    ms, mh = torch.rand(C2, generator=g) + 0.5, torch.randn(C2, generator=g) * 0.5
+    base = F.conv_transpose2d(q(gy, dtype), q(w, dtype))
+    ref = base * ((q(craw, dtype) * ms.view(1, -1, 1, 1) + mh.view(1, -1, 1, 1)) > 0)
+    wt = ops.pack_weight(w.cuda(), dtype, transpose=True)
+    y, st = ops.conv2d_nhwc(to_nhwc(gy, dtype), wt, C2, 1, 1, 1, 0, mode=1, out_hw=(H, W), epi=_hip.EPI_MASK | _hip.EPI_STATS2,
+                            aux=to_nhwc(craw, dtype), mask=(ms.cuda(), mh.cuda()), want_stats=True, tile=tile)
+    s = st.sum(0).cpu()
+    assert err(from_nhwc(y), ref)[2] < TOL[dtype]
+    assert err(s[0], ref.sum(dim=(0, 2, 3)))[2] < 5e-3 and err(s[1], (ref * q(craw, dtype)).sum(dim=(0, 2, 3)))[2] < 5e-3
+    y2, g3 = torch.randn(N, C2, H, W, generator=g), torch.randn(N, C2, H, W, generator=g)
+    yj = ops.conv2d_nhwc(to_nhwc(gy, dtype), wt, C2, 1, 1, 1, 0, mode=1, out_hw=(H, W), epi=_hip.EPI_JOIN, aux2=to_nhwc(y2, dtype),
+                         aux3=to_nhwc(g3, dtype), tile=tile)
+    assert err(from_nhwc(yj), base + q(g3, dtype) * (q(y2, dtype) > 0))[2] < TOL[dtype]
+    # hand-over: RES + MASK2 + STATS3
+    N, H, W, C1, C2 = 2, 17, 15, 64, 256
+    gy = torch.randn(N, C1, H, W, generator=g)
+    w = torch.randn(C1, C2, 1, 1, generator=g) / C2 ** 0.5
+    res, yprev = torch.randn(N, C2, H, W, generator=g), torch.randn(N, C2, H, W, generator=g)
+    c3 = torch.randn(N, C2, H, W, generator=g) * 1.5 + 0.3
+    ref = (F.conv_transpose2d(q(gy, dtype), q(w, dtype)) + q(res, dtype)) * (q(yprev, dtype) > 0)
+    y, st = ops.conv2d_nhwc(to_nhwc(gy, dtype), ops.pack_weight(w.cuda(), dtype, transpose=True), C2, 1, 1, 1, 0, mode=1, out_hw=(H, W),
+                            epi=_hip.EPI_RES | _hip.EPI_MASK2 | _hip.EPI_STATS3, aux=to_nhwc(res, dtype), aux2=to_nhwc(yprev, dtype),
+                            aux3=to_nhwc(c3, dtype), want_stats=True, tile=tile)
+    s = st.sum(0).cpu()
+    assert err(from_nhwc(y), ref)[2] < TOL[dtype]
+    assert err(s[0], ref.sum(dim=(0, 2, 3)))[2] < 5e-3 and err(s[1], (ref * q(c3, dtype)).sum(dim=(0, 2, 3)))[2] < 5e-3
+
+
+def test_conv_mma32_refuses_fp32():
+    from tinyfaces import ops
+    x = torch.randn(1, 8, 8, 64, device="cuda")
+    w = ops.pack_weight(torch.randn(64, 64, 1, 1, device="cuda"), torch.float32)
+    with pytest.raises(RuntimeError):
+        ops.conv2d_nhwc(x, w, 64, 1, 1, 1, 0, tile=14)
+
+
+# ------------------------------------------------------------------ all-taps 3x3 weight gradient (round 2, csrc/wgrad3x3.hip)
+W3_CASES = [
+    # N, H, W, Cin, Cout
+    (2, 5, 7, 64, 64),          # frame smaller than one 64-pixel stage, halo larger than an image
+    (1, 1, 1, 64, 64),          # a single pixel: only the centre tap sees data
+    (2, 20, 22, 64, 64),
+    (3, 32, 32, 256, 256),      # layer-3 shape (smaller batch): 16 tiles
+    (2, 63, 63, 128, 128),      # layer 2: halo of two chunks (W + 3 = 66 > 64)
+    (1, 125, 125, 64, 64),      # layer 1: the widest frame the 512-row ring takes
+    (2, 30, 17, 128, 192),      # rectangular, Cout not a power of two
+]
+
+
+@pytest.mark.parametrize("splitk", [0, 1, 3, 7])
+@pytest.mark.parametrize("case", W3_CASES)
+def test_wgrad3x3_all_taps(case, splitk):
+    """The zero-padded-frame reduction with nine accumulator sets vs torch autograd, for several split-K factors (slice
+    boundaries in the middle of rows / images), packed and OIHW outputs; and vs the per-tap kernel it replaces."""
+    from tinyfaces import ops
+    dtype = torch.bfloat16
+    N, H, W, Cin, Cout = case
+    g = _g(hash(case) % 997)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05).requires_grad_(True)
+    y = F.conv2d(q(x, dtype), w, padding=1)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(q(gy, dtype))
+    xd, gyd = to_nhwc(x, dtype), to_nhwc(gy, dtype)
+    dw = ops.conv2d_wgrad(xd, gyd, Cin, Cout, 3, 3, 1, 1, tile=3, splitk=splitk)
+    d = err(dw.cpu(), w.grad)
+    dwp = ops.conv2d_wgrad(xd, gyd, Cin, Cout, 3, 3, 1, 1, tile=3, splitk=splitk, packed=True)     # [Cout][tap][Cin]
+    dp = err(dwp.cpu().reshape(Cout, 9, Cin).permute(0, 2, 1).reshape(Cout, Cin, 3, 3), w.grad)
+    old = ops.conv2d_wgrad(xd, gyd, Cin, Cout, 3, 3, 1, 1, tile=1)
+    do = err(dw.cpu(), old.cpu())
+    report(f"wgrad3x3[{case},sk{splitk}]", rel=d[2], packed_rel=dp[2], vs_per_tap=do[2])
+    assert d[2] < 2e-3 and dp[2] < 2e-3 and do[2] < 1e-4
+
+
+def test_wgrad3x3_refuses_what_it_cannot_do():
+    from tinyfaces import ops
+    x = torch.randn(1, 9, 9, 64, device="cuda").to(torch.bfloat16)
+    gy = torch.randn(1, 5, 5, 64, device="cuda").to(torch.bfloat16)
+    with pytest.raises(RuntimeError):                       # stride 2: the per-tap kernel's job
+        ops.conv2d_wgrad(x, gy, 64, 64, 3, 3, 2, 1, tile=3)
+    gy1 = torch.randn(1, 9, 9, 64, device="cuda").to(torch.bfloat16)
+    with pytest.raises(RuntimeError):                       # 1x1
+        ops.conv2d_wgrad(x, gy1, 64, 64, 1, 1, 1, 0, tile=3)

@@ -87,6 +87,15 @@ def test_engine_bucket_ranges_partition_the_flat_gradient():
         bucket_of(name)
     sizes = [(e - s) * 4 / 2**20 for _, s, e in ranges]
     assert all(20 < x < 45 for x in sizes[:3]) and sizes[3] < 10, sizes      # three ~35 MB messages + a small tail
+    # the default cut of round 2 (8-12 buckets of ~10 MB in layer 3): >= bucket_mb each, contiguous, tail = layer1/2 + stem
+    firsts = TrainEngine.auto_first_blocks(seg, flat.numel(), 10)
+    r10 = TrainEngine.bucket_ranges(seg, flat.numel(), firsts)
+    assert firsts[-1] == 7 and list(firsts) == sorted(firsts, reverse=True) and 8 <= len(firsts) <= 12
+    assert r10[0][2] == flat.numel() and r10[-1][:2] == (-1, 0)
+    for (_, s0, e0), (_, s1, e1) in zip(r10, r10[1:]):
+        assert e1 == s0 and s1 < e1
+    mb = [(e - s) * 4 / 2**20 for _, s, e in r10]
+    assert all(10 <= x < 16 for x in mb[:-1]) and mb[-1] < 10, mb
 
 
 def test_wider_annotation_parser_vs_reference_golden(golden, tmp_path):
@@ -270,3 +279,58 @@ def test_entry_script_flags_match_the_reference(golden):
     got = ours("evaluate_model.py", ["DATA"])
     assert {k: got[k] for k in ref} == ref
     assert set(got) - set(ref) == {"num_images"}
+
+
+def test_wider_evaluator_reads_official_mat_layout_and_filters_by_setting(tmp_path):
+    """tinyfaces.wider_eval.evaluate end to end on a hand-built ground truth in the layout of the WIDER `eval_tools/ground_truth`
+    files (wider_face_val.mat: event_list / file_list / face_bbx_list cell arrays; wider_{easy,medium,hard}_val.mat: gt_list of
+    1-BASED keep indices) and a result tree written by the product's write_results.  Two events, three images; the settings keep
+    different subsets, one face is ignored in every setting, one image has no faces, one image has no result file.
+    Expected APs are computed by hand below (VOC envelope over the 1000 thresholds)."""
+    from scipy.io import savemat
+    from tinyfaces import wider_eval as we
+    from tinyfaces.evaluation import write_results
+
+    def cell(items):
+        c = np.empty((len(items), 1), dtype=object)
+        for i, it in enumerate(items):
+            c[i, 0] = it
+        return c
+
+    events = ["0--Parade", "1--Handshaking"]
+    files = [["0_Parade_a_1", "0_Parade_b_2"], ["1_Handshaking_c_3"]]
+    # x y w h
+    boxes = [[np.array([[10, 10, 40, 40], [100, 20, 30, 30], [200, 200, 8, 8.0]]), np.zeros((0, 4))],
+             [np.array([[50, 60, 20, 25], [150, 160, 60, 70.0]])]]
+    keep = {"easy": [[[1], []], [[2]]],                         # only the big faces
+            "medium": [[[1, 2], []], [[2]]],
+            "hard": [[[1, 2], []], [[1, 2]]]}                   # face 3 of image a (8x8 px) is ignored everywhere
+    gt_dir = tmp_path / "ground_truth"
+    gt_dir.mkdir()
+    savemat(gt_dir / "wider_face_val.mat", {
+        "event_list": cell([np.array([e]) for e in events]),
+        "file_list": cell([cell([np.array([f]) for f in fl]) for fl in files]),
+        "face_bbx_list": cell([cell(bl) for bl in boxes])})
+    for s, kl in keep.items():
+        savemat(gt_dir / f"wider_{s}_val.mat", {"gt_list": cell([cell([np.array(k, dtype=np.float64).reshape(-1, 1) for k in ke]) for ke in kl])})
+
+    # detections (x1, y1, x2, y2, score) as get_detections returns them; write_results converts to x y w h (evaluation.py:108-110)
+    res = tmp_path / "val_results"
+    dets_a = np.array([[10, 10, 49, 49, 0.9],                   # face 1 of a: IoU 1
+                       [200, 200, 207, 207, 0.8],               # the ignored 8x8 face: dropped from the precision count
+                       [300, 300, 340, 340, 0.7],               # false positive
+                       [100, 20, 129, 49, 0.6]])                # face 2 of a
+    write_results(dets_a, "0--Parade/0_Parade_a_1.jpg", "val", res)
+    write_results(np.array([[5, 5, 30, 30, 0.5]]), "0--Parade/0_Parade_b_2.jpg", "val", res)      # image without faces: a false positive
+    # (no result file for 1_Handshaking_c_3: both of its faces are misses)
+    ap = we.evaluate(str(res), str(gt_dir))
+
+    # by hand.  Scores are min-max normalised over the set: 0.9 -> 1, 0.8 -> .75, 0.7 -> .5, 0.6 -> .25, 0.5 -> 0.
+    # hard: 4 counted faces (a1, a2, c1, c2).  Walking down the thresholds: after a1: P=1/1 R=1/4; the ignored detection adds
+    # nothing; after the FP: P=1/2; after a2: P=2/3 R=2/4; after the FP of image b (score 0): P=2/4 R=2/4.
+    # envelope: precision 1 up to R=.25, then max(2/3, 2/4) = 2/3 up to R=.5, 0 beyond -> AP = .25*1 + .25*(2/3)
+    assert abs(ap["hard"] - (0.25 + 0.25 * 2 / 3)) < 1e-9
+    # medium: faces a1, a2, c2 (3).  Same detection walk: R = 1/3 at P=1, R = 2/3 at P=2/3 -> AP = 1/3 + (1/3)(2/3)
+    assert abs(ap["medium"] - (1 / 3 + (1 / 3) * (2 / 3))) < 1e-9
+    # easy: faces a1, c2 (2).  a2 is now IGNORED too: its detection no longer counts.  R = 1/2 at P=1, then only false positives.
+    assert abs(ap["easy"] - 0.5) < 1e-9

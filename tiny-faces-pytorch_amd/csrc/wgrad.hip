@@ -16,7 +16,8 @@
 #include "common.h"
 #include "profile.h"
 
-int tf_wgrad_dma_launch(const tf_wgrad_args* a, hipStream_t stream);   // wgrad_dma.hip
+int tf_wgrad_dma_launch(const tf_wgrad_args* a, hipStream_t stream);
+int tf_wgrad3x3_launch(const tf_wgrad_args* a, hipStream_t stream);       // wgrad3x3.hip   // wgrad_dma.hip
 
 namespace {
 
@@ -225,9 +226,15 @@ extern "C" int tf_conv2d_wgrad(const tf_wgrad_args* a, void* stream_) {
   const int eps = a->dtype == TF_BF16 ? 8 : 4;
   if (a->ldx % eps || a->lddy % eps || a->ldx < a->Cin || a->lddy < a->Cout) return TF_ERR_ARG;   // 16-byte slots
   if (a->pro_scale && (!a->pro_shift || a->Cin % eps)) return TF_ERR_ARG;
-  // tile: 0 = auto (LDS-DMA pipeline when bf16 and no prologue), 1 = force DMA, 64 / 128 = register-staged kernel
+  // tile: 0 = auto (bf16, no prologue: the all-taps kernel for 3x3 / stride 1 / pad 1, else the per-tap LDS-DMA pipeline),
+  //       1 = force the per-tap DMA kernel, 3 = force the all-taps kernel, 64 / 128 = register-staged kernel
+  if ((a->tile == 0 || a->tile == 3) && a->dtype == TF_BF16 && !a->pro_scale) {
+    static const bool w3_off = getenv("TINYFACES_WGRAD3_OFF") != nullptr;          // A/B knob
+    const int rc = (w3_off && a->tile == 0) ? TF_ERR_UNSUPPORTED : tf_wgrad3x3_launch(a, stream);
+    if (rc != TF_ERR_UNSUPPORTED || a->tile == 3) return rc;
+  }
   if ((a->tile == 0 || a->tile == 1) && a->dtype == TF_BF16 && !a->pro_scale) return tf_wgrad_dma_launch(a, stream);
-  if (a->tile == 1) return TF_ERR_UNSUPPORTED;
+  if (a->tile == 1 || a->tile == 3) return TF_ERR_UNSUPPORTED;
   const bool small = a->tile ? a->tile == 64 : true;   // 64x64 tiles: 4x fewer split-K partials per MFMA flop than 128x128
   if (a->dtype == TF_BF16) return small ? launch_wgrad<tf::bf16_t, 64>(a, stream) : launch_wgrad<tf::bf16_t, 128>(a, stream);
   return small ? launch_wgrad<float, 64>(a, stream) : launch_wgrad<float, 128>(a, stream);

@@ -4,8 +4,9 @@ no per-parameter Python loop and no host sync:
     targets (HIP) -> forward (HIP executor) -> criterion fwd+bwd (HIP) -> backward (HIP executor)
     -> [RCCL all-reduce of the flat gradient, overlapped with the backward pass] -> fused SGD (one launch per group)
 
-Data-parallel overlap: the flat gradient is cut into 4 buckets along the backward order (heads + layer3.15-22,
-layer3.7-14, layer3.0-6, layer1/2 + stem).  The executor records an event when a bucket's gradients are enqueued
+Data-parallel overlap: the flat gradient is cut along the backward order into buckets of ~`bucket_mb` MB (default 10: heads +
+layer3.21-22 first, then two layer-3 bottlenecks of 4.5 MB each per bucket, ..., finally layer1/2 + stem: SURVEY.md 8e asks for
+8-12 buckets of ~10 MB in layer 3).  The executor records an event when a bucket's gradients are enqueued
 (tf_detnet_set_grad_events); a communication stream waits on it and starts that bucket's all-reduce while the
 remaining bottlenecks are still being differentiated, so only the last, small bucket is exposed.
 
@@ -25,7 +26,7 @@ _events_owner = None        # id() of the engine whose events are currently regi
 
 
 class TrainEngine:
-    def __init__(self, model, criterion, lr=1e-4, momentum=0.9, weight_decay=5e-4, device="cuda", bucket_mb=32):
+    def __init__(self, model, criterion, lr=1e-4, momentum=0.9, weight_decay=5e-4, device="cuda", bucket_mb=10):
         self.device = torch.device(device)
         self.model = model.to(self.device).train()
         self.criterion = criterion
@@ -42,8 +43,26 @@ class TrainEngine:
         if parallel.is_distributed():
             self._setup_overlap()
 
-    # first bottleneck (executor index: layer1 0-2, layer2 3-6, layer3 7-29) of each bucket, in backward order
+    # first bottleneck (executor index: layer1 0-2, layer2 3-6, layer3 7-29) of each bucket, in backward order: the coarse
+    # 4-bucket cut of round 1, kept as an explicit choice (bucket_mb=0)
     _BUCKET_FIRST_BLOCK = (22, 14, 7)
+    _BLOCK_NAMES = tuple(f"model.{l}.{i}." for l, n in (("layer1", 3), ("layer2", 4), ("layer3", 23)) for i in range(n))
+
+    @classmethod
+    def auto_first_blocks(cls, segments, total, bucket_mb):
+        """First bottleneck of each bucket (backward order) so that every bucket but the last carries >= bucket_mb MB of fp32
+        gradient: walk the bottlenecks from layer3.22 down, close a bucket as soon as it is big enough; layer 1/2 + stem (6 MB)
+        always form the final bucket (event -1 = end of the backward pass)."""
+        want = bucket_mb * (1 << 20) / 4
+        firsts, end = [], total
+        for b in range(len(cls._BLOCK_NAMES) - 1, 6, -1):             # layer 3 only: 29 .. 7
+            start = min(o for k, (o, _) in segments.items() if k.startswith(cls._BLOCK_NAMES[b]))
+            if end - start >= want:
+                firsts.append(b)
+                end = start
+        if not firsts or firsts[-1] != 7:
+            firsts.append(7)                                            # whatever is left of layer 3
+        return tuple(firsts)
 
     @staticmethod
     def bucket_ranges(segments, total, first_blocks=_BUCKET_FIRST_BLOCK):
@@ -61,7 +80,9 @@ class TrainEngine:
         return ranges
 
     def _setup_overlap(self):
-        ranges = self.bucket_ranges(self.model._segments, self.flat_p.numel())
+        total = self.flat_p.numel()
+        firsts = self.auto_first_blocks(self.model._segments, total, self.bucket_elems * 4 / (1 << 20)) if self.bucket_elems > 0 else self._BUCKET_FIRST_BLOCK
+        ranges = [r for r in self.bucket_ranges(self.model._segments, total, firsts) if r[2] > r[1]]
         events = []
         for _ in ranges:
             ev = torch.cuda.Event()
