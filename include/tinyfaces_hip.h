@@ -70,6 +70,12 @@ int tf_dense_overlap_iou(const double* boxes, int G, const double* templates, in
                          int vsy, int vsx, int ofy, int ofx, int sty, int stx,
                          double* iou_out, void* stream);
 
+/* ---- template clustering: distance matrix of the k-medoids ------------------------------
+ * Replaces compute_distances (tinyfaces/clustering/cluster.py:28-37, a Python double loop over jaccard_index,
+ * tinyfaces/metrics.py:8-40): out[i][j] = 1 - IoU(boxes[i], boxes[j]) in float64, plain areas, IoU = 0 when the union is not
+ * positive; bit-exact with the reference's arithmetic.  boxes [n][4] (x1,y1,x2,y2), out [n][n]. */
+int tf_pairwise_iou_distance(const double* boxes, int n, double* out, void* stream);
+
 /* ---- greedy NMS, float64 -----------------------------------------------------------
  * Replaces torchvision.ops.nms as called at tinyfaces/evaluation.py:84 (float64 boxes and
  * scores): stable descending sort, areas without +1, strict `>` on IoU.  keep_out holds the
@@ -209,8 +215,12 @@ typedef struct tf_wgrad_args {
   int splitk;         /* 0 = auto */
   int tile;           /* 0 = auto; 64 or 128 = channels per tile side */
   int packed;         /* 1: dw is [Cout][KH*KW][Cin] (coalesced atomics; tf_unpack_dw -> OIHW) */
+  void* partial_ws;   /* optional scratch of >= tf_wgrad_workspace_bytes(a) bytes: the all-taps 3x3 kernel then reduces its split-K */
+  size_t partial_ws_bytes;   /* slices through it (plain stores + one summing kernel) instead of fp32 atomics; NULL / too small: atomics */
+  /* tile: 0 = auto, 1 = per-tap LDS-DMA kernel, 3 = all-taps 3x3 kernel (stride 1, pad 1, bf16), 64 / 128 = register-staged kernel */
 } tf_wgrad_args;
 int tf_conv2d_wgrad(const tf_wgrad_args* a, void* stream);
+size_t tf_wgrad_workspace_bytes(const tf_wgrad_args* a);   /* 0 when the all-taps kernel does not apply to `a` */
 /* [Cout][taps][Cin] fp32 -> OIHW fp32 (overwrites) */
 int tf_unpack_dw(const float* packed, int Cout, int Cin, int taps, float* dw_oihw, void* stream);
 

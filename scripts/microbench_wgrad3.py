@@ -31,5 +31,6 @@ for name, H, W, C in [("l1.c2", 125, 125, 64), ("l2.c2", 63, 63, 128), ("l3.c2",
         got = ops.conv2d_wgrad(x, gy, C, C, 3, 3, 1, 1, tile=3, splitk=sk, out=out, packed=True)
         dif = float((got - ref).abs().max() / ref.abs().max())
         us = timeit(lambda: ops.conv2d_wgrad(x, gy, C, C, 3, 3, 1, 1, tile=3, splitk=sk, out=out, packed=True))
-        line += f" | all-taps sk{sk}: {us:6.1f}us {flops/us/1e6:4.0f}TF d={dif:.0e}"
+        us2 = timeit(lambda: ops.conv2d_wgrad(x, gy, C, C, 3, 3, 1, 1, tile=3, splitk=sk, out=out, packed=True, two_phase=True))
+        line += f" | all-taps sk{sk}: atomics {us:6.1f}us, two-phase {us2:6.1f}us {flops/us2/1e6:4.0f}TF d={dif:.0e}"
     print(line, flush=True)

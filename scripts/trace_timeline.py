@@ -1,0 +1,59 @@
+"""Critical-path view of ONE training step from a rocprofv3 kernel trace (scripts/gpu_trace.sh): per queue busy time, idle gaps,
+overlap between the two streams, and the phases of the step (forward / backward chain / tail)."""
+import csv, re, sys, collections
+rows = list(csv.DictReader(open(sys.argv[1])))
+for r in rows:
+    r["s"] = int(r["Start_Timestamp"]); r["e"] = int(r["End_Timestamp"])
+    r["n"] = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"]).split("(")[0].replace("void ", "")[:40]
+    r["q"] = r.get("Queue_Id", "0")
+rows.sort(key=lambda r: r["s"])
+st = [i for i, r in enumerate(rows) if r["n"].startswith("targets_kernel<0>")]
+a, b = st[-2], st[-1]
+step = rows[a:b]
+t0 = step[0]["s"]
+wall = (rows[b]["s"] - t0) / 1e3
+print(f"step wall {wall:.0f} us, {len(step)} kernels")
+byq = collections.defaultdict(list)
+for r in step:
+    byq[r["q"]].append(r)
+mainq = step[0]["q"]
+for q, rs in byq.items():
+    busy = sum(r["e"] - r["s"] for r in rs) / 1e3
+    gaps = [(y["s"] - x["e"]) / 1e3 for x, y in zip(rs, rs[1:])]
+    pos = [g for g in gaps if g > 0]
+    print(f"queue {q}{' (main)' if q == mainq else ''}: {len(rs)} kernels, busy {busy:.0f} us, first start {(rs[0]['s']-t0)/1e3:.0f}, last end {(rs[-1]['e']-t0)/1e3:.0f}, "
+          f"idle gaps: n={len(pos)} sum={sum(pos):.0f} us, median={sorted(pos)[len(pos)//2] if pos else 0:.1f}, >20us: {sum(1 for g in pos if g > 20)} ({sum(g for g in pos if g > 20):.0f} us)")
+main = byq[mainq]
+# phases on the main queue: forward = up to the first crit kernel; backward = from upsample_add_bwd to the last kernel before sgd
+def first(pred):
+    for i, r in enumerate(main):
+        if pred(r["n"]):
+            return i
+    return None
+ic = first(lambda n: n.startswith("crit_ohem"))
+ib = first(lambda n: n.startswith("upsample_add_bwd"))
+isg = first(lambda n: n.startswith("sgd_kernel"))
+if None not in (ic, ib, isg):
+    print(f"forward  : {(main[ic]['s'] - t0)/1e3:.0f} us ({ic} kernels)")
+    print(f"criterion: {(main[ib]['s'] - main[ic]['s'])/1e3:.0f} us")
+    print(f"backward : {(main[isg]['s'] - main[ib]['s'])/1e3:.0f} us ({isg - ib} kernels on the main queue)")
+    print(f"tail     : {(rows[b]['s'] - main[isg]['s'])/1e3:.0f} us")
+    bw = main[ib:isg]
+    busy = sum(r["e"] - r["s"] for r in bw) / 1e3
+    print(f"backward main-queue busy {busy:.0f} us, idle {(main[isg]['s'] - main[ib]['s'])/1e3 - busy:.0f} us; last 5 main kernels before sgd:")
+    for r in bw[-5:]:
+        print(f"    {r['n']:40s} start {(r['s']-t0)/1e3:8.0f} dur {(r['e']-r['s'])/1e3:6.1f}")
+    for q, rs in byq.items():
+        if q != mainq:
+            print(f"  side queue {q}: last end {(rs[-1]['e']-t0)/1e3:.0f} us vs sgd start {(main[isg]['s']-t0)/1e3:.0f} us")
+# biggest idle gaps on the main queue with the kernels around them
+gl = sorted(((y["s"] - x["e"]) / 1e3, x["n"], y["n"], (x["e"] - t0) / 1e3) for x, y in zip(main, main[1:]))[-12:]
+print("largest main-queue gaps:")
+for g, xn, yn, at in reversed(gl):
+    print(f"    {g:7.1f} us at {at:8.0f}: {xn} -> {yn}")
+agg = collections.defaultdict(lambda: [0.0, 0])
+for r in main:
+    agg[r["n"]][0] += (r["e"] - r["s"]) / 1e3; agg[r["n"]][1] += 1
+print("main-queue kernel totals:")
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:18]:
+    print(f"    {k:42s} {v[0]:8.1f} us n={v[1]:4d} avg {v[0]/v[1]:6.1f}")

@@ -39,7 +39,7 @@ def main():
     torch.cuda.set_device(0)
     _hip.lib().tf_set_stat_rows(0)                        # reproducible BN statistics
     m, c, batches = build(golden_path)
-    eng = TrainEngine(m, c, lr=1e-3, momentum=0.9, weight_decay=5e-4, device="cuda:0", bucket_mb=10)
+    eng = TrainEngine(m, c, lr=1e-4, momentum=0.9, weight_decay=5e-4, device="cuda:0", bucket_mb=10)
     assert eng._overlap is not None and len(eng._overlap["ranges"]) >= 8, "the bucketed, event-driven exchange must be active"
     img, cm, rm = [t.cuda() for t in batches[rank]]
     snaps = []

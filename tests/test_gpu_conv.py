@@ -675,8 +675,12 @@ def test_wgrad3x3_all_taps(case, splitk):
     dp = err(dwp.cpu().reshape(Cout, 9, Cin).permute(0, 2, 1).reshape(Cout, Cin, 3, 3), w.grad)
     old = ops.conv2d_wgrad(xd, gyd, Cin, Cout, 3, 3, 1, 1, tile=1)
     do = err(dw.cpu(), old.cpu())
-    report(f"wgrad3x3[{case},sk{splitk}]", rel=d[2], packed_rel=dp[2], vs_per_tap=do[2])
-    assert d[2] < 2e-3 and dp[2] < 2e-3 and do[2] < 1e-4
+    # two-phase epilogue (partial tiles + summing kernel) ACCUMULATES into dW like the atomic form: start from a non-zero buffer
+    base = torch.randn(Cout, Cin, 3, 3, generator=g)
+    dw2 = ops.conv2d_wgrad(xd, gyd, Cin, Cout, 3, 3, 1, 1, tile=3, splitk=splitk, out=base.clone().cuda(), two_phase=True)
+    d2 = err(dw2.cpu() - base, w.grad)
+    report(f"wgrad3x3[{case},sk{splitk}]", rel=d[2], packed_rel=dp[2], vs_per_tap=do[2], two_phase_rel=d2[2])
+    assert d[2] < 2e-3 and dp[2] < 2e-3 and do[2] < 1e-4 and d2[2] < 2e-3
 
 
 def test_wgrad3x3_refuses_what_it_cannot_do():

@@ -57,7 +57,7 @@ def test_two_rank_engine_equals_single_process_gradient_average(tmp_path):
             for rp in reps:
                 for a, b, mult in groups:
                     if mult != 0.0:
-                        ops.sgd_step(rp["flat"][a:b], gsum[a:b], rp["mom"][a:b], 1e-3 * mult, 0.9, 5e-4, 0.5)
+                        ops.sgd_step(rp["flat"][a:b], gsum[a:b], rp["mom"][a:b], 1e-4 * mult, 0.9, 5e-4, 0.5)
             torch.cuda.synchronize()
             ref = reps[0]["flat"].cpu().numpy()
             d = np.abs(dist[s] - ref)
@@ -67,6 +67,7 @@ def test_two_rank_engine_equals_single_process_gradient_average(tmp_path):
     report("dist_two_ranks_vs_single", worst_rel=str([f"{w:.2e}" for w in worst]))
     # step 1: only the fp32-atomic summation order of the weight gradients differs between two runs (1e-7); later steps amplify it
     # through batch-statistics BN on these 2-image batches exactly as between two single-process runs (test_gpu_model.py)
+    assert all(np.isfinite(d).all() for d in dist) and all(np.isfinite(w) for w in worst), worst
     assert worst[0] < 1e-5, worst
     assert worst[-1] < 1e-2, worst
 

@@ -240,3 +240,26 @@ def test_sgd_vs_torch():
     ref = flat[3:500].cpu() - 0.1 * (gflat[3:500].cpu() + 0.0 * flat[3:500].cpu())
     ops.sgd_step(flat[3:500], gflat[3:500], m[3:500], 0.1, 0.0, 0.0)
     assert np.allclose(flat[3:500].cpu().numpy(), ref.numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_pairwise_iou_distance_and_kmedoids_vs_reference_golden(golden):
+    """the n^2 distance matrix of the template clustering on the device is BIT-equal to the reference's
+    compute_distances (tests/golden/clustering.npz holds its output), so the reference's own k-medoids run on it picks exactly
+    the golden medoids; plus a 3000-box matrix against the vectorised numpy expression."""
+    from tinyfaces import clustering as cl
+    g = golden("clustering")
+    shapes = cl.centralize_bbox(g["boxes"])
+    dist = cl.compute_distances(shapes, device="cuda")
+    assert dist.dtype == np.float64 and np.array_equal(dist, g["dist"])
+    for k in (3, 7):
+        med, member = cl.k_medoids(dist, k, rng=np.random.RandomState(40 + k))
+        assert np.array_equal(med, g[f"k{k}_medoids"]) and np.array_equal(member, g[f"k{k}_member"])
+    rng = np.random.RandomState(1)
+    wh = np.exp(rng.uniform(np.log(4), np.log(400), (3000, 2)))
+    big = np.concatenate([-wh / 2, wh / 2], 1)
+    big[7] = 0.0                                              # a degenerate box: union <= 0 against itself -> IoU 0, distance 1
+    d = cl.compute_distances(big, device="cuda")
+    assert np.array_equal(d, cl.compute_distances(big)) and d[7, 7] == 1.0
+    res = cl.compute_kmedoids(g["boxes"], 1, option="local", indices=4, max_clusters=5, rng=np.random.RandomState(0), device="cuda")
+    ref = cl.compute_kmedoids(g["boxes"], 1, option="local", indices=4, max_clusters=5, rng=np.random.RandomState(0))
+    assert all(np.array_equal(np.array(a["medoids"]), np.array(b["medoids"])) for a, b in zip(res[4:], ref[4:]))

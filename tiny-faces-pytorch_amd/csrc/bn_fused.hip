@@ -302,11 +302,11 @@ extern "C" int tf_bn_bwd_apply_fused(int dtype, const void* g, const void* y, co
   if (rows < 1 || rows > TF_STAT_ROWS || bn->nk < 2 || bn->kidx < 1 || bn->kidx >= bn->nk || !fused_shape_ok(C, dtype)) return TF_ERR_ARG;
   const BwdBn d{bn->stat, bn->gamma, bn->mean, bn->invstd, bn->dgamma, bn->dbeta, bn->nk, bn->kidx};
   if (y) {
-    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_fused_kernel<T, true, RT>), fused_grid(M, C, dtype), dim3(256), 0, (hipStream_t)stream, (const T*)g,
-                                         (const T*)y, (const T*)x, d, rows, (size_t)M, C, count, (T*)out));
+    DISPATCH_T(dtype, TF_LAUNCH_WITH_STOP_EVENT((bn_bwd_apply_fused_kernel<T, true, RT>), fused_grid(M, C, dtype), dim3(256), 0, (hipStream_t)stream,
+                                                (const T*)g, (const T*)y, (const T*)x, d, rows, (size_t)M, C, count, (T*)out));
   } else {
-    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_fused_kernel<T, false, RT>), fused_grid(M, C, dtype), dim3(256), 0, (hipStream_t)stream, (const T*)g,
-                                         (const T*)y, (const T*)x, d, rows, (size_t)M, C, count, (T*)out));
+    DISPATCH_T(dtype, TF_LAUNCH_WITH_STOP_EVENT((bn_bwd_apply_fused_kernel<T, false, RT>), fused_grid(M, C, dtype), dim3(256), 0, (hipStream_t)stream,
+                                                (const T*)g, (const T*)y, (const T*)x, d, rows, (size_t)M, C, count, (T*)out));
   }
   TF_CHECK_LAUNCH();
   return TF_OK;

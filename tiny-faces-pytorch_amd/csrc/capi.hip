@@ -3,12 +3,12 @@
 
 static const char* const kSymbols[] = {
     "tf_version", "tf_symbol_count", "tf_symbol_name",
-    "tf_targets_workspace_bytes", "tf_dense_overlap_targets", "tf_dense_overlap_iou",
+    "tf_targets_workspace_bytes", "tf_dense_overlap_targets", "tf_dense_overlap_iou", "tf_pairwise_iou_distance",
     "tf_nms_workspace_bytes", "tf_nms_f64", "tf_nms_batched_workspace_bytes", "tf_nms_f64_batched",
     "tf_decode_workspace_bytes", "tf_decode_compact",
     "tf_criterion_workspace_bytes", "tf_criterion_fwd_bwd",
     "tf_sgd_step", "tf_image_prepare",
-    "tf_conv_mtiles", "tf_conv2d", "tf_pack_weight", "tf_pack_weights_batched", "tf_pack_weights_tiled", "tf_conv2d_wgrad", "tf_unpack_dw",
+    "tf_conv_mtiles", "tf_conv2d", "tf_pack_weight", "tf_pack_weights_batched", "tf_pack_weights_tiled", "tf_conv2d_wgrad", "tf_wgrad_workspace_bytes", "tf_unpack_dw",
     "tf_stem_im2col", "tf_maxpool_fwd", "tf_maxpool_bwd", "tf_colstats_blocks", "tf_colstats",
     "tf_bn_finalize", "tf_bn_fold", "tf_bn_bwd_finalize", "tf_bn_bwd_apply", "tf_bn_relu", "tf_bn_add_relu",
     "tf_bn_relu_fused", "tf_bn_add_relu_fused", "tf_bn_bwd_apply_fused",
@@ -17,6 +17,12 @@ static const char* const kSymbols[] = {
     "tf_detnet_out_shape", "tf_detnet_param_region_bytes", "tf_detnet_forward", "tf_detnet_backward", "tf_detnet_set_dual_stream", "tf_detnet_set_grad_events",
     "tf_probe_tr16", "tf_set_stat_rows", "tf_get_stat_rows", "tf_profile_enable", "tf_profile_collect", "tf_profile_shapes",
 };
+
+namespace tf {
+static thread_local hipEvent_t g_next_stop_event = nullptr;
+void set_next_stop_event(hipEvent_t e) { g_next_stop_event = e; }
+hipEvent_t take_next_stop_event() { hipEvent_t e = g_next_stop_event; g_next_stop_event = nullptr; return e; }
+}  // namespace tf
 
 extern "C" int tf_version(void) { return 200; }
 static int g_stat_rows = 8;

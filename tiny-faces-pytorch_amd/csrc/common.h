@@ -1,9 +1,17 @@
 // Shared device helpers for the tiny-faces gfx950 kernels (CDNA4, wave64).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "../../include/tinyfaces_hip.h"
+
+#define TF_LAUNCH_WITH_STOP_EVENT(kernel, grid, block, lds, stream, ...)                                                  \
+  do {                                                                                                                  \
+    hipEvent_t ev__ = tf::take_next_stop_event();                                                                       \
+    if (ev__) hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, nullptr, ev__, 0, __VA_ARGS__);                   \
+    else hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                             \
+  } while (0)
 
 #define TF_CHECK_LAUNCH()                                  \
   do {                                                     \
@@ -12,6 +20,13 @@
   } while (0)
 
 namespace tf {
+
+// Completion event of the NEXT kernel launched through TF_LAUNCH_WITH_STOP_EVENT on this host thread (one-shot).  The executor
+// uses it to hand a producer kernel's OWN completion signal to the weight-gradient stream (hipExtLaunchKernelGGL stopEvent): a
+// separate hipEventRecord costs a barrier packet -- an ~8 us bubble on the data-gradient chain, 94 times per training step
+// (profiles/r02_step_timeline.txt).
+void set_next_stop_event(hipEvent_t e);
+hipEvent_t take_next_stop_event();
 
 constexpr int kWave = 64;
 

@@ -161,7 +161,7 @@ struct Plan {                    // everything a forward carves; backward re-der
   float* partial; size_t partial_floats;
   float *stat_fwd, *stat_bwd; size_t stat_fwd_floats, stat_bwd_floats;   // per-BN statistic regions (fused finalize)
   // backward-only
-  void *g3, *g4, *G0, *G1, *T4, *R3, *wt; float* dwp;
+  void *g3, *g4, *G0, *G1, *T4, *R3, *wt; float* dwp; size_t dwp_floats;
   void *S1[2], *S2[2], *S3[2], *SD[2];   // per block parity: g_c3, g_c2, g_c1, g_d (read by the weight-gradient stream)   // gradient buffers (roles in tf_detnet_backward) + transposed-weight scratch
   int H3, W3, H4, W4;
   size_t total, param_bytes;
@@ -264,9 +264,12 @@ void build_plan(Plan& P, Arena& ar, int dtype, int N, int H, int W, int nout, in
     for (int k = 0; k < 2; ++k) { P.S1[k] = ar.get(max_act); P.S2[k] = ar.get(max_act); P.S3[k] = ar.get(max_act); P.SD[k] = ar.get(max_act); }
     if (packed_bytes(dtype, 1024, 1, kHeadLd) > max_wt) max_wt = packed_bytes(dtype, 1024, 1, kHeadLd);
     P.wt = ar.get(max_wt);
-    P.dwp = ar.f32((size_t)256 * 9 * 256);      // packed [Cout][tap][Cin] scratch of the 3x3 weight gradients
+    // scratch of the 3x3 weight gradients: the partial [slice][tile][tap][64][64] tiles of the all-taps kernel (one block per CU:
+    // at most 256 + 16 tiles of 144 KiB) or, for the stride-2 convs, the packed [Cout][tap][Cin] gradient of the per-tap kernel
+    P.dwp_floats = (size_t)(256 + 16) * 9 * 64 * 64;
+    P.dwp = ar.f32(P.dwp_floats);
   } else {
-    P.g3 = P.g4 = P.G0 = P.G1 = P.T4 = P.R3 = P.wt = nullptr; P.dwp = nullptr;
+    P.g3 = P.g4 = P.G0 = P.G1 = P.T4 = P.R3 = P.wt = nullptr; P.dwp = nullptr; P.dwp_floats = 0;
     for (int k = 0; k < 2; ++k) P.S1[k] = P.S2[k] = P.S3[k] = P.SD[k] = nullptr;
   }
   P.total = ar.off;
@@ -290,6 +293,19 @@ struct Ctx {
   hipEvent_t next_event() {
     if (ev_next == events->size()) { hipEvent_t e; if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { chk(TF_ERR_LAUNCH); return nullptr; } events->push_back(e); }
     return (*events)[ev_next++];
+  }
+  // fork without a packet of its own on `stream`: the NEXT kernel launched through TF_LAUNCH_WITH_STOP_EVENT (the fused BN-backward
+  // apply that produces a weight gradient's dY operand) carries the event as its completion signal; join_side() then makes the
+  // weight-gradient stream wait for it.  hipEventRecord costs a barrier packet = an ~8 us bubble on the data-gradient chain
+  // (profiles/r02_step_timeline.txt), three to four times per bottleneck.
+  hipEvent_t pending = nullptr;
+  static bool kernel_events() { static const bool on = getenv("TINYFACES_FORK_BY_RECORD") == nullptr; return on; }
+  void arm_fork() { if (!side || !kernel_events()) return; pending = next_event(); if (pending) tf::set_next_stop_event(pending); }
+  void fork_armed() {
+    if (!side) return;
+    if (tf::take_next_stop_event()) pending = nullptr;     // armed but no kernel took it (the producer refused its arguments): plain fork
+    if (pending) { (void)hipStreamWaitEvent(side, pending, 0); pending = nullptr; }
+    else fork();
   }
   // everything enqueued on `stream` so far becomes a dependency of what is enqueued on `side` next
   void fork() { if (!side) return; hipEvent_t e = next_event(); if (e) { (void)hipEventRecord(e, stream); (void)hipStreamWaitEvent(side, e, 0); } }
@@ -553,7 +569,7 @@ void bn_backward_coefs(Ctx& c, const ConvUnit& u, int C, BnBuf& b, const float* 
 }
 
 void wgrad(Ctx& c, const ConvUnit& u, int cout, int N, int H, int W, int OH, int OW, const void* x, int ldx, const void* dy, int lddy,
-           const BnBuf* pro, int cin_override = 0, int k_override = 0, int dw_ld = 0, float* packed_scratch = nullptr) {
+           const BnBuf* pro, int cin_override = 0, int k_override = 0, int dw_ld = 0, float* packed_scratch = nullptr, size_t scratch_floats = 0) {
   tf_wgrad_args w;
   memset(&w, 0, sizeof(w));
   const int cin = cin_override ? cin_override : u.cin, k = k_override ? k_override : u.k;
@@ -561,7 +577,17 @@ void wgrad(Ctx& c, const ConvUnit& u, int cout, int N, int H, int W, int OH, int
   w.stride = u.stride; w.pad = u.pad; w.ldx = ldx; w.lddy = lddy; w.x = x; w.dy = dy; w.dw_oihw = c.G(u.w);
   w.dw_ld = dw_ld ? dw_ld : cin * k * k;
   if (pro) { w.pro_scale = pro->scale; w.pro_shift = pro->shift; w.pro_relu = 1; }
-  if (k > 1 && packed_scratch) {          // 3x3: coalesced atomics into [Cout][tap][Cin], then one transposing copy to OIHW
+  if (k > 1 && packed_scratch && c.grads_zeroed) {
+    // 3x3 / stride 1: the all-taps kernel sums its split-K slices through the scratch straight into the (already zeroed) OIHW
+    // gradient: no memset, no atomics, no transposing copy
+    w.partial_ws = packed_scratch; w.partial_ws_bytes = scratch_floats * 4;
+    if (tf_wgrad_workspace_bytes(&w) != 0 && tf_wgrad_workspace_bytes(&w) <= w.partial_ws_bytes) {
+      static const bool w3_off = getenv("TINYFACES_WGRAD3_OFF") != nullptr;
+      if (!w3_off) { c.chk(tf_conv2d_wgrad(&w, c.wstream())); return; }
+    }
+    w.partial_ws = nullptr; w.partial_ws_bytes = 0;
+  }
+  if (k > 1 && packed_scratch) {          // 3x3 (stride 2): coalesced atomics into [Cout][tap][Cin], then one transposing copy to OIHW
     float* oihw = w.dw_oihw;
     w.dw_oihw = packed_scratch; w.packed = 1;
     if (hipMemsetAsync(packed_scratch, 0, (size_t)cout * w.dw_ld * 4, c.wstream()) != hipSuccess) c.chk(TF_ERR_LAUNCH);   // scratch: always
@@ -692,6 +718,7 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
     // (2) g_c3 -> T1
     if (fused) {
       const tf_bn_bwd_desc d = bwd_desc(c, B.c3, b.b3, b.b3.bst, nk, 1);
+      if (fork_each) c.arm_fork();
       c.chk(tf_bn_bwd_apply_fused(dtype, Gcur, nullptr, b.c3, &d, srows, Mout, c4, (float)Mout, T1, c.stream));
     } else {
       bn_backward_coefs(c, B.c3, c4, b.b3, P.partial, nb, nk, 1, c4, (float)Mout, B.has_ds ? 0 : 1);   // the last reader clears the partial rows
@@ -700,7 +727,7 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
     }
     // (3) wgrad conv3 (its input is relu(bn2(c2)), materialised in the forward)
     auto wg3 = [&]() { wgrad(c, B.c3, c4, N, b.Hout, b.Wout, b.Hout, b.Wout, b.a2, pl, T1, c4, nullptr); };
-    if (fork_each) { c.fork(); wg3(); }
+    if (fork_each) { c.fork_armed(); wg3(); }
     // (4) dgrad conv3 -> gz2 in T2 (masked by relu(bn2(c2))) + BN-backward sums
     conv_fill(a, dtype, 1, N, b.Hout, b.Wout, c4, b.Hout, b.Wout, pl, 1, 1, 0, pl, T1, b.w3t, T2);
     a.epi = TF_EPI_MASK | TF_EPI_STATS2; a.aux = b.c2; a.mask_scale = b.b2.scale; a.mask_shift = b.b2.shift;
@@ -709,14 +736,15 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
     // (5) g_c2 in place
     if (fused) {
       const tf_bn_bwd_desc d = bwd_desc(c, B.c2, b.b2, b.b2.bst, 2, 1);
+      if (fork_each) c.arm_fork();
       c.chk(tf_bn_bwd_apply_fused(dtype, T2, nullptr, b.c2, &d, srows, Mout, pl, (float)Mout, T2, c.stream));
     } else {
       bn_backward_coefs(c, B.c2, pl, b.b2, P.partial, tf_conv_mtiles(&a), 2, 1, pl, (float)Mout);
       c.chk(tf_bn_bwd_apply(dtype, T2, nullptr, b.c2, b.b2.cA, b.b2.cB, b.b2.cD, Mout, pl, T2, c.stream));
     }
     // (6) wgrad conv2 (input relu(bn1(c1)))
-    auto wg2 = [&]() { wgrad(c, B.c2, pl, N, b.Hin, b.Win, b.Hout, b.Wout, b.a1, pl, T2, pl, nullptr, 0, 0, 0, P.dwp); };
-    if (fork_each) { c.fork(); wg2(); }
+    auto wg2 = [&]() { wgrad(c, B.c2, pl, N, b.Hin, b.Win, b.Hout, b.Wout, b.a1, pl, T2, pl, nullptr, 0, 0, 0, P.dwp, P.dwp_floats); };
+    if (fork_each) { c.fork_armed(); wg2(); }
     // (7) dgrad conv2 -> gz1 in U1 (+ sums); output spatial = conv2's input
     conv_fill(a, dtype, 1, N, b.Hout, b.Wout, pl, b.Hin, b.Win, pl, 3, B.stride, 1, pl, T2, b.w2t, U1);
     a.epi = TF_EPI_MASK | TF_EPI_STATS2; a.aux = b.c1; a.mask_scale = b.b1.scale; a.mask_shift = b.b1.shift;
@@ -725,6 +753,7 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
     // (8) g_c1 in place
     if (fused) {
       const tf_bn_bwd_desc d = bwd_desc(c, B.c1, b.b1, b.b1.bst, 2, 1);
+      if (fork_each) c.arm_fork();
       c.chk(tf_bn_bwd_apply_fused(dtype, U1, nullptr, b.c1, &d, srows, Min, pl, (float)Min, U1, c.stream));
     } else {
       bn_backward_coefs(c, B.c1, pl, b.b1, P.partial, tf_conv_mtiles(&a), 2, 1, pl, (float)Min);
@@ -732,7 +761,7 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
     }
     // (9) wgrad conv1 (input = block input, already activated)
     auto wg1 = [&]() { wgrad(c, B.c1, pl, N, b.Hin, b.Win, b.Hin, b.Win, yin, B.cin, U1, pl, nullptr); };
-    if (fork_each) { c.fork(); wg1(); }
+    if (fork_each) { c.fork_armed(); wg1(); }
     // (10) gradient w.r.t. the block input -> Gnext.  Fused flow: the conv that completes it also applies the ReLU mask of
     //      the previous block's output (MASK2 with aux2 = yin) and, unless that block has a downsample branch, accumulates
     //      its BN3-backward sums (STATS3 with aux3 = its c3), so the next iteration starts at step (2).
@@ -744,11 +773,12 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
     if (B.has_ds) {
       if (fused) {
         const tf_bn_bwd_desc d = bwd_desc(c, B.ds, b.bd, b.b3.bst, 3, 2);      // the downsample BN's sums are row 2 of bn3's region
+        if (fork_each) c.arm_fork();
         c.chk(tf_bn_bwd_apply_fused(dtype, Gcur, nullptr, b.d, &d, srows, Mout, c4, (float)Mout, T3, c.stream));
       } else {
         c.chk(tf_bn_bwd_apply(dtype, Gcur, b.y, b.d, b.bd.cA, b.bd.cB, b.bd.cD, Mout, c4, T3, c.stream));
       }
-      if (fork_each) { c.fork(); wgrad(c, B.ds, c4, N, b.Hin, b.Win, b.Hout, b.Wout, yin, B.cin, T3, c4, nullptr); }
+      if (fork_each) { c.fork_armed(); wgrad(c, B.ds, c4, N, b.Hin, b.Win, b.Hout, b.Wout, yin, B.cin, T3, c4, nullptr); }
       conv_fill(a, dtype, 1, N, b.Hout, b.Wout, c4, b.Hin, b.Win, B.cin, 1, B.stride, 0, B.cin, T3, b.wdt, P.T4);
       if (extra) { a.epi = TF_EPI_RES; a.aux = extra; }
       c.chk(tf_conv2d(&a, c.stream));

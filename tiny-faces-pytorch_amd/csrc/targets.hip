@@ -201,3 +201,37 @@ extern "C" int tf_dense_overlap_iou(const double* boxes, int G, const double* te
   TF_CHECK_LAUNCH();
   return TF_OK;
 }
+
+// ---- template clustering: the n x n distance matrix 1 - IoU of the centred ground-truth shapes
+// (tinyfaces/clustering/cluster.py:28-37 over tinyfaces/metrics.py:8-40: plain areas, no +1, IoU = 0 when the union is not
+// positive).  float64, every operation rounded like numpy's (this file is compiled with -ffp-contract=off): bit-exact with the
+// reference's double loop, which is what makes the k-medoids that follows index-exact.
+namespace {
+__global__ void __launch_bounds__(256) pairwise_dist_kernel(const double* __restrict__ boxes, int n, double* __restrict__ out) {
+  __shared__ double4 col[256];
+  const int j0 = blockIdx.x * 256, i0 = blockIdx.y * 16;
+  const int j = j0 + threadIdx.x;
+  if (j < n) col[threadIdx.x] = *reinterpret_cast<const double4*>(boxes + 4 * (size_t)j);
+  __syncthreads();
+  if (j >= n) return;
+  const double4 b = col[threadIdx.x];
+  const double area_b = (b.z - b.x) * (b.w - b.y);
+  for (int i = i0; i < min(n, i0 + 16); ++i) {
+    const double4 a = *reinterpret_cast<const double4*>(boxes + 4 * (size_t)i);       // wave-uniform: one scalar-path load
+    const double area_a = (a.z - a.x) * (a.w - a.y);
+    const double xa = fmax(a.x, b.x), ya = fmax(a.y, b.y), xb = fmin(a.z, b.z), yb = fmin(a.w, b.w);
+    const double inter = (xb - xa) * (yb - ya);
+    const double uni = area_a + area_b - inter;
+    out[(size_t)i * n + j] = 1.0 - (uni <= 0.0 ? 0.0 : inter / uni);
+  }
+}
+}  // namespace
+
+extern "C" int tf_pairwise_iou_distance(const double* boxes, int n, double* out, void* stream) {
+  if (n < 0 || (n > 0 && (!boxes || !out))) return TF_ERR_ARG;
+  if (n == 0) return TF_OK;
+  hipLaunchKernelGGL(pairwise_dist_kernel, dim3((n + 255) / 256, (n + 15) / 16), dim3(256), 0, (hipStream_t)stream, boxes, n, out);
+  TF_CHECK_LAUNCH();
+  return TF_OK;
+}
+

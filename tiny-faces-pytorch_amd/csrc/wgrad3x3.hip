@@ -12,11 +12,16 @@
 //     16 KiB of LDS-DMA per 9 x 262 144 MACs instead of per 262 144;
 //   * X lives in a 512-row circular LDS image (64 KiB): a stage adds 64 new rows, the (W+2)+1 rows of halo on either side are
 //     already there, and every tap reads its fragments with ds_read_b64_tr_b16 from rows shifted by its constant;
-//   * per stage a wave issues 72 MFMAs (9 taps x 2 k-steps x 2x2 fragments) behind ONE barrier, against 40 fragment reads:
-//     the kernel is MFMA-bound by construction (1152 MFMA cycles vs ~690 LDS cycles per CU-stage), where the per-tap kernel
-//     was LDS-bound (profiles/r01e_layer_table.md rows 1, 10, 11: 14-17x over roofline);
-//   * nine accumulator sets (144 registers) and one atomic epilogue instead of nine.
-// Split-K over the padded pixel range; fp32 atomics into dW (packed [Cout][tap][Cin] or OIHW).  bf16 only, no prologue.
+//   * 8 waves per block (2 x 4 over the 64 x 64 output tile: 32 co x 16 ci each), two per SIMD, so that one wave's fragment
+//     reads / address arithmetic overlap its partner's MFMAs (the 4-wave first version of this kernel spent 2.5 us per stage,
+//     5x its MFMA time: profiles/r02_wgrad3x3.txt); per stage a wave issues 36 MFMAs behind ONE barrier against 22 fragment reads;
+//   * nine accumulator sets (72 registers per wave) and ONE epilogue instead of nine.
+// Split-K over the padded pixel range.  Epilogue, two forms:
+//   * partial workspace given: every block stores its 9 x 64 x 64 fp32 tile with plain stores ([slice][tile][tap][co][ci]) and a
+//     second kernel sums the slices straight into dW (OIHW or packed) -- no memset, no transposing copy, no atomics: with one
+//     block per CU the atomic form issues 256 x 36 864 = 9.4 M L2 atomics per launch, which alone cost 31 us (measured);
+//   * no workspace: fp32 atomics into dW (the C-ABI default, tests).
+// bf16 only, no prologue.
 #include <cstdlib>
 #include "common.h"
 #include "profile.h"
@@ -30,13 +35,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ uint4 g_w3zero_page[8];
 
 struct W3K {
-  const char* x; const char* dy; float* dw;
+  const char* x; const char* dy; float* dw; float* partial;
   int N, H, W, Cin, Cout, ldx, lddy, dw_ld, ci_stride, tap_stride;
   int Hp, Wp, HWp, Mp;              // padded frame: H+2, W+2, their product, N * HWp
   int nco, nci, splitk, chunk, hb;  // hb = halo in 64-row chunks on either side: ceil((Wp + 1) / 64)
 };
 
-constexpr int PK = 64, NS = 3, YT = PK * 128, XROWS = 512, XBYTES = XROWS * 128, L = 4;
+constexpr int PK = 64, NS = 3, YT = PK * 128, XROWS = 512, XBYTES = XROWS * 128, L = 2, NT = 512;
+constexpr int TILE_FLOATS = 9 * 64 * 64;
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void dma16(const void* gsrc, void* lds_wave_base) {
@@ -92,7 +98,7 @@ struct PadPos {
   __device__ __forceinline__ size_t pixel(const W3K& a) const { return ((size_t)n * a.H + (hp - 1)) * a.W + (wp - 1); }
 };
 
-__global__ void __launch_bounds__(256, 1) wgrad3x3_kernel(const W3K a) {
+__global__ void __launch_bounds__(NT, 2) wgrad3x3_kernel(const W3K a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const yring = smem;
   char* const xring = smem + NS * YT;
@@ -102,70 +108,49 @@ __global__ void __launch_bounds__(256, 1) wgrad3x3_kernel(const W3K a) {
   const int tco = b;
   const int co0 = tco * 64, ci0 = tci * 64;
   const int pb = ks * a.chunk, pe = min(a.Mp, pb + a.chunk);
-  const int nst = pe > pb ? (pe - pb + PK - 1) / PK : 0;
-  if (nst == 0) return;
+  const int nst = (pe - pb + PK - 1) / PK;               // >= 1: the host sizes splitk so that every slice owns pixels
   const int x0 = pb - PK * a.hb;                         // padded index of ring row 0
   const int D = 2 * a.hb;                                // stage st needs X chunks st .. st + D
-  const int tid = threadIdx.x, lrow = tid >> 3, pslot = tid & 7;
+  const int tid = threadIdx.x, r = tid >> 3, pslot = tid & 7;      // one row of every 64-row group per thread
   const int wave_byte = (tid & ~63) * 16;
   const char* zero = reinterpret_cast<const char*>(g_w3zero_page) + pslot * 16;
 
-  // per-thread DMA rows: lrow and lrow + 32 of every 64-row group; physical slot pslot receives logical slot pslot ^ fsw(row)
-  PadPos ypos[2], xpos[2];
-  int yrow[2];                                           // padded index of the dY row in the NEXT stage to issue
-  int ycol[2], xcol[2];
-  bool ycok[2], xcok[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int r = lrow + i * 32;
-    const int ls = pslot ^ fsw(r);
-    yrow[i] = pb + r;
-    ypos[i].init(pb + r, a);
-    xpos[i].init(x0 + r, a);
-    ycol[i] = co0 + ls * 8; xcol[i] = ci0 + ls * 8;
-    ycok[i] = ycol[i] + 8 <= a.lddy; xcok[i] = xcol[i] + 8 <= a.ldx;
-  }
+  // physical slot pslot of row r receives logical slot pslot ^ fsw(r) (swizzle on the SOURCE)
+  const int ls = pslot ^ fsw(r);
+  PadPos ypos, xpos;
+  ypos.init(pb + r, a);
+  xpos.init(x0 + r, a);
+  int yrow = pb + r;                                     // padded index of this thread's dY row in the NEXT stage to issue
+  const int ycol = co0 + ls * 8, xcol = ci0 + ls * 8;
+  const bool ycok = ycol + 8 <= a.lddy, xcok = xcol + 8 <= a.ldx;
   int ys_slot = 0, xc = 0;                               // dY ring slot / X chunk index of the next issue
   auto issue_y = [&]() {
-    char* ys = yring + ys_slot * YT;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const bool ok = yrow[i] < pe && ycok[i] && ypos[i].interior(a);
-      const uintptr_t src = ok ? reinterpret_cast<uintptr_t>(a.dy) + (ypos[i].pixel(a) * a.lddy + ycol[i]) * 2 : reinterpret_cast<uintptr_t>(zero);
-      dma16(reinterpret_cast<const void*>(src), ys + i * 4096 + wave_byte);
-      ypos[i].advance(a); yrow[i] += PK;
-    }
+    const bool ok = yrow < pe && ycok && ypos.interior(a);
+    const uintptr_t src = ok ? reinterpret_cast<uintptr_t>(a.dy) + (ypos.pixel(a) * a.lddy + ycol) * 2 : reinterpret_cast<uintptr_t>(zero);
+    dma16(reinterpret_cast<const void*>(src), yring + ys_slot * YT + wave_byte);
+    ypos.advance(a); yrow += PK;
     if (++ys_slot == NS) ys_slot = 0;
   };
   auto issue_x = [&]() {
-    char* xs = xring + ((xc * PK) & (XROWS - 1)) * 128;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const bool ok = xcok[i] && xpos[i].interior(a);
-      const uintptr_t src = ok ? reinterpret_cast<uintptr_t>(a.x) + (xpos[i].pixel(a) * a.ldx + xcol[i]) * 2 : reinterpret_cast<uintptr_t>(zero);
-      dma16(reinterpret_cast<const void*>(src), xs + i * 4096 + wave_byte);
-      xpos[i].advance(a);
-    }
+    const bool ok = xcok && xpos.interior(a);
+    const uintptr_t src = ok ? reinterpret_cast<uintptr_t>(a.x) + (xpos.pixel(a) * a.ldx + xcol) * 2 : reinterpret_cast<uintptr_t>(zero);
+    dma16(reinterpret_cast<const void*>(src), xring + ((xc * PK) & (XROWS - 1)) * 128 + wave_byte);
+    xpos.advance(a);
     ++xc;
   };
 
-  f32x4 acc[9][2][2];
+  f32x4 acc[9][2];
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-      for (int m = 0; m < 2; ++m) acc[t][n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int wave = tid >> 6, wco = wave & 1, wci = wave >> 1;
+    for (int n = 0; n < 2; ++n) acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int wave = tid >> 6, wco = wave & 1, wci = wave >> 1;      // 2 x 4 waves: 32 output channels x 16 input channels each
 
   // prologue: the halo chunks 0 .. D-1 first, then the (dY stage, X chunk) pairs of stages 0 and 1.  From then on every loop
-  // iteration issues exactly one pair (L = 4 DMA instructions per thread), so vmcnt(L) == "everything but the youngest pair landed"
+  // iteration issues exactly one pair (L = 2 DMA instructions per thread), so vmcnt(L) == "everything but the youngest pair landed"
   for (int c = 0; c < D; ++c) issue_x();
 #pragma unroll
-  for (int j = 0; j < NS - 1; ++j) {
-    issue_y();                                           // always issued: past the slice the rows come from the zero page (keeps the count uniform)
-    issue_x();
-  }
+  for (int j = 0; j < NS - 1; ++j) { issue_y(); issue_x(); }       // past the slice the rows come from the zero page: the count stays uniform
   int cs = 0;
   for (int st = 0; st < nst; ++st) {
     wait_vm<L*(NS - 2)>();                               // pair (st+1) may still be in flight; pair st and all older ones landed
@@ -181,13 +166,9 @@ __global__ void __launch_bounds__(256, 1) wgrad3x3_kernel(const W3K a) {
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         const int shift = (t / 3 - 1) * a.Wp + (t % 3 - 1);
-        bf16x8 fx[2];
+        const bf16x8 fx = frag_x(xring, rb0 + k0 + shift, wci * 16);
 #pragma unroll
-        for (int m = 0; m < 2; ++m) fx[m] = frag_x(xring, rb0 + k0 + shift, wci * 32 + m * 16);
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-          for (int m = 0; m < 2; ++m) acc[t][n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[n], fx[m], acc[t][n][m], 0, 0, 0);
+        for (int n = 0; n < 2; ++n) acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[n], fx, acc[t][n], 0, 0, 0);
       }
     }
     if (++cs == NS) cs = 0;
@@ -195,35 +176,73 @@ __global__ void __launch_bounds__(256, 1) wgrad3x3_kernel(const W3K a) {
   wait_vm<0>();                                          // drain the pairs issued past the end before the LDS is released
 
   const int l = tid & 63, li = l & 15, lg = l >> 4;
+  if (a.partial) {
+    // [slice][tile][tap][co 64][ci 64]: 16 lanes write 64 contiguous bytes
+    float* out = a.partial + ((size_t)ks * (a.nco * a.nci) + (size_t)tco * a.nci + tci) * TILE_FLOATS;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          out[(t * 64 + wco * 32 + n * 16 + lg * 4 + q) * 64 + wci * 16 + li] = acc[t][n][q];
+    return;
+  }
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int n = 0; n < 2; ++n)
+    for (int n = 0; n < 2; ++n) {
+      const int ci = ci0 + wci * 16 + li;
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        const int ci = ci0 + wci * 32 + m * 16 + li;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int co = co0 + wco * 32 + n * 16 + lg * 4 + r;
-          if (co < a.Cout && ci < a.Cin) atomicAdd(a.dw + (size_t)co * a.dw_ld + (size_t)ci * a.ci_stride + (size_t)t * a.tap_stride, acc[t][n][m][r]);
-        }
+      for (int q = 0; q < 4; ++q) {
+        const int co = co0 + wco * 32 + n * 16 + lg * 4 + q;
+        if (co < a.Cout && ci < a.Cin) atomicAdd(a.dw + (size_t)co * a.dw_ld + (size_t)ci * a.ci_stride + (size_t)t * a.tap_stride, acc[t][n][q]);
       }
+    }
 }
 
-}  // namespace
+// dW += sum over the slices of the partial tiles.  256 threads = 16 float4 columns x 16 slice groups: a thread sums every 16th
+// slice of its four elements, the 16 partial sums meet in LDS -- so a one-tile layer (layer 1: 256 slices of ONE 64 x 64 x 9
+// tile) still spreads over 576 blocks instead of 36
+__global__ void __launch_bounds__(256) wgrad3x3_reduce_kernel(const W3K a) {
+  __shared__ float4 part[16][17];
+  const int ntiles = a.nco * a.nci;
+  const size_t total4 = (size_t)ntiles * TILE_FLOATS / 4;
+  const int col = threadIdx.x & 15, sg = threadIdx.x >> 4;
+  const size_t e4 = (size_t)blockIdx.x * 16 + col;                 // total4 is a multiple of 16 (TILE_FLOATS / 4 = 9216)
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (e4 < total4)
+    for (int ks = sg; ks < a.splitk; ks += 16) {
+      const float4 v = *reinterpret_cast<const float4*>(a.partial + ((size_t)ks * ntiles * TILE_FLOATS + e4 * 4));
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  part[sg][col] = s;
+  __syncthreads();
+  if (sg != 0 || e4 >= total4) return;
+#pragma unroll
+  for (int g = 1; g < 16; ++g) { const float4 v = part[g][col]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+  const size_t e = e4 * 4;
+  const int tile = (int)(e / TILE_FLOATS), rem = (int)(e - (size_t)tile * TILE_FLOATS);
+  const int t = rem / 4096, co = (tile / a.nci) * 64 + (rem % 4096) / 64, ci = (tile % a.nci) * 64 + rem % 64;
+  if (co >= a.Cout) return;
+  float* d = a.dw + (size_t)co * a.dw_ld + (size_t)t * a.tap_stride;
+  const float v[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (ci + j < a.Cin) d[(size_t)(ci + j) * a.ci_stride] += v[j];
+}
 
-// 3x3, stride 1, pad 1, same-size output, bf16, no prologue, W <= 125.  TF_ERR_UNSUPPORTED otherwise (the caller falls back).
-int tf_wgrad3x3_launch(const tf_wgrad_args* A, hipStream_t stream) {
-  if (A->dtype != TF_BF16 || A->pro_scale) return TF_ERR_UNSUPPORTED;
-  if (A->KH != 3 || A->KW != 3 || A->stride != 1 || A->pad != 1 || A->OH != A->H || A->OW != A->W) return TF_ERR_UNSUPPORTED;
-  if (A->W + 3 > 2 * PK) return TF_ERR_UNSUPPORTED;           // halo of at most two 64-row chunks per side (512-row ring)
-  W3K k;
-  k.x = (const char*)A->x; k.dy = (const char*)A->dy; k.dw = A->dw_oihw;
+// shape checks + split-K plan shared by the launch and the workspace query
+bool w3_plan(const tf_wgrad_args* A, W3K& k) {
+  if (A->dtype != TF_BF16 || A->pro_scale) return false;
+  if (A->KH != 3 || A->KW != 3 || A->stride != 1 || A->pad != 1 || A->OH != A->H || A->OW != A->W) return false;
+  if (A->W + 3 > 2 * PK) return false;                         // halo of at most two 64-row chunks per side (512-row ring)
+  k.x = (const char*)A->x; k.dy = (const char*)A->dy; k.dw = A->dw_oihw; k.partial = nullptr;
   k.N = A->N; k.H = A->H; k.W = A->W; k.Cin = A->Cin; k.Cout = A->Cout; k.ldx = A->ldx; k.lddy = A->lddy; k.dw_ld = A->dw_ld;
   if (A->packed) { k.ci_stride = 1; k.tap_stride = A->Cin; } else { k.ci_stride = 9; k.tap_stride = 1; }
   k.Hp = A->H + 2; k.Wp = A->W + 2; k.HWp = k.Hp * k.Wp;
   const long long mp = (long long)A->N * k.HWp;
-  if (mp > (1ll << 30)) return TF_ERR_UNSUPPORTED;
+  if (mp > (1ll << 30)) return false;
   k.Mp = (int)mp;
   k.hb = (k.Wp + 1 + PK - 1) / PK;
   k.nco = (A->Cout + 63) / 64; k.nci = (A->Cin + 63) / 64;
@@ -231,7 +250,7 @@ int tf_wgrad3x3_launch(const tf_wgrad_args* A, hipStream_t stream) {
   int sk = A->splitk;
   if (sk <= 0) {
     // one block per CU (88 KiB of LDS): split the padded pixel range until ~256 blocks exist, but keep >= 6 stages per block
-    // so that the 2*hb halo chunks and the nine-tap atomic epilogue stay a small part of a block
+    // so that the 2*hb halo chunks and the nine-tap epilogue stay a small part of a block
     static const int target = [] { const char* e = getenv("TINYFACES_WGRAD3_BLOCKS"); return e ? atoi(e) : 256; }();
     sk = (target + tiles - 1) / tiles;
     const int maxsk = (k.Mp + 6 * PK - 1) / (6 * PK);
@@ -240,6 +259,25 @@ int tf_wgrad3x3_launch(const tf_wgrad_args* A, hipStream_t stream) {
   }
   k.chunk = (((k.Mp + sk - 1) / sk) + PK - 1) / PK * PK;
   k.splitk = (k.Mp + k.chunk - 1) / k.chunk;
+  return true;
+}
+
+}  // namespace
+
+// bytes of the partial-tile workspace the two-phase epilogue needs for this call (0: the all-taps kernel does not apply)
+extern "C" size_t tf_wgrad_workspace_bytes(const tf_wgrad_args* A) {
+  W3K k;
+  if (!A || !w3_plan(A, k)) return 0;
+  return (size_t)k.splitk * k.nco * k.nci * TILE_FLOATS * sizeof(float);
+}
+
+// 3x3, stride 1, pad 1, same-size output, bf16, no prologue, W <= 125.  TF_ERR_UNSUPPORTED otherwise (the caller falls back).
+int tf_wgrad3x3_launch(const tf_wgrad_args* A, hipStream_t stream) {
+  W3K k;
+  if (!w3_plan(A, k)) return TF_ERR_UNSUPPORTED;
+  const size_t need = (size_t)k.splitk * k.nco * k.nci * TILE_FLOATS * sizeof(float);
+  static const bool atomics_only = getenv("TINYFACES_WGRAD3_ATOMICS") != nullptr;      // A/B knob
+  if (A->partial_ws && A->partial_ws_bytes >= need && !atomics_only) k.partial = (float*)A->partial_ws;
   const size_t lds = (size_t)NS * YT + XBYTES;
   static bool attr_set = false;
   if (!attr_set) {
@@ -247,8 +285,14 @@ int tf_wgrad3x3_launch(const tf_wgrad_args* A, hipStream_t stream) {
     attr_set = true;
   }
   const double Md = (double)A->N * A->H * A->W;
-  tf::ProfScope prof(14, 2.0 * Md * A->Cout * A->Cin * 9, (Md * A->Cout + Md * A->Cin) * 2 + (double)A->Cout * A->Cin * 9 * 4, stream, (int)Md,
-                     A->Cout, A->Cin * 9, 9, 2, 0);
-  hipLaunchKernelGGL(wgrad3x3_kernel, dim3(tiles * k.splitk), dim3(256), lds, stream, k);
+  {
+    tf::ProfScope prof(14, 2.0 * Md * A->Cout * A->Cin * 9, (Md * A->Cout + Md * A->Cin) * 2 + (double)A->Cout * A->Cin * 9 * 4, stream, (int)Md,
+                       A->Cout, A->Cin * 9, 9, 2, 0);
+    hipLaunchKernelGGL(wgrad3x3_kernel, dim3(k.nco * k.nci * k.splitk), dim3(NT), lds, stream, k);
+  }
+  if (k.partial) {
+    const size_t total4 = (size_t)k.nco * k.nci * TILE_FLOATS / 4;
+    hipLaunchKernelGGL(wgrad3x3_reduce_kernel, dim3((unsigned)((total4 + 15) / 16)), dim3(256), 0, stream, k);
+  }
   return hipGetLastError() == hipSuccess ? TF_OK : TF_ERR_LAUNCH;
 }

@@ -64,7 +64,7 @@ class WgradArgs(C.Structure):
                 ("KH", i32), ("KW", i32), ("stride", i32), ("pad", i32),
                 ("ldx", i32), ("lddy", i32), ("pro_relu", i32),
                 ("x", vp), ("dy", vp), ("dw_oihw", vp), ("pro_scale", vp), ("pro_shift", vp),
-                ("dw_ld", i32), ("splitk", i32), ("tile", i32), ("packed", i32)]
+                ("dw_ld", i32), ("splitk", i32), ("tile", i32), ("packed", i32), ("partial_ws", vp), ("partial_ws_bytes", sz)]
 
 
 _SIGNATURES = {
@@ -75,6 +75,7 @@ _SIGNATURES = {
     "tf_dense_overlap_targets": (i32, [vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, u64, f64, f64,
                                        vp, vp, vp, sz, vp]),
     "tf_dense_overlap_iou": (i32, [vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "tf_pairwise_iou_distance": (i32, [vp, i32, vp, vp]),
     "tf_nms_workspace_bytes": (sz, [i32]),
     "tf_nms_f64": (i32, [vp, vp, i32, f64, vp, vp, vp, sz, vp]),
     "tf_nms_batched_workspace_bytes": (sz, [C.POINTER(i32), i32]),
@@ -89,6 +90,7 @@ _SIGNATURES = {
     "tf_conv2d": (i32, [C.POINTER(ConvArgs), vp]),
     "tf_pack_weight": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp]),
     "tf_conv2d_wgrad": (i32, [C.POINTER(WgradArgs), vp]),
+    "tf_wgrad_workspace_bytes": (sz, [C.POINTER(WgradArgs)]),
     "tf_unpack_dw": (i32, [vp, i32, i32, i32, vp, vp]),
     "tf_stem_im2col": (i32, [vp, i32, i32, i32, i32, vp, i32, vp]),
     "tf_maxpool_fwd": (i32, [i32, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]),

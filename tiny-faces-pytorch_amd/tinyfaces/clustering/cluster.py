@@ -20,9 +20,13 @@ def centralize_bbox(bboxes):
     return np.stack([-half_w, -half_h, half_w, half_h], axis=1)
 
 
-def compute_distances(bboxes):
+def compute_distances(bboxes, device=None):
     """1 - jaccard_index for every pair (cluster.py:28-37 with tinyfaces/metrics.py:8-40: plain areas, no +1, IoU 0 when the
-    union is not positive)."""
+    union is not positive).  device='cuda': the n^2 matrix comes from the HIP kernel (tf_pairwise_iou_distance, bit-exact with
+    this expression), which is what the 5000-box default of compute_kmedoids (25 M distances) wants; None: numpy on the host."""
+    if device is not None and str(device) != "cpu":
+        from .. import ops
+        return ops.pairwise_iou_distance(bboxes, device=device).cpu().numpy()
     b = np.asarray(bboxes, dtype=np.float64)
     area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
     xa = np.maximum(b[:, None, 0], b[None, :, 0]); ya = np.maximum(b[:, None, 1], b[None, :, 1])
@@ -55,7 +59,7 @@ def k_medoids(distances, k, rng=np.random):
     return medoids, member
 
 
-def compute_kmedoids(bboxes, cls, option="local", indices=15, max_clusters=35, max_limit=5000, rng=np.random):
+def compute_kmedoids(bboxes, cls, option="local", indices=15, max_clusters=35, max_limit=5000, rng=np.random, device=None):
     """cluster.py:40-130 for option='local': one clustering per k in [indices, max_clusters].  The returned list keeps the
     reference's shape: `indices` empty dicts first, then one entry per k, so entry k sits at index k when the caller passes
     indices == max_clusters == k, which is how tinyfaces/datasets/__init__.py:26-33 reads clustering[num_templates]."""
@@ -66,7 +70,7 @@ def compute_kmedoids(bboxes, cls, option="local", indices=15, max_clusters=35, m
     shapes = centralize_bbox(bboxes)
     if shapes.shape[0] > max_limit:
         shapes = shapes[rng.choice(np.arange(shapes.shape[0]), size=max_limit, replace=False)]
-    dist = compute_distances(shapes)
+    dist = compute_distances(shapes, device=device)
     for k in range(indices, max_clusters + 1):
         medoids, _ = k_medoids(dist, k, rng)
         clustering.append({"n_clusters": k, "medoids": [shapes[m, :] for m in medoids], "class": cls})

@@ -118,6 +118,18 @@ def dense_overlap_iou(boxes, templates, heatmap_size=(63, 63), rf=RF, device="cu
     return out
 
 
+def pairwise_iou_distance(boxes, device="cuda"):
+    """1 - IoU for every pair of (x1, y1, x2, y2) float64 boxes: the distance matrix of the template clustering
+    (tinyfaces/clustering/cluster.py:28-37), (n, n) float64 device tensor, bit-exact with the reference's double loop."""
+    b = torch.as_tensor(np.asarray(boxes), dtype=torch.float64).reshape(-1, 4).contiguous().to(device)
+    require_gpu(b, "pairwise_iou_distance")
+    n = b.shape[0]
+    out = torch.empty(n, n, dtype=torch.float64, device=b.device)
+    with torch.cuda.device(b.device):
+        check(lib().tf_pairwise_iou_distance(ptr(b), n, ptr(out), stream()), "tf_pairwise_iou_distance")
+    return out
+
+
 # --------------------------------------------------------------------------- NMS
 def nms(boxes, scores, iou_threshold):
     """torchvision.ops.nms semantics on float64 device tensors (call site tinyfaces/evaluation.py:84).
@@ -327,8 +339,9 @@ def conv2d_nhwc(x, w_packed, Cout, KH, KW, stride, pad, mode=0, out_hw=None, ldy
     return (y, stats) if want_stats else y
 
 
-def conv2d_wgrad(x, dy, Cin, Cout, KH, KW, stride, pad, pro=None, splitk=0, tile=0, out=None, packed=False):
-    """x (N,H,W,ldx), dy (N,OH,OW,lddy) -> dW (Cout,Cin,KH,KW) fp32."""
+def conv2d_wgrad(x, dy, Cin, Cout, KH, KW, stride, pad, pro=None, splitk=0, tile=0, out=None, packed=False, two_phase=False):
+    """x (N,H,W,ldx), dy (N,OH,OW,lddy) -> dW (Cout,Cin,KH,KW) fp32.  two_phase: hand the all-taps 3x3 kernel a partial-tile
+    workspace so that its split-K slices are summed by a second kernel instead of fp32 atomics."""
     require_gpu(x, "conv2d_wgrad")
     N, H, W, ldx = x.shape
     _, OH, OW, lddy = dy.shape
@@ -341,6 +354,12 @@ def conv2d_wgrad(x, dy, Cin, Cout, KH, KW, stride, pad, pro=None, splitk=0, tile
     a.ldx, a.lddy, a.x, a.dy, a.dw_oihw, a.dw_ld, a.splitk = ldx, lddy, ptr(x), ptr(dy), ptr(dw), Cin * KH * KW, splitk
     if pro is not None:
         a.pro_scale, a.pro_shift, a.pro_relu = ptr(pro[0]), ptr(pro[1]), int(pro[2])
+    ws = None
+    if two_phase:
+        nbytes = lib().tf_wgrad_workspace_bytes(C.byref(a))
+        if nbytes:
+            ws = _workspace("wgrad3", nbytes, x.device)
+            a.partial_ws, a.partial_ws_bytes = ptr(ws), nbytes
     with torch.cuda.device(x.device):
         check(lib().tf_conv2d_wgrad(C.byref(a), stream()), "tf_conv2d_wgrad")
     return dw
