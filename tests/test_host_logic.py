@@ -228,8 +228,23 @@ def test_bench_reads_committed_pmc_traffic():
     spec.loader.exec_module(bench)
     t = bench.pmc_traffic(13)
     assert t is not None and 2e7 < t < 3e8
-    assert bench.pmc_traffic(14) is not None                     # wgrad_dma rows exist too
+    assert bench.pmc_traffic(14) is not None                     # weight-gradient rows exist too
     assert bench.pmc_traffic(5) is None                          # a kernel kind with no pattern: None, not an exception
+    # a file whose kernel names no longer match the binary must fail loudly, not report a stale number
+    import json
+    import pytest
+    stale = dict(json.load(open(bench.PMC_TRAFFIC_FILE)))
+    stale["kernels"] = {"some_renamed_kernel<1>": next(iter(stale["kernels"].values()))}
+    old = bench.PMC_TRAFFIC_FILE
+    try:
+        import tempfile
+        with tempfile.NamedTemporaryFile("w", suffix=".json", delete=False) as f:
+            json.dump(stale, f)
+        bench.PMC_TRAFFIC_FILE = f.name
+        with pytest.raises(RuntimeError, match="regenerate"):
+            bench.pmc_traffic(13)
+    finally:
+        bench.PMC_TRAFFIC_FILE = old
 
 
 def test_template_clustering_vs_reference_golden(golden):

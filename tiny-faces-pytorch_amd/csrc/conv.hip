@@ -366,6 +366,13 @@ int pick_tile(const tf_conv_args* a) {
     static const bool t12_off = getenv("TINYFACES_T12_SHORTK_OFF") != nullptr;
     const int nst = a->KH * a->KW * (a->Cin / 64);
     if (!t12_off && a->dtype != TF_F32 && nst <= 4) return 32;
+    // 32x32x16 fragments (64 pixels x 128 channels per block, 32 x 64 per wave, 2-deep ring) win where a launch still has several
+    // blocks per CU AND a long K loop: 3x3 convs / K >= 576 with M >= 16 384 pixels -- layer 2 at bs = 12 (26.3 vs 32.9 us forward,
+    // 25.0 vs 30.6 us data gradient) and layers 2-3 of the evaluation pyramid (41.0 vs 50.6, 40.2 vs 44.8, 21.3 vs 23.8 us);
+    // at M = 12 288 (layer 3, bs = 12) they lose: one block per CU, nothing hides a wave's LDS latency
+    // (profiles/r02a_microbench_mma32_tiles.txt, profiles/r02a_microbench_eval_tiles.txt)
+    static const bool mma32_off = getenv("TINYFACES_MMA32_OFF") != nullptr;
+    if (!mma32_off && a->dtype != TF_F32 && nst >= 9 && M >= 16384 && a->Cout % 128 == 0) return 46;
     return 13;
   }
   return t2 >= 256 ? 2 : 3;                       // producer-BN prologue needs the register-staged kernel

@@ -157,7 +157,7 @@ __device__ __forceinline__ void dma16(const void* gsrc, void* lds_wave_base) {
 // MMA = 32: 32x32x16 fragments (bf16/fp16), accumulators of a 64 x 64 wave tile = 64 registers -> two waves per SIMD
 //           (__launch_bounds__(256, 2): up to 256 VGPR+AGPR per lane, no spills; profiles/r02*_kernel_resources.txt)
 template <typename T, int BM, int BN, int NS, int KIND, int MMA = 16>
-__global__ void __launch_bounds__(256, MMA == 32 ? 2 : 5) conv_dma_kernel(const DmaK a) {
+__global__ void __launch_bounds__(256, MMA == 32 ? 2 : (NS == 1 && BM == 128 ? 4 : 5)) conv_dma_kernel(const DmaK a) {
   constexpr int KCH = MmaD<T>::KCH;
   constexpr int EPS = tf::Elem<T>::kPer16B;
   constexpr int XR = BM / 32, WR = BN / 32;
@@ -206,6 +206,26 @@ __global__ void __launch_bounds__(256, MMA == 32 ? 2 : 5) conv_dma_kernel(const 
   for (int i = 0; i < WR; ++i) {
     const int row = lrow + i * 32;
     wsrc[i] = a.w + ((size_t)(n0 + row) * a.Ktot + (pslot ^ swz(row)) * EPS) * sizeof(T);
+  }
+
+  // Ring-less variants (K <= 256: the wide 1x1 convs and the hand-over data gradients) are epilogue-bound: their residual /
+  // mask / statistic operands (up to three tensors as large as the output) used to be requested only after the K loop, with the
+  // whole HBM latency exposed once per block.  Request them NOW: they travel while the K stages are DMA-ed and multiplied.
+  // (Older loads retire first, so the counted vmcnt waits of the K loop are unaffected.)
+  constexpr bool PREF = (NS == 1 && KIND == 1);      // the pointwise ring-less variants: every hot instance (the gather variants would spill)
+  constexpr int P_CPR = BN / EPS, P_RPP = 256 / P_CPR, P_PASSES = BM / P_RPP;
+  uint4 pf1[P_PASSES], pf2[P_PASSES];      // (the third operand, STATS3's / JOIN's aux3, stays a late load: registers)
+  if constexpr (PREF) {
+    const int pchunk = tid % P_CPR, prl = tid / P_CPR, pc0 = n0 + pchunk * EPS;
+    const bool w1 = a.epi & (TF_EPI_RES | TF_EPI_MASK | TF_EPI_STATS2), w2 = a.epi & (TF_EPI_JOIN | TF_EPI_MASK2);
+#pragma unroll
+    for (int ps = 0; ps < P_PASSES; ++ps) {
+      const int p = m0 + prl + ps * P_RPP;
+      const bool ok = p < a.M && pc0 < a.ldy;
+      const size_t o = ((size_t)(ok ? p : 0) * a.ldy + (ok ? pc0 : 0)) * sizeof(T);
+      pf1[ps] = (ok && w1) ? *reinterpret_cast<const uint4*>(a.aux + o) : make_uint4(0, 0, 0, 0);
+      pf2[ps] = (ok && w2) ? *reinterpret_cast<const uint4*>(a.aux2 + o) : make_uint4(0, 0, 0, 0);
+    }
   }
 
   // stage iterator (scalar): stages are issued in order, so (slot, chunk, kw, kh) advance incrementally
@@ -344,7 +364,9 @@ __global__ void __launch_bounds__(256, MMA == 32 ? 2 : 5) conv_dma_kernel(const 
     if (p < a.M && cok) {
       const size_t o = ((size_t)p * a.ldy + c0) * sizeof(T);
       float ax[EPS];
-      if (a.epi & (TF_EPI_RES | TF_EPI_MASK | TF_EPI_STATS2)) tf::unpack16<T>(*reinterpret_cast<const uint4*>(a.aux + o), ax);
+      if (a.epi & (TF_EPI_RES | TF_EPI_MASK | TF_EPI_STATS2)) {
+        if constexpr (PREF) tf::unpack16<T>(pf1[ps], ax); else tf::unpack16<T>(*reinterpret_cast<const uint4*>(a.aux + o), ax);
+      }
       if (a.epi & TF_EPI_AFFINE) {
 #pragma unroll
         for (int j = 0; j < EPS; ++j) v[j] = v[j] * es[j] + eh[j];
@@ -359,14 +381,14 @@ __global__ void __launch_bounds__(256, MMA == 32 ? 2 : 5) conv_dma_kernel(const 
       }
       if (a.epi & TF_EPI_JOIN) {
         float y2[EPS], g3[EPS];
-        tf::unpack16<T>(*reinterpret_cast<const uint4*>(a.aux2 + o), y2);
+        if constexpr (PREF) tf::unpack16<T>(pf2[ps], y2); else tf::unpack16<T>(*reinterpret_cast<const uint4*>(a.aux2 + o), y2);
         tf::unpack16<T>(*reinterpret_cast<const uint4*>(a.aux3 + o), g3);
 #pragma unroll
         for (int j = 0; j < EPS; ++j) v[j] += (y2[j] > 0.f) ? g3[j] : 0.f;
       }
       if (a.epi & TF_EPI_MASK2) {
         float y2[EPS];
-        tf::unpack16<T>(*reinterpret_cast<const uint4*>(a.aux2 + o), y2);
+        if constexpr (PREF) tf::unpack16<T>(pf2[ps], y2); else tf::unpack16<T>(*reinterpret_cast<const uint4*>(a.aux2 + o), y2);
 #pragma unroll
         for (int j = 0; j < EPS; ++j) v[j] = (y2[j] > 0.f) ? v[j] : 0.f;
       }

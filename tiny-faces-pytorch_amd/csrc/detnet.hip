@@ -639,6 +639,8 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
       // the weight gradients are off the critical chain: lowest priority, so the data-gradient chain's workgroups are placed first
       int least = 0, greatest = 0;
       static const bool flat_prio = getenv("TINYFACES_SIDE_PRIO_DEFAULT") != nullptr;      // A/B knob
+      // (A CU mask on this stream -- hipExtStreamCreateWithCUMask, 160-224 of the 256 CUs, to keep CUs free for the data-gradient
+      //  chain -- was measured: 603 img/s instead of 1054 whatever the mask, the masked queue no longer overlaps the other one.)
       if (flat_prio || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess ||
           hipStreamCreateWithPriority(&g_side, hipStreamNonBlocking, least) != hipSuccess) {
         if (hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) != hipSuccess) g_side = nullptr;
@@ -697,6 +699,12 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
 
   // one fork per weight gradient (default) or, TINYFACES_FORK_PER_BLOCK=1, one per block: measured 948 vs 943 img/s
   static const bool fork_each = getenv("TINYFACES_FORK_PER_BLOCK") == nullptr;
+  // Every fork makes its producer kernel carry a completion signal, which costs ~6 us of main-queue bubble behind that kernel
+  // (profiles/r02b_step_timeline.txt: 90 x 5.9 us).  The 22 identity bottlenecks of layer 3 therefore fork ONCE, behind the
+  // BN1-backward apply, when the dY operands of all three weight gradients exist: conv3's and conv2's gradients start ~100 us
+  // later and overlap the next bottleneck instead, far from the end of the pass (layer 1 / 2 and the stem keep one fork per
+  // gradient so that the tail of the weight-gradient stream stays short).  TINYFACES_L3_FORK_PER_WGRAD=1: the old schedule.
+  static const bool l3_single_fork = getenv("TINYFACES_L3_FORK_PER_WGRAD") == nullptr;
   // ---- bottlenecks in reverse
   std::vector<hipEvent_t> block_done(A.blocks.size(), nullptr);
   for (int i = (int)A.blocks.size() - 1; i >= 0; --i) {
@@ -707,6 +715,7 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
     const void* yin = i == 0 ? P.pool : P.blk[i - 1].y;
     const void* extra = (i == A.layer_end[1] + 1) ? P.R3 : nullptr;     // the block whose INPUT is res3
     const int par = i & 1;
+    const bool late = fused && fork_each && l3_single_fork && i > A.layer_end[1] && !B.has_ds;    // the three gradients behind ONE fork
     void *T1 = P.S1[par], *T2 = P.S2[par], *U1 = P.S3[par], *T3 = P.SD[par];
     // this parity's buffers were last read by the weight gradients of block i+2: wait for them
     if (i + 2 < (int)A.blocks.size()) c.wait_on_main(block_done[i + 2]);
@@ -718,7 +727,7 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
     // (2) g_c3 -> T1
     if (fused) {
       const tf_bn_bwd_desc d = bwd_desc(c, B.c3, b.b3, b.b3.bst, nk, 1);
-      if (fork_each) c.arm_fork();
+      if (fork_each && !late) c.arm_fork();
       c.chk(tf_bn_bwd_apply_fused(dtype, Gcur, nullptr, b.c3, &d, srows, Mout, c4, (float)Mout, T1, c.stream));
     } else {
       bn_backward_coefs(c, B.c3, c4, b.b3, P.partial, nb, nk, 1, c4, (float)Mout, B.has_ds ? 0 : 1);   // the last reader clears the partial rows
@@ -727,7 +736,7 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
     }
     // (3) wgrad conv3 (its input is relu(bn2(c2)), materialised in the forward)
     auto wg3 = [&]() { wgrad(c, B.c3, c4, N, b.Hout, b.Wout, b.Hout, b.Wout, b.a2, pl, T1, c4, nullptr); };
-    if (fork_each) { c.fork_armed(); wg3(); }
+    if (fork_each && !late) { c.fork_armed(); wg3(); }
     // (4) dgrad conv3 -> gz2 in T2 (masked by relu(bn2(c2))) + BN-backward sums
     conv_fill(a, dtype, 1, N, b.Hout, b.Wout, c4, b.Hout, b.Wout, pl, 1, 1, 0, pl, T1, b.w3t, T2);
     a.epi = TF_EPI_MASK | TF_EPI_STATS2; a.aux = b.c2; a.mask_scale = b.b2.scale; a.mask_shift = b.b2.shift;
@@ -736,7 +745,7 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
     // (5) g_c2 in place
     if (fused) {
       const tf_bn_bwd_desc d = bwd_desc(c, B.c2, b.b2, b.b2.bst, 2, 1);
-      if (fork_each) c.arm_fork();
+      if (fork_each && !late) c.arm_fork();
       c.chk(tf_bn_bwd_apply_fused(dtype, T2, nullptr, b.c2, &d, srows, Mout, pl, (float)Mout, T2, c.stream));
     } else {
       bn_backward_coefs(c, B.c2, pl, b.b2, P.partial, tf_conv_mtiles(&a), 2, 1, pl, (float)Mout);
@@ -744,7 +753,7 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
     }
     // (6) wgrad conv2 (input relu(bn1(c1)))
     auto wg2 = [&]() { wgrad(c, B.c2, pl, N, b.Hin, b.Win, b.Hout, b.Wout, b.a1, pl, T2, pl, nullptr, 0, 0, 0, P.dwp, P.dwp_floats); };
-    if (fork_each) { c.fork_armed(); wg2(); }
+    if (fork_each && !late) { c.fork_armed(); wg2(); }
     // (7) dgrad conv2 -> gz1 in U1 (+ sums); output spatial = conv2's input
     conv_fill(a, dtype, 1, N, b.Hout, b.Wout, pl, b.Hin, b.Win, pl, 3, B.stride, 1, pl, T2, b.w2t, U1);
     a.epi = TF_EPI_MASK | TF_EPI_STATS2; a.aux = b.c1; a.mask_scale = b.b1.scale; a.mask_shift = b.b1.shift;
@@ -761,7 +770,7 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
     }
     // (9) wgrad conv1 (input = block input, already activated)
     auto wg1 = [&]() { wgrad(c, B.c1, pl, N, b.Hin, b.Win, b.Hin, b.Win, yin, B.cin, U1, pl, nullptr); };
-    if (fork_each) { c.fork_armed(); wg1(); }
+    if (fork_each) { c.fork_armed(); if (late) { wg3(); wg2(); } wg1(); }
     // (10) gradient w.r.t. the block input -> Gnext.  Fused flow: the conv that completes it also applies the ReLU mask of
     //      the previous block's output (MASK2 with aux2 = yin) and, unless that block has a downsample branch, accumulates
     //      its BN3-backward sums (STATS3 with aux3 = its c3), so the next iteration starts at step (2).

@@ -201,26 +201,35 @@ __global__ void __launch_bounds__(NT, 2) wgrad3x3_kernel(const W3K a) {
     }
 }
 
-// dW += sum over the slices of the partial tiles.  256 threads = 16 float4 columns x 16 slice groups: a thread sums every 16th
-// slice of its four elements, the 16 partial sums meet in LDS -- so a one-tile layer (layer 1: 256 slices of ONE 64 x 64 x 9
-// tile) still spreads over 576 blocks instead of 36
+// dW += sum over the slices of the partial tiles.  256 threads = (256 / SG) float4 columns x SG slice groups; SG is chosen so that a
+// thread sums >= 8 slices (SG = 2 for the 16 slices of layer 3, 16 for the 256 slices of layer 1's single tile): enough loads in
+// flight per thread, and a one-tile layer still spreads over hundreds of blocks.  The SG partial sums meet in LDS.
+template <int SG>
 __global__ void __launch_bounds__(256) wgrad3x3_reduce_kernel(const W3K a) {
-  __shared__ float4 part[16][17];
+  constexpr int COLS = 256 / SG;
+  __shared__ float4 part[SG][COLS + 1];
   const int ntiles = a.nco * a.nci;
-  const size_t total4 = (size_t)ntiles * TILE_FLOATS / 4;
-  const int col = threadIdx.x & 15, sg = threadIdx.x >> 4;
-  const size_t e4 = (size_t)blockIdx.x * 16 + col;                 // total4 is a multiple of 16 (TILE_FLOATS / 4 = 9216)
+  const size_t total4 = (size_t)ntiles * TILE_FLOATS / 4;              // a multiple of 256
+  const int col = threadIdx.x % COLS, sg = threadIdx.x / COLS;
+  const size_t e4 = (size_t)blockIdx.x * COLS + col;
+  const size_t stride = (size_t)ntiles * TILE_FLOATS;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (e4 < total4)
-    for (int ks = sg; ks < a.splitk; ks += 16) {
-      const float4 v = *reinterpret_cast<const float4*>(a.partial + ((size_t)ks * ntiles * TILE_FLOATS + e4 * 4));
+  if (e4 < total4) {
+    const float* src = a.partial + e4 * 4;
+#pragma unroll 4
+    for (int ks = sg; ks < a.splitk; ks += SG) {
+      const float4 v = *reinterpret_cast<const float4*>(src + (size_t)ks * stride);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
-  part[sg][col] = s;
-  __syncthreads();
-  if (sg != 0 || e4 >= total4) return;
+  }
+  if (SG > 1) {
+    part[sg][col] = s;
+    __syncthreads();
+    if (sg != 0) return;
 #pragma unroll
-  for (int g = 1; g < 16; ++g) { const float4 v = part[g][col]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+    for (int g = 1; g < SG; ++g) { const float4 v = part[g][col]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+  }
+  if (e4 >= total4) return;
   const size_t e = e4 * 4;
   const int tile = (int)(e / TILE_FLOATS), rem = (int)(e - (size_t)tile * TILE_FLOATS);
   const int t = rem / 4096, co = (tile / a.nci) * 64 + (rem % 4096) / 64, ci = (tile % a.nci) * 64 + rem % 64;
@@ -292,7 +301,10 @@ int tf_wgrad3x3_launch(const tf_wgrad_args* A, hipStream_t stream) {
   }
   if (k.partial) {
     const size_t total4 = (size_t)k.nco * k.nci * TILE_FLOATS / 4;
-    hipLaunchKernelGGL(wgrad3x3_reduce_kernel, dim3((unsigned)((total4 + 15) / 16)), dim3(256), 0, stream, k);
+    if (k.splitk >= 128)     hipLaunchKernelGGL(wgrad3x3_reduce_kernel<16>, dim3((unsigned)(total4 / 16)), dim3(256), 0, stream, k);
+    else if (k.splitk >= 32) hipLaunchKernelGGL(wgrad3x3_reduce_kernel<4>, dim3((unsigned)(total4 / 64)), dim3(256), 0, stream, k);
+    else if (k.splitk >= 16) hipLaunchKernelGGL(wgrad3x3_reduce_kernel<2>, dim3((unsigned)(total4 / 128)), dim3(256), 0, stream, k);
+    else                     hipLaunchKernelGGL(wgrad3x3_reduce_kernel<1>, dim3((unsigned)(total4 / 256)), dim3(256), 0, stream, k);
   }
   return hipGetLastError() == hipSuccess ? TF_OK : TF_ERR_LAUNCH;
 }
