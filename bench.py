@@ -488,7 +488,7 @@ def main():
     #      EVERY MFMA launch bracketed and the weight gradients on the caller's stream, so that per-kernel times are free of
     #      two-stream contention and add up to less than the step they were taken from
     extra = {}
-    if world == 1 and not args.no_profile:
+    if world == 1 and not args.no_profile and not args.layer_table:       # (--layer-table keeps the shapes of the TIMED region)
         try:
             b = pool[0]
             m = eng.model
