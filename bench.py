@@ -119,6 +119,20 @@ def cpu_baseline(bs=12, warmup=1, steps=2, eval_warmup=1, eval_runs=1, threads=N
     timed = times[warmup:] if len(times) > warmup else times
     steps = len(timed)
     dt = float(np.median(timed))
+    # the reference's own target assignment is a four-deep Python loop (dense_overlap.py:30-75): its literal cost for ONE box
+    b1 = np.array([[100.0, 120.0, 180.0, 230.0]])
+    t0 = time.perf_counter()
+    otgt.dense_overlap_loop(-1, -1, 8, 8, 63, 63, t[:, 0], t[:, 1], t[:, 2], t[:, 3], b1[:, 0], b1[:, 1], b1[:, 2], b1[:, 3])
+    loop_ms = (time.perf_counter() - t0) * 1e3
+    # eval forward of one 500x500 image
+    m.eval()
+    xe = torch.randn(1, 3, 500, 500, generator=g)
+    fw = []
+    with torch.no_grad():
+        for _ in range(4):
+            t0 = time.perf_counter()
+            m(xe)
+            fw.append(time.perf_counter() - t0)
     # eval leg: the 3-scale pyramid of configs[1] on the CPU path, on FRESH weights (the three SGD steps above move the score
     # distribution of the random-weight detector: 45 k survivors and minutes of CPU NMS instead of a few thousand candidates)
     m = o_tame(OracleDetectionModel(num_templates=25), 0).eval()
@@ -136,7 +150,9 @@ def cpu_baseline(bs=12, warmup=1, steps=2, eval_warmup=1, eval_runs=1, threads=N
             "sample": f"median of {steps} timed bs={bs} 500x500 training steps after {warmup} warm-up (numpy target assignment "
                       f"{np.median(t_tgt[-steps:]) * 1e3:.0f} ms/step + torch-CPU fp32 fwd/criterion/bwd/SGD); eval leg: median of "
                       f"{eval_runs} get_detections runs after {eval_warmup} warm-up on a 1280x960 image, scales (-1,0,1), CPU NMS",
-            "ms_per_step": round(dt * 1e3, 1), "eval_ms_per_image": round(float(np.median(et[eval_warmup:] if len(et) > eval_warmup else et)) * 1e3, 1), "eval_kept": kept,
+            "ms_per_step": round(dt * 1e3, 1), "targets_ms_per_image": round(float(np.median(t_tgt[-steps:])) * 1e3 / bs, 1),
+            "dense_overlap_quad_loop_ms_per_box": round(loop_ms, 1), "eval_forward_500x500_ms": round(float(np.median(fw[1:])) * 1e3, 1),
+            "eval_ms_per_image": round(float(np.median(et[eval_warmup:] if len(et) > eval_warmup else et)) * 1e3, 1), "eval_kept": kept,
             "cpu": _cpu_model(), "host_threads": os.cpu_count(), "torch": torch.__version__}
 
 
