@@ -33,9 +33,9 @@ PEAK_HBM_GBS = 8000.0
 FWD_GFLOP_PER_IMG = 73.559                           # BASELINE.md section 3 (2*MACs of all 97 convs @500x500)
 PROFILE_EVERY = 11                                    # roofline timing: HIP events around every 11th MFMA launch (287 launches/step is not a multiple: the sample rotates over the layers)
 # kernel kinds of tf_profile_collect (csrc/profile.hip): the executor only launches 12-15; 0-11 are the register-staged kernels kept for the C ABI
-KIND_NAMES = {12: "conv_dma<f32>", 13: "conv_dma<bf16>", 14: "wgrad_dma<bf16>", 15: "conv_dma<f16>",
+KIND_NAMES = {6: "conv3x3h<bf16>", 7: "conv3x3h<f16>", 12: "conv_dma<f32>", 13: "conv_dma<bf16>", 14: "wgrad_dma<bf16>", 15: "conv_dma<f16>",
               8: "wgrad<f32,64>", 9: "wgrad<f32,128>", 10: "wgrad<bf16,64>", 11: "wgrad<bf16,128>"}
-BF16_KINDS = (3, 4, 5, 10, 11, 13, 14, 15)
+BF16_KINDS = (3, 4, 5, 6, 7, 10, 11, 13, 14, 15)
 
 
 def tame_init_(model, seed=0):

@@ -353,12 +353,16 @@ int tf_image_prepare(const tf_image_prepare_args* a, void* stream);
  * the stream it is launched on.  tf_profile_collect blocks until they completed and writes
  * rows of 5 doubles to HOST memory: kind, launches, total_ms, algorithmic flops, algorithmic
  * bytes.  kind 0..5 = conv_igemm (dtype*3 + tile-1), 8..11 = wgrad (8 + dtype*2 + (tile==128)),
- * 12/13 = conv_dma f32/bf16, 14 = wgrad_dma bf16. */
+ * 12/13/15 = conv_dma f32/bf16/f16, 14 = wgrad_dma bf16, 6/7 = conv3x3h bf16/f16. */
 int tf_profile_enable(int every);   /* 0 = off, 1 = bracket every launch, n = every n-th launch (sampling keeps the timed region undisturbed) */
 int tf_profile_collect(double* host_out, int max_rows);
 /* per layer shape, for the records consumed by the LAST tf_profile_collect: rows of 11 doubles
  * (kind, M pixels, N output channels, K reduction length, taps, mode (0 fwd, 1 dgrad, 2 wgrad), epilogue flags, launches, total_ms, flops, bytes) */
 int tf_profile_shapes(double* host_out, int max_rows);
+/* debugging hook of the halo-resident 3x3 kernel (csrc/conv3x3h.hip): register (NULL: clear) a DEVICE buffer of
+ * 8 blocks x 8 waves x 64 stages x 8 uint64; the next launches run an instrumented instantiation that stamps s_memtime at the
+ * five points of every K stage (scripts/trace_conv3x3h.py).  Not part of the product path. */
+int tf_debug_conv3x3h_trace(void* device_buf);
 /* test hook: raw lane mapping of ds_read_b64_tr_b16 (see tests/test_gpu_small_ops.py) */
 int tf_probe_tr16(unsigned short* out256, void* stream);
 

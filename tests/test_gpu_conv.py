@@ -641,6 +641,94 @@ def test_conv_mma32_refuses_fp32():
         ops.conv2d_nhwc(x, w, 64, 1, 1, 1, 0, tile=14)
 
 
+# ------------------------------------------------------------------ halo-resident 3x3 / stride 1 kernel (round 2, csrc/conv3x3h.hip)
+C3H_CASES = [
+    # N, H, W, Cin, Cout
+    (1, 1, 1, 64, 128),         # one pixel: 8 of the 9 taps read only the zero halo
+    (2, 4, 32, 64, 128),        # exactly one tile per image
+    (2, 5, 33, 128, 128),       # one row / one column past a tile: edge tiles in both directions, 2 channel chunks
+    (1, 21, 70, 64, 256),       # 3 column tiles (the last 6 wide), 2 channel tiles
+    (3, 32, 32, 256, 256),      # layer-3 shape (smaller batch)
+    (1, 63, 63, 128, 128),      # layer-2 shape
+    (1, 9, 40, 320, 384),       # 5 chunks (odd), 3 channel tiles
+]
+
+
+@pytest.mark.parametrize("dtype", HALF)
+@pytest.mark.parametrize("case", C3H_CASES)
+def test_conv3x3h_forward_and_dgrad(dtype, case):
+    """Forward and data gradient of the halo-resident kernel (tile code 50): chunk-major K order, taps as row shifts of the
+    6 x 34 frame, K halves added in the epilogue -- against torch-CPU fp32 fed the same rounded operands, and against the
+    im2col kernel (tile 13) on the same operands (same products, different summation order)."""
+    from tinyfaces import ops
+    N, H, W, Cin, Cout = case
+    g = _g(hash(case) % 1000)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    xr = q(x, dtype).requires_grad_(True)
+    ref = F.conv2d(xr, q(w, dtype), padding=1)
+    gy = torch.randn(ref.shape, generator=g)
+    ref.backward(q(gy, dtype))
+    wp, wt = ops.pack_weight(w.cuda(), dtype), ops.pack_weight(w.cuda(), dtype, transpose=True)
+    y = ops.conv2d_nhwc(to_nhwc(x, dtype), wp, Cout, 3, 3, 1, 1, tile=50)
+    y13 = ops.conv2d_nhwc(to_nhwc(x, dtype), wp, Cout, 3, 3, 1, 1, tile=13)
+    d = err(from_nhwc(y), ref.detach())
+    gx = ops.conv2d_nhwc(to_nhwc(gy, dtype), wt, Cin, 3, 3, 1, 1, mode=1, out_hw=(H, W), tile=50) if Cin % 128 == 0 else None
+    report(f"conv3x3h[{dtype},{case}]", fwd_rel=d[2], vs_im2col=err(from_nhwc(y), from_nhwc(y13).float().cpu())[2])
+    assert d[2] < TOL_H[dtype]
+    assert err(from_nhwc(y), from_nhwc(y13).float().cpu())[2] < TOL_H[dtype]
+    if gx is not None:                      # the data gradient's output channels are the forward's input channels: 128-multiples only
+        dg = err(from_nhwc(gx), xr.grad)
+        assert dg[2] < TOL_H[dtype]
+
+
+def test_conv3x3h_epilogues():
+    """The epilogues the executor asks of a 3x3 conv: STATS (training forward; tile pixels outside the image must not count),
+    AFFINE + RELU (evaluation), MASK + STATS2 (data gradient through ReLU(BN)), with more tiles than statistic rows."""
+    from tinyfaces import _hip, ops
+    dtype = torch.bfloat16
+    g = _g(77)
+    N, H, W, Cin, Cout = 3, 30, 45, 128, 256          # 3 * 8 * 2 = 48 tiles > TF_STAT_ROWS: atomics into mt % rows
+    x = torch.randn(N, Cin, H, W, generator=g) + 0.25
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    ref = F.conv2d(q(x, dtype), q(w, dtype), padding=1)
+    wp = ops.pack_weight(w.cuda(), dtype)
+    y, st = ops.conv2d_nhwc(to_nhwc(x, dtype), wp, Cout, 3, 3, 1, 1, epi=_hip.EPI_STATS, want_stats=True, tile=50)
+    n = ref.numel() / Cout
+    ssum = st.sum(0).cpu()
+    assert st.shape[0] < 48          # folded into tf_get_stat_rows() rows
+    assert err(from_nhwc(y), ref)[2] < TOL[dtype]
+    assert err(ssum[0] / n, ref.mean(dim=(0, 2, 3)))[0] < 2e-3 and err(ssum[1] / n, (ref ** 2).mean(dim=(0, 2, 3)))[2] < 2e-3
+    sc, sh = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    y = ops.conv2d_nhwc(to_nhwc(x, dtype), wp, Cout, 3, 3, 1, 1, epi=_hip.EPI_AFFINE | _hip.EPI_RELU, epi_scale=sc.cuda(), epi_shift=sh.cuda(), tile=50)
+    assert err(from_nhwc(y), torch.relu(ref * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)))[2] < TOL[dtype]
+    # data gradient: dX = conv_transpose(dY) masked by the producer's ReLU(BN(c_raw)), with the dgamma / dbeta partial sums
+    gy = torch.randn(N, Cout, H, W, generator=g)
+    craw = torch.randn(N, Cin, H, W, generator=g)
+    ms, mh = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.5
+    base = F.conv_transpose2d(q(gy, dtype), q(w, dtype), padding=1)
+    refm = base * ((q(craw, dtype) * ms.view(1, -1, 1, 1) + mh.view(1, -1, 1, 1)) > 0)
+    wt = ops.pack_weight(w.cuda(), dtype, transpose=True)
+    y, st = ops.conv2d_nhwc(to_nhwc(gy, dtype), wt, Cin, 3, 3, 1, 1, mode=1, out_hw=(H, W), epi=_hip.EPI_MASK | _hip.EPI_STATS2,
+                            aux=to_nhwc(craw, dtype), mask=(ms.cuda(), mh.cuda()), want_stats=True, tile=50)
+    s = st.sum(0).cpu()
+    assert err(from_nhwc(y), refm)[2] < TOL[dtype]
+    assert err(s[0], refm.sum(dim=(0, 2, 3)))[2] < 5e-3 and err(s[1], (refm * q(craw, dtype)).sum(dim=(0, 2, 3)))[2] < 5e-3
+
+
+def test_conv3x3h_refuses_what_it_cannot_do():
+    from tinyfaces import ops
+    x = torch.randn(1, 8, 8, 64, device="cuda", dtype=torch.bfloat16)
+    w = ops.pack_weight(torch.randn(64, 64, 3, 3, device="cuda"), torch.bfloat16)
+    with pytest.raises(RuntimeError):                                   # 64 output channels: not a multiple of the 128-wide tile
+        ops.conv2d_nhwc(x, w, 64, 3, 3, 1, 1, tile=50)
+    w = ops.pack_weight(torch.randn(128, 64, 3, 3, device="cuda"), torch.bfloat16)
+    with pytest.raises(RuntimeError):                                   # stride 2
+        ops.conv2d_nhwc(x, w, 128, 3, 3, 2, 1, tile=50)
+    with pytest.raises(RuntimeError):                                   # fp32
+        ops.conv2d_nhwc(x.float(), ops.pack_weight(torch.randn(128, 64, 3, 3, device="cuda"), torch.float32), 128, 3, 3, 1, 1, tile=50)
+
+
 # ------------------------------------------------------------------ all-taps 3x3 weight gradient (round 2, csrc/wgrad3x3.hip)
 W3_CASES = [
     # N, H, W, Cin, Cout

@@ -25,6 +25,9 @@
 #include "profile.h"
 
 int tf_conv_dma_launch(const tf_conv_args* a, int tile, int depth, hipStream_t stream);   // conv_dma.hip
+bool tf_conv3x3h_applicable(const tf_conv_args* a, bool forced);                              // conv3x3h.hip
+int tf_conv3x3h_mtiles(const tf_conv_args* a);
+int tf_conv3x3h_launch(const tf_conv_args* a, hipStream_t stream);
 
 namespace {
 
@@ -352,7 +355,7 @@ int launch_conv(const tf_conv_args* A, hipStream_t stream) {
 // tile codes: 1/2/3 = register-staged 128x128 / 128x64 / 64x64 (pixels x channels); 11/12/13 = LDS-DMA pipeline with a
 // 3-deep ring (13: the ring depth then follows K, see tf_conv_dma_launch), 21/22/23 = 4-deep ring, 32 = ring-less 128x64;
 // x4/x5/x6 = LDS-DMA pipeline on 32x32x16 fragments, 128x128 / 128x64 / 64x128, ring depth 3 (14..16), ring-less (34..36) or 2 (44..46).
-// 0 = auto.
+// 50 = halo-resident 3x3 / stride 1 kernel (conv3x3h.hip).  0 = auto.
 int pick_tile(const tf_conv_args* a) {
   if (a->tile) return a->tile;
   // measured on the bs=12 500x500 layer shapes (scripts/microbench.py): 128 pixels x 64 channels wins on every
@@ -371,6 +374,9 @@ int pick_tile(const tf_conv_args* a) {
     // 25.0 vs 30.6 us data gradient) and layers 2-3 of the evaluation pyramid (41.0 vs 50.6, 40.2 vs 44.8, 21.3 vs 23.8 us);
     // at M = 12 288 (layer 3, bs = 12) they lose: one block per CU, nothing hides a wave's LDS latency
     // (profiles/r02a_microbench_mma32_tiles.txt, profiles/r02a_microbench_eval_tiles.txt)
+    // 3x3 / stride 1 with >= 128 output channels and enough tiles to fill the chip: the halo-resident kernel (conv3x3h.hip), which
+    // moves each input byte into LDS once per 64-channel chunk instead of once per tap
+    if (tf_conv3x3h_applicable(a, false)) return 50;
     static const bool mma32_off = getenv("TINYFACES_MMA32_OFF") != nullptr;
     if (!mma32_off && a->dtype != TF_F32 && nst >= 9 && M >= 16384 && a->Cout % 128 == 0) return 46;
     return 13;
@@ -384,6 +390,7 @@ int tile_bm(int t) { return ((t % 10) == 3 || (t % 10) == 6) ? 64 : 128; }
 extern "C" int tf_conv_mtiles(const tf_conv_args* a) {
   const long M = (long)a->N * a->OH * a->OW;
   const int t = pick_tile(a);
+  if (t == 50) { const int mt = tf_conv3x3h_mtiles(a); return mt > tf_get_stat_rows() ? tf_get_stat_rows() : mt; }
   const int bm = tile_bm(t);
   const int mt = (int)((M + bm - 1) / bm);
   return (t >= 10 && mt > tf_get_stat_rows()) ? tf_get_stat_rows() : mt;     // the DMA kernel folds its tiles into <= TF_STAT_ROWS rows
@@ -411,6 +418,7 @@ extern "C" int tf_conv2d(const tf_conv_args* a, void* stream_) {
   if ((a->epi & TF_EPI_MASK) && (!a->mask_scale || !a->mask_shift)) return TF_ERR_ARG;
   if (a->pro_scale && !a->pro_shift) return TF_ERR_ARG;
   const int t = pick_tile(a);
+  if (t == 50) return tf_conv3x3h_applicable(a, true) ? tf_conv3x3h_launch(a, stream) : TF_ERR_UNSUPPORTED;
   if (t >= 10) {
     if (a->pro_scale) return TF_ERR_UNSUPPORTED;
     return tf_conv_dma_launch(a, t % 10, t >= 40 ? 2 : (t >= 30 ? 1 : (t >= 20 ? 4 : 3)), stream);

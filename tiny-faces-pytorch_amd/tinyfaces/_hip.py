@@ -127,6 +127,7 @@ _SIGNATURES = {
     "tf_profile_enable": (i32, [i32]),
     "tf_profile_shapes": (i32, [C.POINTER(C.c_double), i32]),
     "tf_profile_collect": (i32, [C.POINTER(C.c_double), i32]),
+    "tf_debug_conv3x3h_trace": (i32, [vp]),
 }
 
 _lib = None
