@@ -39,6 +39,7 @@ struct W3K {
   int N, H, W, Cin, Cout, ldx, lddy, dw_ld, ci_stride, tap_stride;
   int Hp, Wp, HWp, Mp;              // padded frame: H+2, W+2, their product, N * HWp
   int nco, nci, splitk, chunk, hb;  // hb = halo in 64-row chunks on either side: ceil((Wp + 1) / 64)
+  int q64, r64, small_frame, dbg;   // 64 = q64 * Wp + r64; small_frame: a frame of <= q64 + 1 rows (loop in PadPos::advance)
 };
 
 constexpr int PK = 64, NS = 3, YT = PK * 128, XROWS = 512, XBYTES = XROWS * 128, L = 2, NT = 512;
@@ -56,27 +57,6 @@ __device__ __forceinline__ int fsw(int row) { return ((row >> 1) & 3) << 1; }
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
-// dY fragment: 16 channels (c0 multiple of 16) x 32 pixels of a linear 64-row stage tile; k <-> pixel = h*16 + g*4 + j
-__device__ __forceinline__ bf16x8 frag_y(const char* tile, int pk0, int c0) {
-  const int l = threadIdx.x & 63, i = l & 15, g = l >> 4;
-  const int row = pk0 + g * 4 + (i >> 2);
-  const int slot = (c0 >> 3) + ((i & 3) >> 1);
-  const char* p = tile + row * 128 + ((slot ^ fsw(row)) << 4) + ((i & 1) << 3);
-  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p));
-  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + 16 * 128));
-  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-}
-// X fragment from the circular image: ring row of the fragment's first pixel = rowbase (any integer, wrapped here)
-__device__ __forceinline__ bf16x8 frag_x(const char* ring, int rowbase, int c0) {
-  const int l = threadIdx.x & 63, i = l & 15, g = l >> 4;
-  const int row = (rowbase + g * 4 + (i >> 2)) & (XROWS - 1);
-  const int slot = (c0 >> 3) + ((i & 3) >> 1);
-  const int off = row * 128 + ((slot ^ fsw(row)) << 4) + ((i & 1) << 3);
-  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(ring + off));
-  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(ring + ((off + 16 * 128) & (XBYTES - 1))));   // fsw(row+16) == fsw(row)
-  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-}
-
 // (image, padded row, padded column) of a padded pixel index, advanced 64 at a time
 struct PadPos {
   int n, hp, wp;
@@ -88,16 +68,39 @@ struct PadPos {
     const int rem = rr - q * a.HWp;
     hp = rem / a.Wp; wp = rem - hp * a.Wp;
   }
+  // + 64 pixels = + q64 rows + r64 columns (q64 = 64 / Wp, r64 = 64 % Wp: launch constants), carries by select: no loop, no
+  // divergent branch for any frame of more than q64 + 1 rows; smaller frames (H <= 2 at W <= 30 ...) take the loop
+  template <bool SMALL>
   __device__ __forceinline__ void advance(const W3K& a) {
-    wp += PK;
-    while (wp >= a.Wp) { wp -= a.Wp; if (++hp == a.Hp) { hp = 0; ++n; } }
+    wp += a.r64;
+    const int c = wp >= a.Wp ? 1 : 0;
+    wp -= c * a.Wp;
+    hp += a.q64 + c;
+    if (SMALL) { while (hp >= a.Hp) { hp -= a.Hp; ++n; } }
+    else { const int c2 = hp >= a.Hp ? 1 : 0; hp -= c2 * a.Hp; n += c2; }
   }
-  __device__ __forceinline__ bool interior(const W3K& a) const {
-    return (unsigned)n < (unsigned)a.N && (unsigned)(hp - 1) < (unsigned)a.H && (unsigned)(wp - 1) < (unsigned)a.W;
+  __device__ __forceinline__ bool interior(const W3K& a) const {       // (bitwise: no short-circuit control flow)
+    return ((unsigned)n < (unsigned)a.N) & ((unsigned)(hp - 1) < (unsigned)a.H) & ((unsigned)(wp - 1) < (unsigned)a.W);
   }
-  __device__ __forceinline__ size_t pixel(const W3K& a) const { return ((size_t)n * a.H + (hp - 1)) * a.W + (wp - 1); }
+  __device__ __forceinline__ int pixel(const W3K& a) const { return (n * a.H + (hp - 1)) * a.W + (wp - 1); }
 };
 
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+constexpr int STG_PITCH = 68;                            // floats per staged [co] row of 64 ci: 272 B, 16-byte aligned, conflict-light
+
+__device__ __forceinline__ bf16x8 read_tr_pair(const char* base, int off_lo, int off_hi) {
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(base + off_lo));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(base + off_hi));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// The K loop is written for INSTRUCTION COUNT (the first version re-derived every fragment address per tap and stage and walked
+// the padded raster with data-dependent loops: ~410 instructions, 8 divergent branches per stage and wave for 36 MFMAs):
+//   * the 18 X-fragment ring offsets of a lane (9 taps x 2 k-steps) are registers that advance by 64 rows (8 KiB) per stage
+//     modulo the 64 KiB ring; the swizzle term is stage-invariant (64 and the 512-row wrap are multiples of 8 rows);
+//   * the 4 dY-fragment offsets are fixed; the ring slot is a scalar add;
+//   * the DMA source walk is branch-free (PadPos::advance).
+template <bool SMALL>
 __global__ void __launch_bounds__(NT, 2) wgrad3x3_kernel(const W3K a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const yring = smem;
@@ -112,7 +115,7 @@ __global__ void __launch_bounds__(NT, 2) wgrad3x3_kernel(const W3K a) {
   const int x0 = pb - PK * a.hb;                         // padded index of ring row 0
   const int D = 2 * a.hb;                                // stage st needs X chunks st .. st + D
   const int tid = threadIdx.x, r = tid >> 3, pslot = tid & 7;      // one row of every 64-row group per thread
-  const int wave_byte = (tid & ~63) * 16;
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
   const char* zero = reinterpret_cast<const char*>(g_w3zero_page) + pslot * 16;
 
   // physical slot pslot of row r receives logical slot pslot ^ fsw(r) (swizzle on the SOURCE)
@@ -123,19 +126,21 @@ __global__ void __launch_bounds__(NT, 2) wgrad3x3_kernel(const W3K a) {
   int yrow = pb + r;                                     // padded index of this thread's dY row in the NEXT stage to issue
   const int ycol = co0 + ls * 8, xcol = ci0 + ls * 8;
   const bool ycok = ycol + 8 <= a.lddy, xcok = xcol + 8 <= a.ldx;
-  int ys_slot = 0, xc = 0;                               // dY ring slot / X chunk index of the next issue
+  const char* const ybase = a.dy + (size_t)ycol * 2;
+  const char* const xbase = a.x + (size_t)xcol * 2;
+  int ys_slot = 0, xc = 0;                               // dY ring slot / X chunk index of the next issue (scalar)
   auto issue_y = [&]() {
-    const bool ok = yrow < pe && ycok && ypos.interior(a);
-    const uintptr_t src = ok ? reinterpret_cast<uintptr_t>(a.dy) + (ypos.pixel(a) * a.lddy + ycol) * 2 : reinterpret_cast<uintptr_t>(zero);
-    dma16(reinterpret_cast<const void*>(src), yring + ys_slot * YT + wave_byte);
-    ypos.advance(a); yrow += PK;
+    const bool ok = (yrow < pe) & ycok & ypos.interior(a);
+    const unsigned off = ok ? (unsigned)ypos.pixel(a) * (unsigned)(a.lddy * 2) : 0u;        // (the launch checks that a tensor is < 4 GiB)
+    dma16((ok ? ybase : zero) + off, yring + ys_slot * YT + wave_u * 1024);
+    ypos.template advance<SMALL>(a); yrow += PK;
     if (++ys_slot == NS) ys_slot = 0;
   };
   auto issue_x = [&]() {
-    const bool ok = xcok && xpos.interior(a);
-    const uintptr_t src = ok ? reinterpret_cast<uintptr_t>(a.x) + (xpos.pixel(a) * a.ldx + xcol) * 2 : reinterpret_cast<uintptr_t>(zero);
-    dma16(reinterpret_cast<const void*>(src), xring + ((xc * PK) & (XROWS - 1)) * 128 + wave_byte);
-    xpos.advance(a);
+    const bool ok = xcok & xpos.interior(a);
+    const unsigned off = ok ? (unsigned)xpos.pixel(a) * (unsigned)(a.ldx * 2) : 0u;
+    dma16((ok ? xbase : zero) + off, xring + (xc & 7) * (PK * 128) + wave_u * 1024);
+    xpos.template advance<SMALL>(a);
     ++xc;
   };
 
@@ -145,6 +150,29 @@ __global__ void __launch_bounds__(NT, 2) wgrad3x3_kernel(const W3K a) {
 #pragma unroll
     for (int n = 0; n < 2; ++n) acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int wave = tid >> 6, wco = wave & 1, wci = wave >> 1;      // 2 x 4 waves: 32 output channels x 16 input channels each
+
+  // fragment offsets (bytes).  Transposing read of 16 channels x 32 pixels: lane (i = l & 15, g = l >> 4) reads rows
+  // g*4 + (i >> 2) and +16 of the 32-pixel k-step, 8 bytes at 16-byte slot (c0 >> 3) + ((i & 3) >> 1), half (i & 1)
+  const int l = tid & 63, li = l & 15, lg = l >> 4;
+  const int frow = lg * 4 + (li >> 2), fhalf = (li & 1) << 3, fs = (li & 3) >> 1;
+  int yoff[2][2];                                        // [k-step][n]: inside a 64-row dY stage tile; the +16-row half is +2048
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int row = k * 32 + frow, slot = ((wco * 32 + n * 16) >> 3) + fs;
+      yoff[k][n] = row * 128 + ((slot ^ fsw(row)) << 4) + fhalf;
+    }
+  int xoff[9][2];                                        // [tap][k-step]: inside the 512-row ring, for the CURRENT stage
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int shift = (t / 3 - 1) * a.Wp + (t % 3 - 1);
+      const int row = (PK * a.hb + k * 32 + shift + frow) & (XROWS - 1);        // stage 0: ring row of padded pixel pb + k*32 + shift
+      const int slot = ((wci * 16) >> 3) + fs;
+      xoff[t][k] = row * 128 + ((slot ^ fsw(row)) << 4) + fhalf;
+    }
 
   // prologue: the halo chunks 0 .. D-1 first, then the (dY stage, X chunk) pairs of stages 0 and 1.  From then on every loop
   // iteration issues exactly one pair (L = 2 DMA instructions per thread), so vmcnt(L) == "everything but the youngest pair landed"
@@ -156,36 +184,53 @@ __global__ void __launch_bounds__(NT, 2) wgrad3x3_kernel(const W3K a) {
     wait_vm<L*(NS - 2)>();                               // pair (st+1) may still be in flight; pair st and all older ones landed
     __builtin_amdgcn_s_barrier();                        // everyone's pieces of stage st landed; stage st-1 fully consumed
     issue_y(); issue_x();                                // pair st + 2 (dY slot (st+2) % 3, X chunk st + D + 2)
-    const char* ys = yring + cs * YT;
-    const int rb0 = PK * (st + a.hb);                    // ring row of padded pixel pb + 64 st
+    if (!(a.dbg & 1)) {
+      const char* ys = yring + cs * YT;
 #pragma unroll
-    for (int k0 = 0; k0 < PK; k0 += 32) {
-      bf16x8 fy[2];
+      for (int k = 0; k < 2; ++k) {
+        bf16x8 fy[2];
 #pragma unroll
-      for (int n = 0; n < 2; ++n) fy[n] = frag_y(ys, k0, wco * 32 + n * 16);
+        for (int n = 0; n < 2; ++n) fy[n] = read_tr_pair(ys, yoff[k][n], yoff[k][n] + 16 * 128);
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int shift = (t / 3 - 1) * a.Wp + (t % 3 - 1);
-        const bf16x8 fx = frag_x(xring, rb0 + k0 + shift, wci * 16);
+        for (int t = 0; t < 9; ++t) {
+          const int o = xoff[t][k];
+          const bf16x8 fx = read_tr_pair(xring, o, (o + 16 * 128) & (XBYTES - 1));          // fsw(row + 16) == fsw(row)
+          xoff[t][k] = (o + PK * 128) & (XBYTES - 1);                                         // next stage: 64 rows further round the ring
 #pragma unroll
-        for (int n = 0; n < 2; ++n) acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[n], fx, acc[t][n], 0, 0, 0);
+          for (int n = 0; n < 2; ++n) acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[n], fx, acc[t][n], 0, 0, 0);
+        }
       }
     }
     if (++cs == NS) cs = 0;
   }
   wait_vm<0>();                                          // drain the pairs issued past the end before the LDS is released
 
-  const int l = tid & 63, li = l & 15, lg = l >> 4;
   if (a.partial) {
-    // [slice][tile][tap][co 64][ci 64]: 16 lanes write 64 contiguous bytes
+    // [slice][tile][tap][co 64][ci 64] fp32.  Through LDS, three taps at a time, so that a lane stores 16 contiguous bytes and a
+    // wave 1 KiB: the direct form (72 4-byte stores per lane, 16 lanes per 64-byte run) was bound by store ISSUE
+    // (147 KiB per block at ~7 B/clk: as long as the whole K loop).
+    if (a.dbg & 2) return;
     float* out = a.partial + ((size_t)ks * (a.nco * a.nci) + (size_t)tco * a.nci + tci) * TILE_FLOATS;
+    float* stg = reinterpret_cast<float*>(smem);
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t0 = 0; t0 < 9; t0 += 3) {
+      __syncthreads();                                   // rings (first round) / previous round fully read
 #pragma unroll
-      for (int n = 0; n < 2; ++n)
+      for (int tl = 0; tl < 3; ++tl)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          out[(t * 64 + wco * 32 + n * 16 + lg * 4 + q) * 64 + wci * 16 + li] = acc[t][n][q];
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            stg[(tl * 64 + wco * 32 + n * 16 + lg * 4 + q) * STG_PITCH + wci * 16 + li] = acc[t0 + tl][n][q];
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const int e4 = tid + k * NT;                     // float4 index inside the 3 x 64 x 64 round
+        const int row = e4 >> 4, c4 = e4 & 15;           // row = tl * 64 + co
+        const f32x4v v = *reinterpret_cast<const f32x4v*>(stg + row * STG_PITCH + c4 * 4);
+        *reinterpret_cast<f32x4v*>(out + (size_t)t0 * 4096 + (size_t)e4 * 4) = v;
+      }
+    }
     return;
   }
 #pragma unroll
@@ -252,8 +297,10 @@ bool w3_plan(const tf_wgrad_args* A, W3K& k) {
   k.Hp = A->H + 2; k.Wp = A->W + 2; k.HWp = k.Hp * k.Wp;
   const long long mp = (long long)A->N * k.HWp;
   if (mp > (1ll << 30)) return false;
+  if ((long long)A->N * A->H * A->W * 2 * (A->ldx > A->lddy ? A->ldx : A->lddy) >= (1ll << 32)) return false;       // 32-bit byte offsets in the DMA walk
   k.Mp = (int)mp;
   k.hb = (k.Wp + 1 + PK - 1) / PK;
+  k.q64 = PK / k.Wp; k.r64 = PK % k.Wp; k.small_frame = k.Hp <= k.q64 + 1; k.dbg = 0;
   k.nco = (A->Cout + 63) / 64; k.nci = (A->Cin + 63) / 64;
   const int tiles = k.nco * k.nci;
   int sk = A->splitk;
@@ -287,17 +334,21 @@ int tf_wgrad3x3_launch(const tf_wgrad_args* A, hipStream_t stream) {
   const size_t need = (size_t)k.splitk * k.nco * k.nci * TILE_FLOATS * sizeof(float);
   static const bool atomics_only = getenv("TINYFACES_WGRAD3_ATOMICS") != nullptr;      // A/B knob
   if (A->partial_ws && A->partial_ws_bytes >= need && !atomics_only) k.partial = (float*)A->partial_ws;
+  static const int dbg = [] { const char* e = getenv("TINYFACES_WGRAD3_DBG"); return e ? atoi(e) : 0; }();     // timing ablation: 1 = no MFMA loop body, 2 = no partial stores (results invalid)
+  k.dbg = dbg;
   const size_t lds = (size_t)NS * YT + XBYTES;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   const double Md = (double)A->N * A->H * A->W;
   {
     tf::ProfScope prof(14, 2.0 * Md * A->Cout * A->Cin * 9, (Md * A->Cout + Md * A->Cin) * 2 + (double)A->Cout * A->Cin * 9 * 4, stream, (int)Md,
                        A->Cout, A->Cin * 9, 9, 2, 0);
-    hipLaunchKernelGGL(wgrad3x3_kernel, dim3(k.nco * k.nci * k.splitk), dim3(NT), lds, stream, k);
+    if (k.small_frame) hipLaunchKernelGGL(wgrad3x3_kernel<true>, dim3(k.nco * k.nci * k.splitk), dim3(NT), lds, stream, k);
+    else hipLaunchKernelGGL(wgrad3x3_kernel<false>, dim3(k.nco * k.nci * k.splitk), dim3(NT), lds, stream, k);
   }
   if (k.partial) {
     const size_t total4 = (size_t)k.nco * k.nci * TILE_FLOATS / 4;
