@@ -37,7 +37,16 @@ def test_main_and_evaluate_model_scripts(tmp_path):
     out = _run([main, "synthetic", "synthetic", "--epochs", "2", "--save-every", "1", "--synthetic-len", "8", "--batch_size", "4", "--lr", "1e-5",
                 "--resume", str(ck), "--no-fused", "--dtype", "fp32"], tmp_path)
     assert "Epoch: [1][1/2]" in out
-    # evaluation: two synthetic images through the loader contract of evaluate_model.py:60-68, result files of evaluation.py:90-114
+    # evaluation: two synthetic images through the loader contract of evaluate_model.py:60-68, result files of evaluation.py:90-114.
+    # (A kaiming-initialised head regresses exp(huge) = inf box sizes, which int() in write_results refuses like the reference's does:
+    # evaluate a checkpoint in the same format whose heads are scaled down, bench.py's random-init recipe.)
+    sys.path.insert(0, ROOT); sys.path.insert(0, PKG)
+    from bench import tame_init_
+    from tinyfaces.models.model import DetectionModel
+    m = DetectionModel(num_objects=1, num_templates=25)
+    tame_init_(m, seed=3)
+    ck = tmp_path / "weights" / "tame.pth"
+    torch.save({"epoch": 1, "batch_size": 4, "model": m.state_dict(), "optimizer": {}}, ck)
     out = _run([evalm, "synthetic", "--checkpoint", str(ck), "--num-images", "2", "--prob_thresh", "0.5", "--results_dir", str(tmp_path / "res")], tmp_path)
     files = sorted(os.listdir(tmp_path / "res" / "synthetic"))
     assert files == ["img_0.txt", "img_1.txt"]

@@ -38,9 +38,10 @@ constexpr int BM = TR * TC, BN = 128, NT = 512;
 constexpr int XPASS = 4, XBUF = XPASS * 64 * 128;                     // frame buffer: 256 rows of 128 B (rows >= FR unused)
 constexpr int WPASS = 2, WBUF = BN * 128;                             // weight stage: 128 channels x 64 k
 constexpr int W_AT = 2 * XBUF;
-constexpr int NSW = 3, LDS_BYTES = W_AT + NSW * WBUF;                // 3-deep weight ring (9 taps = 3 turns): 112 KiB
-constexpr int PITCH = BN + 4;
-static_assert(BM * PITCH * 4 <= LDS_BYTES, "epilogue staging tile overlays the operand rings");
+constexpr int NSW = 3;                                               // 3-deep weight ring (9 taps = 3 turns)
+constexpr int PITCH = BN + 4, STG_FLOATS = BM * PITCH;
+constexpr int RING_BYTES = W_AT + NSW * WBUF;                          // 112 KiB
+constexpr int LDS_BYTES = 2 * STG_FLOATS * 4 > RING_BYTES ? 2 * STG_FLOATS * 4 : RING_BYTES;      // the two epilogue staging tiles (132 KiB) overlay the rings
 
 struct HK {
   const char* x; const char* w; char* y;
@@ -78,7 +79,7 @@ constexpr int TRACE_BYTES = 8 * 64 * 8 * 8;
 template <typename T, bool TRACE>
 __global__ void __launch_bounds__(NT, 2) conv3x3h_kernel(const HK a) {
   typedef typename Frag<T>::t frag;
-  constexpr int EPS = 8, TRACE_AT = LDS_BYTES;
+  constexpr int EPS = 8, TRACE_AT = RING_BYTES;       // (the stamps are dumped before the epilogue overlays them)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned long long t_start = 0, r_start = 0;
   if constexpr (TRACE) { t_start = __builtin_amdgcn_s_memtime(); r_start = __builtin_amdgcn_s_memrealtime(); }
@@ -135,6 +136,11 @@ __global__ void __launch_bounds__(NT, 2) conv3x3h_kernel(const HK a) {
 #pragma unroll
     for (int i = 0; i < WPASS; ++i) dma16(wptr[i] + kofs_bytes, dst + i * 8192);
   };
+  // request the first frame and the first two weight stages NOW: they travel while the fragment offsets below are computed
+  const int cpt = a.cpt, tapC = a.C * (int)sizeof(T);      // bytes between two taps of one weight row
+  issue_x();
+  issue_w(std::integral_constant<int, 0>{}, 0);
+  issue_w(std::integral_constant<int, 1>{}, tapC);
 
   // ---- MFMA roles: wave = (K half kg, pixel half wm, channel half wn); 2 x 2 fragments of 32 pixels x 32 channels
   const int kg = wave >> 2, wm = wave & 1, wn = (wave >> 1) & 1;
@@ -164,10 +170,6 @@ __global__ void __launch_bounds__(NT, 2) conv3x3h_kernel(const HK a) {
 #pragma unroll
     for (int m = 0; m < 2; ++m) acc[n][m] = f32x16(0.f);
 
-  const int cpt = a.cpt, tapC = a.C * (int)sizeof(T);      // bytes between two taps of one weight row
-  issue_x();
-  issue_w(std::integral_constant<int, 0>{}, 0);
-  issue_w(std::integral_constant<int, 1>{}, tapC);
   int st = 0;
   for (int chunk = 0; chunk < cpt; ++chunk) {
     const bool more = chunk + 1 < cpt;              // another chunk follows
@@ -184,12 +186,15 @@ __global__ void __launch_bounds__(NT, 2) conv3x3h_kernel(const HK a) {
       stamp(st, 1);
       __builtin_amdgcn_s_barrier();                 // everyone's pieces landed; everyone finished reading stage st-1's buffers
       stamp(st, 2);
-      if (!TRACE || !(a.dbg & 1)) {
-        if (tap == 0 && more) issue_x();
-        // stage st+2 = tap+2 of this chunk, or tap+2-9 of the next one
-        if (tap < 7) issue_w(std::integral_constant<int, (tap + 2) % 3>{}, (tap + 2) * tapC + kchunk);
-        else if (more) issue_w(std::integral_constant<int, (tap + 2) % 3>{}, (tap + 2 - 9) * tapC + kchunk + 128);
-      }
+      auto issue = [&]() {
+        if (!TRACE || !(a.dbg & 1)) {
+          if (tap == 0 && more) issue_x();
+          // stage st+2 = tap+2 of this chunk, or tap+2-9 of the next one
+          if (tap < 7) issue_w(std::integral_constant<int, (tap + 2) % 3>{}, (tap + 2) * tapC + kchunk);
+          else if (more) issue_w(std::integral_constant<int, (tap + 2) % 3>{}, (tap + 2 - 9) * tapC + kchunk + 128);
+        }
+      };
+      issue();               // (issuing after the first MFMA group instead was measured: no difference, profiles/r02_conv3x3h_trace.txt)
       stamp(st, 3);
       if (!TRACE || !(a.dbg & 2)) {
         const char* wb = smem + (tap % 3) * WBUF;
@@ -238,31 +243,19 @@ __global__ void __launch_bounds__(NT, 2) conv3x3h_kernel(const HK a) {
 
   unsigned long long e_t[5] = {0, 0, 0, 0, 0};
   if constexpr (TRACE) e_t[0] = __builtin_amdgcn_s_memtime();
-  // ---------------- epilogue, phase 1: fp32 [BM][BN+4] tile in LDS = K half 0 + K half 1
+  // ---------------- epilogue, phase 1: one fp32 [BM][BN+4] tile in LDS per K half (both halves write at once; phase 2 adds them)
   // 32x32 accumulator: lane l holds pixel l & 31, channels 8*g + 4*(l >> 5) + {0..3} for g = 0..3 (registers 4g .. 4g+3)
   float* stg = reinterpret_cast<float*>(smem);
-  if (kg == 0) {
+  {
+    float* mine = stg + kg * STG_FLOATS;
 #pragma unroll
     for (int n = 0; n < 2; ++n)
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-          *reinterpret_cast<f32x4*>(stg + (wm * 64 + m * 32 + r32) * PITCH + wn * 64 + n * 32 + g * 8 + h * 4) =
+          *reinterpret_cast<f32x4*>(mine + (wm * 64 + m * 32 + r32) * PITCH + wn * 64 + n * 32 + g * 8 + h * 4) =
               f32x4{acc[n][m][4 * g], acc[n][m][4 * g + 1], acc[n][m][4 * g + 2], acc[n][m][4 * g + 3]};
-  }
-  __syncthreads();
-  if (kg == 1) {
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          f32x4* q = reinterpret_cast<f32x4*>(stg + (wm * 64 + m * 32 + r32) * PITCH + wn * 64 + n * 32 + g * 8 + h * 4);
-          const f32x4 t = *q;
-          *q = f32x4{t[0] + acc[n][m][4 * g], t[1] + acc[n][m][4 * g + 1], t[2] + acc[n][m][4 * g + 2], t[3] + acc[n][m][4 * g + 3]};
-        }
   }
   __syncthreads();
   if constexpr (TRACE) e_t[1] = __builtin_amdgcn_s_memtime();
@@ -294,7 +287,8 @@ __global__ void __launch_bounds__(NT, 2) conv3x3h_kernel(const HK a) {
     float v[EPS];
 #pragma unroll
     for (int j = 0; j < EPS; j += 4) {
-      const f32x4 t = *reinterpret_cast<const f32x4*>(stg + row * PITCH + chunk8 * EPS + j);
+      const f32x4 t = *reinterpret_cast<const f32x4*>(stg + row * PITCH + chunk8 * EPS + j) +
+                      *reinterpret_cast<const f32x4*>(stg + STG_FLOATS + row * PITCH + chunk8 * EPS + j);
       v[j] = t[0]; v[j + 1] = t[1]; v[j + 2] = t[2]; v[j + 3] = t[3];
     }
     if (a.epi & TF_EPI_STATS) {
@@ -405,7 +399,7 @@ void launch_var(const HK& k, hipStream_t stream) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3h_kernel<T, TRACE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv3x3h_kernel<T, TRACE>), dim3(k.mtiles * k.ntiles), dim3(NT), LDS_BYTES + (TRACE ? TRACE_BYTES : 0), stream, k);
+  hipLaunchKernelGGL((conv3x3h_kernel<T, TRACE>), dim3(k.mtiles * k.ntiles), dim3(NT), TRACE && RING_BYTES + TRACE_BYTES > LDS_BYTES ? RING_BYTES + TRACE_BYTES : LDS_BYTES, stream, k);
 }
 
 template <typename T>
@@ -442,6 +436,10 @@ bool tf_conv3x3h_applicable(const tf_conv_args* a, bool forced) {
   if (forced) return true;
   static const bool off = getenv("TINYFACES_CONV3H_OFF") != nullptr;
   if (off) return false;
+  // >= 4 channel chunks (36 stages): with the 18 stages of layer 2 (128 channels) the prologue / epilogue weigh too much and the
+  // 64 x 128 im2col tile wins (A/B on one box: 1116 / 1114 img/s without layer 2, 1107 / 1111 with)
+  static const int min_cin = [] { const char* e = getenv("TINYFACES_CONV3H_MINCIN"); return e ? atoi(e) : 256; }();
+  if (a->Cin < min_cin) return false;
   const long blocks = (long)a->N * ((a->OH + TR - 1) / TR) * ((a->OW + TC - 1) / TC) * (a->Cout / BN);
   return blocks >= min_blocks();
 }

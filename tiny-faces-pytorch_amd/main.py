@@ -107,6 +107,7 @@ def main():
         if state is not None:
             engine.load_optimizer_state_dict(state.get("optimizer"))      # momentum buffers (a torch.optim.SGD state_dict)
     else:
+        model = model.to(device)          # before load_state_dict: torch casts the momentum buffers to the device the parameters are on THEN
         optimizer = optim.SGD(model.learnable_parameters(args.lr), lr=args.lr, momentum=args.momentum, weight_decay=args.weight_decay)
         if state is not None and state.get("optimizer", {}).get("param_groups"):
             optimizer.load_state_dict(state["optimizer"])                 # main.py:76
