@@ -31,16 +31,15 @@ hipEvent_t take_next_stop_event();
 constexpr int kWave = 64;
 
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
-// round-to-nearest-even (same as torch's float->bfloat16); NaN kept quiet
-__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
-}
+// float -> bfloat16, round-to-nearest-even (same as torch's float->bfloat16; NaN stays NaN): the gfx950 conversion instruction
+// v_cvt_pk_bf16_f32 (two values per instruction).  The integer sequence it replaces (add 0x7fff + lsb, NaN test) cost ~6 VALU
+// operations and, through the NaN select, a pair of exec-mask updates PER ELEMENT in every epilogue.
+typedef __bf16 tf_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float tf_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(tf_f32x2{lo, hi}, tf_bf16x2));
 }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) { return (uint16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
 
 template <typename T> struct Elem;
 template <> struct Elem<float> {
