@@ -157,7 +157,7 @@ def cpu_baseline(bs=12, warmup=1, steps=2, eval_warmup=1, eval_runs=1, threads=N
 
 
 PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-PMC_PATTERNS = {13: ("conv_dma_kernel<tf::bf16_t,",), 12: ("conv_dma_kernel<float,",), 15: ("conv_dma_kernel<tf::f16_t,",),
+PMC_PATTERNS = {6: ("conv3x3h_kernel<tf::bf16_t,",), 7: ("conv3x3h_kernel<tf::f16_t,",), 13: ("conv_dma_kernel<tf::bf16_t,",), 12: ("conv_dma_kernel<float,",), 15: ("conv_dma_kernel<tf::f16_t,",),
                 14: ("wgrad_dma_kernel", "wgrad3x3_kernel")}
 
 
