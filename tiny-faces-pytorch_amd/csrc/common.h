@@ -103,10 +103,36 @@ __device__ __forceinline__ double wave_sum(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// v + (v of lane ^ O) for O = 8, 16, 32 without the LDS crossbar (`__shfl_xor` is ds_bpermute_b32: an LDS instruction plus an
+// lgkmcnt wait per level): a DPP row rotation folded into the add (8), and the gfx950 row-swap instructions
+// v_permlane16_swap / v_permlane32_swap (with both operands = v they leave "my half" and "the other half" in the two results).
+template <int O> __device__ __forceinline__ float lane_xor_sum(float v) {
+  if constexpr (O == 8) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+  } else if constexpr (O == 16) {
+    typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+    const u32x2_ r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+  } else if constexpr (O == 32) {
+    typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+    const u32x2_ r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+  } else {
+    return v + __shfl_xor(v, O, 64);
+  }
+}
+// sum over the lanes that share (lane % FROM): the levels FROM, 2*FROM, ... 32
+template <int FROM> __device__ __forceinline__ float lane_group_sum(float v) {
+  if constexpr (FROM <= 32) { v = lane_xor_sum<FROM>(v); if constexpr (FROM < 32) v = lane_group_sum<FROM * 2>(v); }
   return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  // inside a 16-lane row: four rotate-and-add steps (every lane ends with the row total), then the two row swaps
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));   // row_ror:8
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));   // row_ror:4
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));   // row_ror:2
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));   // row_ror:1
+  return lane_group_sum<16>(v);
 }
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 

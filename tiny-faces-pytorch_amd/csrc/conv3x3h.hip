@@ -342,10 +342,7 @@ __global__ void __launch_bounds__(NT, 2) conv3x3h_kernel(const HK a) {
   if constexpr (TRACE) e_t[2] = __builtin_amdgcn_s_memtime();
   if (a.epi & (TF_EPI_STATS | TF_EPI_STATS2 | TF_EPI_STATS3)) {       // block-uniform: column sums of the tile
 #pragma unroll
-    for (int o = CPR; o < 64; o <<= 1) {
-#pragma unroll
-      for (int j = 0; j < EPS; ++j) { s1[j] += __shfl_xor(s1[j], o, 64); s2[j] += __shfl_xor(s2[j], o, 64); }
-    }
+    for (int j = 0; j < EPS; ++j) { s1[j] = tf::lane_group_sum<CPR>(s1[j]); s2[j] = tf::lane_group_sum<CPR>(s2[j]); }       // DPP / row swaps, no LDS crossbar
     __syncthreads();                                 // staging tile fully consumed
     float* red = reinterpret_cast<float*>(smem);     // [8 waves][2][BN]
     const int lane = tid & 63;

@@ -411,10 +411,15 @@ __global__ void __launch_bounds__(256, MMA == 32 ? 2 : (NS == 1 && BM == 128 ? 4
   }
   if (a.epi & (TF_EPI_STATS | TF_EPI_STATS2 | TF_EPI_STATS3)) {       // block-uniform: column sums of the tile
     // lanes sharing a chunk inside a wave differ in the lane bits >= log2(CPR)
+    if (a.dbg & 16) {                                // A/B knob (TF_CONV_DBG=16): the ds_bpermute form
 #pragma unroll
-    for (int o = CPR; o < 64; o <<= 1) {
+      for (int o = CPR; o < 64; o <<= 1) {
 #pragma unroll
-      for (int j = 0; j < EPS; ++j) { s1[j] += __shfl_xor(s1[j], o, 64); s2[j] += __shfl_xor(s2[j], o, 64); }
+        for (int j = 0; j < EPS; ++j) { s1[j] += __shfl_xor(s1[j], o, 64); s2[j] += __shfl_xor(s2[j], o, 64); }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < EPS; ++j) { s1[j] = tf::lane_group_sum<CPR>(s1[j]); s2[j] = tf::lane_group_sum<CPR>(s2[j]); }     // DPP / row swaps, no LDS crossbar
     }
     __syncthreads();                                 // staging tile fully consumed
     float* red = reinterpret_cast<float*>(smem);     // [4 waves][2][BN]
