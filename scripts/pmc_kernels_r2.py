@@ -11,7 +11,7 @@ for name, H, W, Cin, Cout, K in (("l3.c1", 32, 32, 1024, 256, 1), ("l3.c2", 32, 
     wp = ops.pack_weight(w, dt)
     gy = torch.randn(N, H, W, Cout, device="cuda").to(dt)
     out = torch.zeros(Cout, Cin, K, K, device="cuda")
-    for tile in (13, 44, 46):
+    for tile in (13, 44, 46) + ((50,) if K == 3 else ()):       # 50: the halo-resident 3x3 kernel (conv3x3h)
         for _ in range(3):
             ops.conv2d_nhwc(x, wp, Cout, K, K, 1, K // 2, tile=tile)
     if K == 3:
