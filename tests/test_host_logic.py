@@ -217,6 +217,33 @@ def test_wider_evaluator_reads_write_results_tree(tmp_path):
     assert rows[0, :4].tolist() == [5.0, 5.0, 10.0, 10.0]                               # x y w h with the +1 of evaluation.py:108-109
 
 
+def test_bench_cross_checks_launch_durations_with_the_committed_rocprof_summary():
+    """roofline.rocprof_avg_launch_us: the true kernel duration of the dominant kernel in the committed rocprofv3 --stats summary of
+    the bench command, next to the HIP-event average measured live; a summary without that kernel must fail loudly."""
+    import importlib.util
+    import os
+    import tempfile
+    import pytest
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    us = bench.rocprof_avg_us(13)
+    assert us is not None and 5.0 < us < 200.0                   # tens of microseconds per conv launch
+    assert bench.rocprof_avg_us(6) is not None and bench.rocprof_avg_us(14) is not None
+    assert bench.rocprof_avg_us(5) is None
+    old = bench.ROCPROF_STATS_FILE
+    try:
+        with tempfile.NamedTemporaryFile("w", suffix=".csv", delete=False) as f:
+            f.write('"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs","StdDev"\n"some_other_kernel()",3,300,100,100,90,110,1\n')
+        bench.ROCPROF_STATS_FILE = f.name
+        with pytest.raises(RuntimeError, match="regenerate"):
+            bench.rocprof_avg_us(13)
+    finally:
+        bench.ROCPROF_STATS_FILE = old
+        os.unlink(f.name)
+
+
 def test_bench_reads_committed_pmc_traffic():
     """bench.py's roofline.traffic comes from the committed rocprofv3 --pmc passes: the file must parse and give a per-launch byte
     count of the dominant kernel that is of the order of its algorithmic bytes (tens of MB), never silently zero."""
