@@ -462,7 +462,8 @@ int launch_kind(const tf_conv_args* A, hipStream_t stream) {
     if (dbg < 0) {
       const char* e = getenv("TF_CONV_DBG");
       dbg = e ? atoi(e) : 0;
-      if (dbg) fprintf(stderr, "tinyfaces: TF_CONV_DBG=%d -- timing-ablation mode, convolution RESULTS ARE INVALID\n", dbg);
+      if (dbg & 15) fprintf(stderr, "tinyfaces: TF_CONV_DBG=%d -- timing-ablation mode, convolution RESULTS ARE INVALID\n", dbg);
+      else if (dbg) fprintf(stderr, "tinyfaces: TF_CONV_DBG=%d -- A/B form of the statistic epilogue (results unchanged)\n", dbg);
     }
     k.dbg = dbg;
   }
