@@ -2,9 +2,9 @@
 //
 // Why a second conv kernel.  The generic LDS-DMA kernel (conv_dma.hip) treats a 3x3 conv as a GEMM over an im2col view: every
 // K-stage (one tap x 64 channels) DMAs a fresh [pixels][64] slab of the input, so each input byte crosses the L2 -> L1 -> LDS
-// path nine times.  On the layer-3 shape (12 x 32 x 32 pixels, 256 -> 256 channels) that is 442 MB of LDS-DMA per launch at
-// 64 x 64 tiles, moved at ~31 TB/s -- the vector-memory path (64 B/clk/CU) is the bound, not the MFMA pipe, and the DMA time
-// does not hide behind the MFMAs (profiles/r01d_conv_dma_pipeline_ablation.txt: 14 us DMA + 13 us compute + 9 us base ~ 32 us).
+// path nine times: on the layer-3 shape (12 x 32 x 32 pixels, 256 -> 256 channels) 442 MB of LDS-DMA per launch at 64 x 64
+// tiles, and a wave gets 8 MFMAs per barrier behind the address arithmetic of a generic gather (28-30 us per launch whatever
+// the tile: profiles/r01d_conv_dma_pipeline_ablation.txt, profiles/r02a_microbench_mma32_tiles.txt).
 // Here the block's input patch is loaded ONCE per 64-channel chunk, with its one-pixel halo:
 //   * output tile = 4 rows x 32 columns of one image (128 pixels) x 128 output channels;
 //   * input frame = 6 x 34 pixels x 64 channels = 204 rows of 128 bytes in LDS; a tap is a CONSTANT ROW SHIFT of the fragment
@@ -14,9 +14,11 @@
 //   LDS-DMA bytes per block and stage: 16 KiB + 26/9 KiB = 19 KiB instead of 32 KiB (128 x 128 im2col) or 2 x 16 KiB (64 x 64).
 // Eight waves: 2 (pixels) x 2 (channels) x 2 (K halves).  Each wave owns a 64 x 64 accumulator block on 32x32x16 fragments
 // (16 MACs per LDS byte read) and multiplies HALF of every 64-deep stage (32 of the 64 channels); the two K halves are added
-// through the fp32 staging tile of the epilogue.  Two waves per SIMD with the same MFMA work as the four-wave form: one
+// through two fp32 staging tiles in the epilogue.  Two waves per SIMD with the same MFMA work as the four-wave form: one
 // wave's DMA issue / LDS latency / barrier wait is covered by its partner's MFMAs (the four-wave 128 x 128 form had nothing
 // to cover them: profiles/r02a_microbench_mma32_tiles.txt).
+// The K loop is written for instruction count (see below): 23 us per launch = 628 TFLOP/s on the layer-3 shape
+// (profiles/r02_conv3x3h_trace.txt: stage stamps, ablations, the versions that did not work).
 // Epilogue = conv_dma's (fp32 tile in LDS, 16 output bytes per thread, every TF_EPI_* flag), for 512 threads.
 #include <cstdio>
 #include <cstdlib>
