@@ -68,3 +68,46 @@ def test_workspace_and_shape_queries(hip):
     assert 1e9 < evalb < train < 2e10
     assert l.tf_nms_workspace_bytes(4096) > 4096 * 64 * 8
     assert l.tf_criterion_workspace_bytes(12, 25, 63, 63) > 0 and l.tf_targets_workspace_bytes(100) >= 1200
+
+
+def test_kernel_selection_queries_host_side(hip):
+    """The host-side planning functions that decide which MFMA kernel a call gets (no device work): the statistic-row count of a
+    conv launch (tf_conv_mtiles: the row count its BN consumer must read) and the partial-tile workspace of a weight gradient
+    (tf_wgrad_workspace_bytes), for the shapes of the training step at bs = 12."""
+    import ctypes as C
+    l = hip.lib()
+    rows = l.tf_get_stat_rows()
+    assert 1 <= rows <= 16
+
+    def conv(N, H, W, Cin, Cout, K, stride=1, dtype=hip.TF_BF16, tile=0):
+        a = hip.ConvArgs()
+        a.dtype, a.mode, a.N, a.H, a.W, a.Cin, a.Cout, a.KH, a.KW, a.stride, a.pad = dtype, 0, N, H, W, Cin, Cout, K, K, stride, K // 2
+        a.OH, a.OW = (H + 2 * (K // 2) - K) // stride + 1, (W + 2 * (K // 2) - K) // stride + 1
+        a.ldy, a.tile = Cout, tile
+        return l.tf_conv_mtiles(C.byref(a))
+
+    # layer 3 at bs = 12 (12 x 32 x 32 pixels): the 3x3 goes to the halo-resident kernel (96 tiles of 4 x 32 pixels), the 1x1s to the
+    # LDS-DMA kernel (192 / 96 tiles): all fold their partial sums into the same <= TF_STAT_ROWS rows
+    assert conv(12, 32, 32, 256, 256, 3) == rows and conv(12, 32, 32, 1024, 256, 1) == rows and conv(12, 32, 32, 256, 1024, 1) == rows
+    # few tiles: one row per tile.  4 x 32 output tiles of conv3x3h when forced (tile 50): 1 image x 2 x 1 tiles
+    assert conv(1, 8, 32, 256, 256, 3, tile=50) == 2
+    assert conv(1, 8, 8, 64, 64, 1) == 1                         # 64 pixels: one 64 x 64 / 128 x 64 tile
+    # fp32 (the parity path) never takes the 2-byte kernels
+    assert conv(1, 16, 16, 256, 256, 3, dtype=hip.TF_F32) == min(rows, 4)      # 256 pixels / 64
+
+    def wgrad_ws(N, H, W, Cin, Cout, K, stride=1):
+        a = hip.WgradArgs()
+        a.dtype, a.N, a.H, a.W, a.Cin, a.Cout, a.KH, a.KW, a.stride, a.pad = hip.TF_BF16, N, H, W, Cin, Cout, K, K, stride, K // 2
+        a.OH, a.OW = (H + 2 * (K // 2) - K) // stride + 1, (W + 2 * (K // 2) - K) // stride + 1
+        a.ldx, a.lddy, a.dw_ld = Cin, Cout, Cin * K * K
+        return l.tf_wgrad_workspace_bytes(C.byref(a))
+
+    tile_bytes = 9 * 64 * 64 * 4
+    # layer-3 3x3: 16 tiles of 64 x 64 x 9 taps, 16 pixel slices (256 blocks): 16 x 16 partial tiles
+    assert wgrad_ws(12, 32, 32, 256, 256, 3) == 16 * 16 * tile_bytes
+    # layer-1 3x3 (one tile): at most 256 slices, every slice >= 6 stages of 64 padded pixels
+    w1 = wgrad_ws(12, 125, 125, 64, 64, 3)
+    assert w1 % tile_bytes == 0 and 128 <= w1 // tile_bytes <= 256
+    assert w1 <= (256 + 16) * tile_bytes                          # fits the executor's scratch (csrc/detnet.hip: P.dwp_floats)
+    assert wgrad_ws(12, 32, 32, 256, 1024, 1) == 0                # pointwise: atomics, no workspace
+    assert wgrad_ws(12, 63, 63, 128, 128, 3, stride=2) == 0       # strided 3x3: the per-tap kernel
