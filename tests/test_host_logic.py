@@ -376,3 +376,48 @@ def test_wider_evaluator_reads_official_mat_layout_and_filters_by_setting(tmp_pa
     assert abs(ap["medium"] - (1 / 3 + (1 / 3) * (2 / 3))) < 1e-9
     # easy: faces a1, c2 (2).  a2 is now IGNORED too: its detection no longer counts.  R = 1/2 at P=1, then only false positives.
     assert abs(ap["easy"] - 0.5) < 1e-9
+
+
+def test_lds_swizzle_of_the_mfma_fragment_reads_is_bank_conflict_free():
+    """The XOR swizzle of the conv kernels' LDS image (csrc/conv_dma.hip, csrc/conv3x3h.hip: 128-byte rows, 16-byte slots, slot ^ h(row))
+    restated on the host and checked against the ds_read_b128 service model of gfx950 (/opt/skills/guides/MI355X_MICROARCH.md, section
+    LDS: four groups of 16 lanes per instruction, bank = (byte address / 4) mod 64; a group is conflict-free when its 16 lanes x 4
+    dwords touch 64 distinct banks): the 16x16x32 and 32x32x16 fragment reads at every fragment base, and the tap-shifted reads of the
+    halo-resident 3x3 kernel, which start at ARBITRARY rows of the 6 x 34-pixel frame."""
+    def swz(row):
+        return ((row >> 1) & 1) ^ (((row >> 2) & 1) << 2) ^ (((row >> 3) & 1) * 6)
+
+    def off(row, slot):
+        return row * 128 + ((slot ^ swz(row)) << 4)
+
+    groups = [list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)), list(range(4, 12)) + list(range(16, 20)) + list(range(28, 32))]
+    groups += [[l + 32 for l in g] for g in groups]
+    assert sorted(sum(groups, [])) == list(range(64))
+
+    def conflict_free(addr_of_lane):
+        for g in groups:
+            banks = [((addr_of_lane(l) >> 2) + j) % 64 for l in g for j in range(4)]
+            if len(set(banks)) != 64:
+                return False
+        return True
+
+    # 16x16x32 fragments (MmaD<bf16>::stage): lane l -> row base + (l & 15), slot ks*4 + (l >> 4)
+    for base in range(0, 128, 16):
+        for ks in range(2):
+            assert conflict_free(lambda l: off(base + (l & 15), ks * 4 + (l >> 4))), (16, base, ks)
+    # 32x32x16 fragments (stage32 / conv3x3h weights): lane l -> row base + (l & 31), slot ks*2 + (l >> 5)
+    for base in range(0, 128, 32):
+        for ks in range(4):
+            assert conflict_free(lambda l: off(base + (l & 31), ks * 2 + (l >> 5))), (32, base, ks)
+    # conv3x3h input fragments: 32 consecutive frame rows starting anywhere (output row + tap shift), both K halves
+    FW, FR = 34, 6 * 34
+    for tr in range(4):
+        for tap in range(9):
+            for sign in (1, -1):
+                base = (tr + 1) * FW + 1 + sign * ((tap // 3 - 1) * FW + (tap % 3 - 1))
+                assert 0 <= base and base + 31 < FR
+                for slot0 in range(0, 8, 2):
+                    assert conflict_free(lambda l: off(base + (l & 31), slot0 + (l >> 5))), (tr, tap, sign, slot0)
+    # the swizzle is applied on the SOURCE side of the LDS-DMA: lane (row r, physical slot p) fetches logical slot p ^ h(r) -- a bijection per row
+    for r in range(256):
+        assert sorted(p ^ swz(r) for p in range(8)) == list(range(8))
