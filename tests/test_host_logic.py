@@ -421,3 +421,40 @@ def test_lds_swizzle_of_the_mfma_fragment_reads_is_bank_conflict_free():
     # the swizzle is applied on the SOURCE side of the LDS-DMA: lane (row r, physical slot p) fetches logical slot p ^ h(r) -- a bijection per row
     for r in range(256):
         assert sorted(p ^ swz(r) for p in range(8)) == list(range(8))
+
+
+def test_conv3x3h_operand_pipeline_protocol():
+    """The counted-vmcnt protocol of csrc/conv3x3h.hip restated as a queue model: a wave's LDS-DMA instructions retire in issue order,
+    `s_waitcnt vmcnt(N)` returns when at most N are outstanding.  For every chunk count: at stage st (= chunk * 9 + tap) the wait of
+    the kernel guarantees that weight stage st and the input frame of its chunk have landed, and no DMA is issued into a ring slot /
+    frame buffer whose previous content is still to be read."""
+    WPASS, XPASS = 2, 4
+    for cpt in range(1, 7):
+        nst = 9 * cpt
+        q = []                                                    # issue order: (kind, index) per DMA instruction
+        issue = lambda kind, idx, n: q.extend([(kind, idx)] * n)
+        issue("X", 0, XPASS); issue("W", 0, WPASS); issue("W", 1, WPASS)
+        w_slot = {0: 0, 1: 1}                                     # ring slot -> weight stage it holds (or will hold)
+        x_buf = {0: 0}                                            # frame buffer -> chunk
+        for st in range(nst):
+            chunk, tap = divmod(st, 9)
+            more = chunk + 1 < cpt
+            if tap == 8:
+                n = WPASS if more else 0
+            elif tap == 1:
+                n = WPASS + XPASS if more else WPASS
+            else:
+                n = WPASS
+            landed = set(q[:len(q) - n]) if n else set(q)
+            assert ("W", st) in landed and ("X", chunk) in landed, (cpt, st)
+            assert w_slot[st % 3] == st and x_buf[chunk & 1] == chunk     # what the stage reads is what its buffers hold
+            # after the barrier of stage st every wave has finished reading stage st-1: the slots of stages <= st-1 are free
+            if tap == 0 and more:
+                assert x_buf.get((chunk + 1) & 1, -1) < chunk             # the other frame buffer held chunk-1 (or nothing)
+                x_buf[(chunk + 1) & 1] = chunk + 1
+                issue("X", chunk + 1, XPASS)
+            if tap < 7 or more:
+                assert w_slot.get((st + 2) % 3, -1) <= st - 1             # slot of stage st+2 == slot of stage st-1
+                w_slot[(st + 2) % 3] = st + 2
+                issue("W", st + 2, WPASS)
+        assert {i for k, i in q if k == "W"} == set(range(nst)) and {i for k, i in q if k == "X"} == set(range(cpt))
