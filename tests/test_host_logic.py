@@ -458,3 +458,47 @@ def test_conv3x3h_operand_pipeline_protocol():
                 w_slot[(st + 2) % 3] = st + 2
                 issue("W", st + 2, WPASS)
         assert {i for k, i in q if k == "W"} == set(range(nst)) and {i for k, i in q if k == "X"} == set(range(cpt))
+
+
+def test_wgrad3x3_running_offsets_and_raster_walk():
+    """Two pieces of host-checkable arithmetic of csrc/wgrad3x3.hip (v3): (1) the 18 fragment offsets of a lane into the 512-row circular
+    X image advance by (o + 8192) & 0xFFFF per 64-pixel stage and must equal the offset re-derived from scratch (row * 128 + swizzled
+    slot), because the swizzle term only depends on row bits 1-2; (2) the branch-free +64 step of the padded-raster walk
+    (PadPos::advance: q64 rows + r64 columns with carries by select) equals stepping one padded pixel 64 times."""
+    import numpy as np
+    fsw = lambda row: ((row >> 1) & 3) << 1
+    rng = np.random.RandomState(3)
+    for _ in range(200):
+        Wp, hb = int(rng.randint(3, 128)), int(rng.randint(1, 3))
+        lane = int(rng.randint(64)); li, lg = lane & 15, lane >> 4
+        frow, fhalf, fs = lg * 4 + (li >> 2), (li & 1) << 3, (li & 3) >> 1
+        slot0 = int(rng.randint(4)) * 2
+        for t in range(9):
+            for k in range(2):
+                shift = (t // 3 - 1) * Wp + (t % 3 - 1)
+                derive = lambda st: (lambda row: row * 128 + (((slot0 + fs) ^ fsw(row)) << 4) + fhalf)((64 * (st + hb) + k * 32 + shift + frow) & 511)
+                o = derive(0)
+                for st in range(1, 20):
+                    o = (o + 8192) & 0xFFFF
+                    assert o == derive(st), (Wp, hb, lane, t, k, st)
+                    assert ((o + 2048) & 0xFFFF) == (lambda row: row * 128 + (((slot0 + fs) ^ fsw(row)) << 4) + fhalf)(
+                        ((64 * (st + hb) + k * 32 + shift + frow) + 16) & 511)
+    for _ in range(300):
+        H, W, N = int(rng.randint(1, 130)), int(rng.randint(1, 130)), int(rng.randint(1, 4))
+        Hp, Wp = H + 2, W + 2
+        q64, r64, small = 64 // Wp, 64 % Wp, Hp <= 64 // Wp + 1
+        p = int(rng.randint(0, N * Hp * Wp))
+        n, rem = divmod(p, Hp * Wp); hp, wp = divmod(rem, Wp)
+        for _ in range(5):
+            wp += r64
+            c = 1 if wp >= Wp else 0
+            wp -= c * Wp; hp += q64 + c
+            if small:
+                while hp >= Hp:
+                    hp -= Hp; n += 1
+            else:
+                c2 = 1 if hp >= Hp else 0
+                hp -= c2 * Hp; n += c2
+            p += 64
+            n_ref, rem = divmod(p, Hp * Wp); hp_ref, wp_ref = divmod(rem, Wp)
+            assert (n, hp, wp) == (n_ref, hp_ref, wp_ref), (H, W, p)
