@@ -181,6 +181,8 @@ typedef struct tf_conv_args {
   const float* mask_scale; const float* mask_shift;
   float* stat_out;    /* [mtiles][2][ldy] fp32 partial sums, mtiles = tf_conv_mtiles() */
   int tile;           /* 0 = auto; else 1:(128x128) 2:(128x64) 3:(64x64) pixels x channels */
+  int alg_k, alg_n;   /* measurement hooks only: the UNPADDED reduction length (taps * channels) and output-channel count when the
+                         operands are zero-padded (stem: 147 of 192, heads: 125 of 128); 0 = Cin*KH*KW / Cout */
 } tf_conv_args;
 
 int tf_conv_mtiles(const tf_conv_args* a);   /* rows of stat_out this launch writes (<= TF_STAT_ROWS for the DMA kernel) */
@@ -351,18 +353,26 @@ int tf_image_prepare(const tf_image_prepare_args* a, void* stream);
 /* ---- measurement hooks (bench.py `roofline`) ------------------------------------------
  * While enabled, every MFMA kernel launch (conv_igemm / wgrad) is bracketed by HIP events on
  * the stream it is launched on.  tf_profile_collect blocks until they completed and writes
- * rows of 5 doubles to HOST memory: kind, launches, total_ms, algorithmic flops, algorithmic
- * bytes.  kind 0..5 = conv_igemm (dtype*3 + tile-1), 8..11 = wgrad (8 + dtype*2 + (tile==128)),
- * 12/13/15 = conv_dma f32/bf16/f16, 14 = wgrad_dma bf16, 6/7 = conv3x3h bf16/f16. */
+ * rows of 6 doubles to HOST memory: kind, launches, total_ms, ALGORITHMIC flops (2 x the MACs of the
+ * forward convolution the launch belongs to, unpadded channels: a stride-2 data gradient counts the
+ * forward conv's MACs, not the zero-inserted gather it executes), algorithmic bytes, EXECUTED flops
+ * (2*M*N*K of the GEMM the kernel ran, padding and zero taps included).  kind 0..5 = conv_igemm (dtype*3 + tile-1), 8..11 = wgrad (8 + dtype*2 + (tile==128)),
+ * 12/13/15 = conv_dma f32/bf16/f16, 14 = wgrad_dma bf16, 6/7 = conv3x3h bf16/f16, 16 = wgrad3x3 bf16 (both launches of its two-phase form). */
 int tf_profile_enable(int every);   /* 0 = off, 1 = bracket every launch, n = every n-th launch (sampling keeps the timed region undisturbed) */
 int tf_profile_collect(double* host_out, int max_rows);
-/* per layer shape, for the records consumed by the LAST tf_profile_collect: rows of 11 doubles
- * (kind, M pixels, N output channels, K reduction length, taps, mode (0 fwd, 1 dgrad, 2 wgrad), epilogue flags, launches, total_ms, flops, bytes) */
+/* per layer shape, for the records consumed by the LAST tf_profile_collect: rows of 12 doubles
+ * (kind, M pixels, N output channels, K reduction length, taps, mode (0 fwd, 1 dgrad, 2 wgrad), epilogue flags, launches, total_ms,
+ *  algorithmic flops, algorithmic bytes, executed flops) */
 int tf_profile_shapes(double* host_out, int max_rows);
 /* debugging hook of the halo-resident 3x3 kernel (csrc/conv3x3h.hip): register (NULL: clear) a DEVICE buffer of
  * 8 blocks x 8 waves x 64 stages x 8 uint64; the next launches run an instrumented instantiation that stamps s_memtime at the
  * five points of every K stage (scripts/trace_conv3x3h.py).  Not part of the product path. */
 int tf_debug_conv3x3h_trace(void* device_buf);
+/* interference probe of the two-stream contention measurement (csrc/probe.hip, scripts/contention.py): `blocks` workgroups of 256
+ * threads that hog ONE CU resource for `iters` rounds -- kind 0 park (LDS capacity + wave slots only), 1 L2 loads, 2 HBM loads,
+ * 3 MFMA, 4 LDS-DMA, 5 fp32 atomics, 6 LDS reads; `buf` / `window_bytes`: device window of the memory kinds.  Not part of the
+ * product path. */
+int tf_debug_probe(int kind, int blocks, int lds_bytes, void* buf, size_t window_bytes, int iters, void* stream);
 /* test hook: raw lane mapping of ds_read_b64_tr_b16 (see tests/test_gpu_small_ops.py) */
 int tf_probe_tr16(unsigned short* out256, void* stream);
 

@@ -121,10 +121,15 @@ def test_train_step_bs12_500x500_vs_oracle(train_case, dtype):
         assert cosv.min() > 0.9999 and np.median(relv) < 5e-3, (worst, cos[worst])    # measured 0.99998 / 2.6e-3
         assert drm < 1e-5 and drv < 1e-5
     else:
-        assert dy[0] < 2e-2                                       # bf16 operands, fp32 accumulation (tightened from the measured value)
-        # measured 0.888-0.923 / 0.967 depending on the summation order of the conv kernels (the worst tensor is a layer-1 BN bias: a sum
-        # of 187 500 bf16-noisy terms that cancel); torch bf16 autocast on the small fixture: 0.933 / 0.968
-        assert cosv.min() > 0.85 and np.median(cosv) > 0.95, (worst, cos[worst])
+        # bf16 operands, fp32 accumulation: what the 1150+ img/s of bench.py are quoted on.  Asserted = measured with a margin:
+        # maps 1.5e-2 of a 1.19 range; gradient cosine 0.967 median, 0.888-0.923 minimum depending on the summation order of the fp32
+        # atomics (the worst tensor is ALWAYS a layer-1 BN bias: a sum of 187 500 bf16-noisy terms that cancel); every other tensor
+        # >= 0.90.  torch's own bf16 autocast on the small fixture: 0.933 / 0.968 (scripts/debug_gpu.py amp).
+        low = sorted((v, k) for k, v in cos.items() if v < 0.90)
+        report(f"fullsize_train_bf16_margin", below_090=len(low), lowest=str(low[:3]), cos_p05=float(np.quantile(cosv, .05)))
+        assert dy[0] < 1.8e-2
+        assert cosv.min() > 0.85 and len(low) <= 2 and np.median(cosv) > 0.96, (worst, cos[worst], low)
+        assert all(".bn" in k and "layer1" in k for _, k in low), low      # only cancelling layer-1 BN sums may dip below 0.90
         assert drm < 2e-2 and drv < 2e-2
 
 
@@ -213,6 +218,14 @@ def test_get_detections_960x1280_bf16_overlap(pyramid_case):
         inter = np.clip(x2 - x1, 0, None) * np.clip(y2 - y1, 0, None)
         a = (dets[:, 2] - dets[:, 0]) * (dets[:, 3] - dets[:, 1]) + (b[2] - b[0]) * (b[3] - b[1]) - inter
         return bool((inter / a).max() > 0.9) if dets.shape[0] else False
-    found = sum(iou_hit(b) for b in ref)
-    report("fullsize_detections[bf16]", kept=dets.shape[0], ref_kept=ref.shape[0], found=found)
-    assert found >= 0.85 * ref.shape[0] and abs(dets.shape[0] - ref.shape[0]) <= 0.1 * ref.shape[0]     # measured 604 of 668: the random-weight probabilities pile up at the threshold
+    hits = np.array([iou_hit(b) for b in ref])
+    found = int(hits.sum())
+    # margin analysis (as the fp32 fixture does for its threshold): the random-weight probabilities pile up AT the threshold, and a bf16
+    # logit is off by up to ~1.5e-2 (test_train_step above), so a reference survivor whose logit clears the threshold by less than twice
+    # that may legitimately drop out.  The survivors that clear it by more must (nearly) all be found.
+    logit_thr = float(np.log(c["thr"] / (1.0 - c["thr"])))
+    safe = ref[:, 4] - logit_thr > 3e-2
+    found_safe = int(hits[safe].sum())
+    report("fullsize_detections[bf16]", kept=dets.shape[0], ref_kept=ref.shape[0], found=found, safe=int(safe.sum()), found_safe=found_safe)
+    assert found >= 0.88 * ref.shape[0] and abs(dets.shape[0] - ref.shape[0]) <= 0.1 * ref.shape[0]     # measured 604 of 668 (0.904)
+    assert safe.sum() > 100 and found_safe >= 0.95 * safe.sum()

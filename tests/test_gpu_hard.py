@@ -127,6 +127,35 @@ def test_nms_65536_boxes_vs_oracle(templates):
     assert np.array_equal(keeps[0].cpu().numpy(), want) and np.array_equal(keeps[1].cpu().numpy() - 65536, onms(b2, s2, 0.3))
 
 
+def test_top_level_3750x5000_fp32_vs_cpu_oracle():
+    """The shapes that exist ONLY at the 5000-px level of configs[4] -- M = 293 125 pixels at /16, 1.17 M at /8, 4.7 M stem pixels,
+    grids beyond 65 535 blocks, byte offsets beyond 2^32 inside the 25.7 GB fp32 arena -- against an INDEPENDENT implementation:
+    ONE eval-mode forward of a 1 x 3 x 3750 x 5000 image through the CPU oracle (torch-CPU fp32 restatement of
+    tinyfaces/models/model.py:89-128, ~5.3 TFLOP: about a minute on the box's host cores) and through the HIP fp32 path.
+    north_star's bar: per-anchor cls / reg maps within 1e-3.  The fp16-vs-fp32 check of the next test is anchored by this one."""
+    import os
+    import time
+    from tinyfaces.models.model import DetectionModel
+    from oracle.model import OracleDetectionModel, tame_init_
+    torch.set_num_threads(min(64, os.cpu_count() or 8))
+    om = tame_init_(OracleDetectionModel(num_templates=25), 0).eval()
+    m = DetectionModel(num_templates=25)
+    m.load_state_dict(om.state_dict(), strict=True)
+    m = m.cuda().eval().set_compute_dtype(torch.float32)
+    x = torch.randn(1, 3, 3750, 5000, generator=_g(5))
+    with torch.no_grad():
+        y = m(x.cuda()).cpu()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ref = om(x)
+        t_cpu = time.perf_counter() - t0
+    assert y.shape == ref.shape == (1, 125, 469, 625)
+    d_cls, d_reg = err(y[:, :25].numpy(), ref[:, :25].numpy()), err(y[:, 25:].numpy(), ref[:, 25:].numpy())
+    report("hard_top_level_fp32_vs_oracle", cls_maxabs=d_cls[0], cls_maxref=d_cls[1], reg_maxabs=d_reg[0], reg_maxref=d_reg[1], oracle_cpu_s=t_cpu)
+    assert torch.isfinite(y).all()
+    assert d_cls[0] < 1e-3 and d_reg[0] < 1e-3
+
+
 def test_pyramid_5000px_fp16_and_batched_detections(templates):
     """The hard setting end to end: a 1875 x 2500 image with scales (-1, 0, 1) -> levels 937x1250, 1875x2500, 3750x5000 (long side
     5000 px, one un-tiled forward: the activation arena of that level is asked from the executor and reported), fp16 operands.

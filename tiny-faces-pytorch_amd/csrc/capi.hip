@@ -15,7 +15,7 @@ static const char* const kSymbols[] = {
     "tf_upsample_add_crop", "tf_upsample_add_crop_bwd", "tf_reduce_partials",
     "tf_detnet_num_params", "tf_detnet_param_name", "tf_detnet_param_numel", "tf_detnet_workspace_bytes",
     "tf_detnet_out_shape", "tf_detnet_param_region_bytes", "tf_detnet_forward", "tf_detnet_backward", "tf_detnet_set_dual_stream", "tf_detnet_set_grad_events",
-    "tf_probe_tr16", "tf_set_stat_rows", "tf_get_stat_rows", "tf_profile_enable", "tf_profile_collect", "tf_profile_shapes", "tf_debug_conv3x3h_trace",
+    "tf_probe_tr16", "tf_set_stat_rows", "tf_get_stat_rows", "tf_profile_enable", "tf_profile_collect", "tf_profile_shapes", "tf_debug_conv3x3h_trace", "tf_debug_probe",
 };
 
 namespace tf {
@@ -24,7 +24,7 @@ void set_next_stop_event(hipEvent_t e) { g_next_stop_event = e; }
 hipEvent_t take_next_stop_event() { hipEvent_t e = g_next_stop_event; g_next_stop_event = nullptr; return e; }
 }  // namespace tf
 
-extern "C" int tf_version(void) { return 200; }
+extern "C" int tf_version(void) { return 300; }
 static int g_stat_rows = 8;
 extern "C" int tf_set_stat_rows(int rows) { g_stat_rows = rows <= 0 ? (1 << 30) : (rows > TF_STAT_ROWS ? TF_STAT_ROWS : rows); return TF_OK; }
 extern "C" int tf_get_stat_rows(void) { return g_stat_rows; }

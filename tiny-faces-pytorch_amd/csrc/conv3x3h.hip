@@ -41,9 +41,13 @@ constexpr int XPASS = 4, XBUF = XPASS * 64 * 128;                     // frame b
 constexpr int WPASS = 2, WBUF = BN * 128;                             // weight stage: 128 channels x 64 k
 constexpr int W_AT = 2 * XBUF;
 constexpr int NSW = 3;                                               // 3-deep weight ring (9 taps = 3 turns)
-constexpr int PITCH = BN + 4, STG_FLOATS = BM * PITCH;
+constexpr int PITCH = BN + 4, STG_FLOATS = (BM / 2) * PITCH;          // r3: the epilogue stages HALF the tile (64 pixels) at a time
 constexpr int RING_BYTES = W_AT + NSW * WBUF;                          // 112 KiB
-constexpr int LDS_BYTES = 2 * STG_FLOATS * 4 > RING_BYTES ? 2 * STG_FLOATS * 4 : RING_BYTES;      // the two epilogue staging tiles (132 KiB) overlay the rings
+// r3: 112 KiB instead of 132.  LDS capacity is what the two streams of the backward pass fight over (profiles/r03_contention.txt):
+// with the two K-half staging tiles of the WHOLE 128-pixel tile (2 x 66 KiB) a block left 28 KiB of its CU, so not even one 48 KiB
+// weight-gradient block could sit beside it and the two kernels time-sliced the CU; two passes of 64 pixels (2 x 33 KiB, overlaying
+// the rings) cost two more barriers per block.
+constexpr int LDS_BYTES = 2 * STG_FLOATS * 4 > RING_BYTES ? 2 * STG_FLOATS * 4 : RING_BYTES;
 
 struct HK {
   const char* x; const char* w; char* y;
@@ -248,7 +252,8 @@ __global__ void __launch_bounds__(NT, 2) conv3x3h_kernel(const HK a) {
   // ---------------- epilogue, phase 1: one fp32 [BM][BN+4] tile in LDS per K half (both halves write at once; phase 2 adds them)
   // 32x32 accumulator: lane l holds pixel l & 31, channels 8*g + 4*(l >> 5) + {0..3} for g = 0..3 (registers 4g .. 4g+3)
   float* stg = reinterpret_cast<float*>(smem);
-  {
+  auto park = [&](int half) {                        // the waves that own pixel half `half` (wm) write their accumulators
+    if (wm != half) return;
     float* mine = stg + kg * STG_FLOATS;
 #pragma unroll
     for (int n = 0; n < 2; ++n)
@@ -256,9 +261,10 @@ __global__ void __launch_bounds__(NT, 2) conv3x3h_kernel(const HK a) {
       for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-          *reinterpret_cast<f32x4*>(mine + (wm * 64 + m * 32 + r32) * PITCH + wn * 64 + n * 32 + g * 8 + h * 4) =
+          *reinterpret_cast<f32x4*>(mine + (m * 32 + r32) * PITCH + wn * 64 + n * 32 + g * 8 + h * 4) =
               f32x4{acc[n][m][4 * g], acc[n][m][4 * g + 1], acc[n][m][4 * g + 2], acc[n][m][4 * g + 3]};
-  }
+  };
+  park(0);
   __syncthreads();
   if constexpr (TRACE) e_t[1] = __builtin_amdgcn_s_memtime();
 
@@ -283,9 +289,14 @@ __global__ void __launch_bounds__(NT, 2) conv3x3h_kernel(const HK a) {
   }
 #pragma unroll
   for (int ps = 0; ps < TR; ++ps) {
+    if (ps == TR / 2) {                              // second pixel half: rows 2, 3 of the tile replace rows 0, 1 in the staging tiles
+      __syncthreads();
+      park(1);
+      __syncthreads();
+    }
     const int oh = r0 + ps, ow = c0 + tc;
     if (!(oh < a.H && ow < a.W && cok)) continue;   // tile pixels outside the image hold meaningless sums: no store, no statistics
-    const int row = ps * TC + tc;
+    const int row = (ps % (TR / 2)) * TC + tc;
     float v[EPS];
 #pragma unroll
     for (int j = 0; j < EPS; j += 4) {

@@ -482,8 +482,13 @@ int launch_kind(const tf_conv_args* A, hipStream_t stream) {
     if (A->epi & TF_EPI_JOIN) bytes += 2 * M * A->Cout * es;
     if (A->epi & TF_EPI_MASK2) bytes += M * A->Cout * es;
     if (A->epi & TF_EPI_STATS3) bytes += M * A->Cout * es;
-    tf::ProfScope prof(A->dtype == TF_F32 ? 12 : (A->dtype == TF_BF16 ? 13 : 15), 2.0 * M * A->Cout * Kt, bytes, stream, k.M, A->Cout, k.Ktot,
-                       A->KH * A->KW, A->mode, A->epi);   // 12 = conv_dma f32, 13 = conv_dma bf16, 15 = conv_dma f16
+    // algorithmic work = 2 x the MACs of the FORWARD convolution this launch belongs to, on unpadded channels:
+    // a data gradient (mode 1) has as many MACs as its forward conv -- one per (forward output pixel, tap, cin, cout) -- although a
+    // stride-2 one executes the zero-inserted gather over its 4x larger output raster; padded K / N (stem, heads) count as what they hold
+    const double alg_k = A->alg_k > 0 ? A->alg_k : Kt, alg_n = A->alg_n > 0 ? A->alg_n : A->Cout;
+    const double alg_m = A->mode == 1 ? (double)A->N * A->H * A->W : M;
+    tf::ProfScope prof(A->dtype == TF_F32 ? 12 : (A->dtype == TF_BF16 ? 13 : 15), 2.0 * alg_m * alg_n * alg_k, bytes, stream, k.M, A->Cout, k.Ktot,
+                       A->KH * A->KW, A->mode, A->epi, 2.0 * M * A->Cout * Kt);   // 12 = conv_dma f32, 13 = conv_dma bf16, 15 = conv_dma f16
     hipLaunchKernelGGL((conv_dma_kernel<T, BM, BN, NS, KIND, MMA>), dim3(mtiles * k.ntiles), dim3(256), lds, stream, k);
   }
   return hipGetLastError() == hipSuccess ? TF_OK : TF_ERR_LAUNCH;

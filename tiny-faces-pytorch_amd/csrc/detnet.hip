@@ -23,6 +23,7 @@
 //          a second stream against parity buffers.
 //   tf_set_stat_rows(0) (unfolded, bit-reproducible statistics) falls back to the separate
 //   finalize kernels and the unmasked gradient flow: the A/B and race-screen path.
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -468,6 +469,7 @@ extern "C" int tf_detnet_forward(int dtype, int training, const float* x, int N,
   c.flush_packs();
   }
   conv_fill(a, dtype, 0, 1, 1, M1, kStemK, 1, M1, 64, 1, 1, 0, 64, P.col, P.wstem, P.cstem);
+  a.alg_k = 147;                                  // 7 x 7 x 3 taps*channels, zero-padded to kStemK for the 64-deep K stages
   if (tr) { a.epi = TF_EPI_STATS; a.stat_out = P.partial; }
   else {
     bn_forward(c, A.stem, 64, P.bn_stem, false, nullptr, nullptr, 0, eps, mom);
@@ -547,10 +549,10 @@ extern "C" int tf_detnet_forward(int dtype, int training, const float* x, int N,
     hipLaunchKernelGGL(head_vectors_kernel, dim3((nout * 16 + 255) / 256), dim3(256), 0, c.stream, c.P(A.head3.bias), c.P(A.head4.bias),
                        c.P(A.upsample_w), nout, P.hbias3, P.hbias4, P.ones, P.wup_diag);
   conv_fill(a, dtype, 0, N, P.H3, P.W3, 512, P.H3, P.W3, kHeadLd, 1, 1, 0, kHeadLd, res3, P.w_h3, P.s3);
-  a.epi = TF_EPI_AFFINE; a.epi_scale = P.ones; a.epi_shift = P.hbias3;
+  a.epi = TF_EPI_AFFINE; a.epi_scale = P.ones; a.epi_shift = P.hbias3; a.alg_n = nout;
   c.chk(tf_conv2d(&a, c.stream));
   conv_fill(a, dtype, 0, N, P.H4, P.W4, 1024, P.H4, P.W4, kHeadLd, 1, 1, 0, kHeadLd, res4, P.w_h4, P.s4);
-  a.epi = TF_EPI_AFFINE; a.epi_scale = P.ones; a.epi_shift = P.hbias4;
+  a.epi = TF_EPI_AFFINE; a.epi_scale = P.ones; a.epi_shift = P.hbias4; a.alg_n = nout;
   c.chk(tf_conv2d(&a, c.stream));
   c.chk(tf_upsample_add_crop(dtype, P.s3, P.s4, P.wup_diag, N, nout, kHeadLd, P.H3, P.W3, P.H4, P.W4, out, c.stream));
   if (hipGetLastError() != hipSuccess && c.rc == TF_OK) c.rc = TF_ERR_LAUNCH;
@@ -570,6 +572,9 @@ void bn_backward_coefs(Ctx& c, const ConvUnit& u, int C, BnBuf& b, const float* 
 
 void wgrad(Ctx& c, const ConvUnit& u, int cout, int N, int H, int W, int OH, int OW, const void* x, int ldx, const void* dy, int lddy,
            const BnBuf* pro, int cin_override = 0, int k_override = 0, int dw_ld = 0, float* packed_scratch = nullptr, size_t scratch_floats = 0) {
+  // timing-ablation knob (RESULTS INVALID): the step without any weight gradient = what the data-gradient chain costs when it owns the GPU
+  static const bool skip = [] { const bool s = getenv("TINYFACES_DBG_SKIP_WGRAD") != nullptr; if (s) fprintf(stderr, "tinyfaces: TINYFACES_DBG_SKIP_WGRAD -- weight gradients NOT computed, timing only\n"); return s; }();
+  if (skip) return;
   tf_wgrad_args w;
   memset(&w, 0, sizeof(w));
   const int cin = cin_override ? cin_override : u.cin, k = k_override ? k_override : u.k;
@@ -686,6 +691,7 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
   // T2 = gz2 -> g_c2; T3 = g_d; T4 = downsample-branch input gradient; R3 = gradient w.r.t. res3 from the head.
   void *Gcur = P.G0, *Gnext = P.G1;
   conv_fill(a, dtype, 1, N, P.H4, P.W4, kHeadLd, P.H4, P.W4, 1024, 1, 1, 0, 1024, P.g4, P.w_h4t, Gcur);
+  a.alg_k = nout;
   if (fused) {
     // fused flow: Gcur always carries gz = g_y * (y > 0) of the block about to be processed, and (unless that block has a
     // downsample branch) its BN3-backward sums are accumulated by the conv that produces it (MASK2 | STATS3)
@@ -695,6 +701,7 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
   }
   c.chk(tf_conv2d(&a, c.stream));
   conv_fill(a, dtype, 1, N, P.H3, P.W3, kHeadLd, P.H3, P.W3, 512, 1, 1, 0, 512, P.g3, P.w_h3t, P.R3);
+  a.alg_k = nout;
   c.chk(tf_conv2d(&a, c.stream));
 
   // one fork per weight gradient (default) or, TINYFACES_FORK_PER_BLOCK=1, one per block: measured 948 vs 943 img/s

@@ -1,0 +1,120 @@
+// probe: interference kernels for the two-stream contention measurement (scripts/contention.py; profiles/r03_contention.txt).
+//
+// The backward pass runs the data-gradient chain and the weight gradients on two HIP streams; inside the step both run ~2x slower
+// than alone (profiles/r02_layer_table.md).  rocprofv3 --pmc serialises dispatches, so counters cannot see which resource the two
+// queues fight over.  These kernels each hog ONE resource of a CU for a chosen time; the victim (a real conv / weight-gradient
+// launch on another stream) is timed beside each of them:
+//   0 park    : waves that only s_sleep; with `lds_bytes` of dynamic LDS they take LDS capacity + wave slots and nothing else
+//   1 l2      : 16-byte global loads over a small (L2-resident) window      -> vector-memory path / L2 bandwidth
+//   2 hbm     : 16-byte global loads over a large window                     -> HBM bandwidth
+//   3 mfma    : dependent-free v_mfma_f32_32x32x16_bf16 chains               -> the matrix pipes
+//   4 ldsdma  : global_load_lds_dwordx4 from an L2-resident window           -> the LDS-DMA path (TA -> LDS write port)
+//   5 atomic  : fp32 atomicAdd to an L2-resident window                      -> the L2 atomic units
+//   6 ldsread : ds_read_b128 loops                                           -> the LDS read port
+// Not part of the product path (debug symbol of the C ABI, like tf_debug_conv3x3h_trace).
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ void dma16(const void* gsrc, void* lds_wave_base) {
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef __attribute__((address_space(1))) const void glb_void;
+  __builtin_amdgcn_global_load_lds((glb_void*)gsrc, (lds_void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(256) probe_kernel(char* buf, size_t window, int iters, float* sink) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const size_t nchunk = window / 16;
+  size_t idx = ((size_t)blockIdx.x * blockDim.x + tid) % nchunk;
+  const size_t step = (size_t)gridDim.x * blockDim.x;
+  if constexpr (KIND == 0) {
+    for (int i = 0; i < iters; ++i) __builtin_amdgcn_s_sleep(32);
+    if (iters < 0) smem[tid] = 1;
+  } else if constexpr (KIND == 1 || KIND == 2) {
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const uint4 v = *reinterpret_cast<const uint4*>(buf + idx * 16);
+        acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w;
+        idx += step; if (idx >= nchunk) idx -= nchunk;
+      }
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[0] = 1.f;
+  } else if constexpr (KIND == 3) {
+    f32x16 a0 = f32x16(0.f), a1 = f32x16(0.f), a2 = f32x16(0.f), a3 = f32x16(0.f);
+    bf16x8 x, w;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { x[j] = (__bf16)(float)(tid & 3); w[j] = (__bf16)0.5f; }
+    for (int i = 0; i < iters; ++i) {
+      a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, x, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, x, a1, 0, 0, 0);
+      a2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, x, a2, 0, 0, 0);
+      a3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, x, a3, 0, 0, 0);
+    }
+    if (a0[0] + a1[1] + a2[2] + a3[3] == 123.456f) sink[0] = 1.f;
+  } else if constexpr (KIND == 4) {
+    char* dst = smem + (tid & ~63) * 16;             // wave-uniform base; 4 KiB per block and pass
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        dma16(buf + idx * 16, dst + (u & 3) * 4096);
+        idx += step; if (idx >= nchunk) idx -= nchunk;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (iters < 0) sink[0] = smem[tid];
+  } else if constexpr (KIND == 5) {
+    float* f = reinterpret_cast<float*>(buf);
+    const size_t nf = window / 4;
+    size_t j = ((size_t)blockIdx.x * blockDim.x + tid) % nf;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { atomicAdd(f + j, 1.0f); j += step; if (j >= nf) j -= nf; }
+    }
+  } else if constexpr (KIND == 6) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4* p = reinterpret_cast<const float4*>(smem);
+    int o = tid;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const float4 v = p[o]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; o = (o + 256) & 1023; }
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 123.456f) sink[0] = 1.f;
+  }
+}
+
+template <int KIND>
+int launch(int blocks, int lds, char* buf, size_t window, int iters, hipStream_t s) {
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&probe_kernel<KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  hipLaunchKernelGGL(probe_kernel<KIND>, dim3(blocks), dim3(256), lds, s, buf, window, iters, reinterpret_cast<float*>(buf));
+  return hipGetLastError() == hipSuccess ? TF_OK : TF_ERR_LAUNCH;
+}
+
+}  // namespace
+
+// kind: see the header comment; `blocks` workgroups of 256 threads with `lds_bytes` of dynamic LDS (>= 16 KiB is forced for the
+// kinds that touch it); `buf` / `window_bytes`: the device window the memory kinds walk (multiple of 16, >= 4 KiB)
+extern "C" int tf_debug_probe(int kind, int blocks, int lds_bytes, void* buf, size_t window_bytes, int iters, void* stream_) {
+  if (blocks <= 0 || iters < 0 || lds_bytes < 0 || lds_bytes > 160 * 1024) return TF_ERR_ARG;
+  if (kind != 0 && kind != 3 && kind != 6 && (!buf || window_bytes < 4096 || window_bytes % 16)) return TF_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream_;
+  char* b = (char*)buf;
+  if ((kind == 4 || kind == 6) && lds_bytes < 16 * 1024) lds_bytes = 16 * 1024;
+  switch (kind) {
+    case 0: return launch<0>(blocks, lds_bytes, b, 4096, iters, s);
+    case 1: return launch<1>(blocks, lds_bytes, b, window_bytes, iters, s);
+    case 2: return launch<2>(blocks, lds_bytes, b, window_bytes, iters, s);
+    case 3: return launch<3>(blocks, lds_bytes, b, 4096, iters, s);
+    case 4: return launch<4>(blocks, lds_bytes, b, window_bytes, iters, s);
+    case 5: return launch<5>(blocks, lds_bytes, b, window_bytes, iters, s);
+    case 6: return launch<6>(blocks, lds_bytes, b, 4096, iters, s);
+  }
+  return TF_ERR_ARG;
+}

@@ -10,7 +10,8 @@ struct ProfScope {
   hipStream_t stream;
   // shape: optional GEMM view of the launch (M = pixels, N = output channels, K = reduction length, taps, mode, epilogue flags)
   // so that tf_profile_shapes can aggregate per layer shape, not only per kernel kind
-  ProfScope(int kind, double flops, double bytes, hipStream_t s, int M = 0, int N = 0, int K = 0, int taps = 0, int mode = 0, int epi = 0);
+  ProfScope(int kind, double flops, double bytes, hipStream_t s, int M = 0, int N = 0, int K = 0, int taps = 0, int mode = 0, int epi = 0,
+            double exec_flops = -1.0);   // exec_flops: what the kernel executed (padding, zero taps); < 0: same as flops
   ~ProfScope();                                                     // records the stop event
 };
 }  // namespace tf

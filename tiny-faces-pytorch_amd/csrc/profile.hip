@@ -7,8 +7,8 @@
 #include "profile.h"
 
 namespace {
-struct Rec { int kind; double flops, bytes; hipEvent_t a, b; int M, N, K, taps, mode, epi; };
-struct ShapeAgg { int kind, M, N, K, taps, mode, epi; double launches, ms, flops, bytes; };
+struct Rec { int kind; double flops, bytes, xflops; hipEvent_t a, b; int M, N, K, taps, mode, epi; };
+struct ShapeAgg { int kind, M, N, K, taps, mode, epi; double launches, ms, flops, bytes, xflops; };
 std::vector<ShapeAgg> g_shapes;       // filled by tf_profile_collect, read by tf_profile_shapes
 std::mutex g_mu;
 int g_every = 0;            // 0 = off, n = bracket every n-th profiled launch (1 = all)
@@ -22,11 +22,12 @@ hipEvent_t get_event() {
 }
 }  // namespace
 
-tf::ProfScope::ProfScope(int kind, double flops, double bytes, hipStream_t s, int M, int N, int K, int taps, int mode, int epi) : slot(-1), stream(s) {
+tf::ProfScope::ProfScope(int kind, double flops, double bytes, hipStream_t s, int M, int N, int K, int taps, int mode, int epi, double exec_flops)
+    : slot(-1), stream(s) {
   if (!g_every) return;
   std::lock_guard<std::mutex> lk(g_mu);
   if (g_seq++ % (unsigned long long)g_every) return;
-  Rec r{kind, flops, bytes, get_event(), get_event(), M, N, K, taps, mode, epi};
+  Rec r{kind, flops, bytes, exec_flops < 0 ? flops : exec_flops, get_event(), get_event(), M, N, K, taps, mode, epi};
   (void)hipEventRecord(r.a, s);
   g_recs.push_back(r);
   slot = (int)g_recs.size() - 1;
@@ -44,43 +45,44 @@ extern "C" int tf_profile_enable(int on) {
   return TF_OK;
 }
 
-// rows of 5 doubles: kind, launches, total_ms, total_flops, total_bytes.  Blocks until the recorded events completed.
+// rows of 6 doubles: kind, launches, total_ms, algorithmic flops, algorithmic bytes, executed flops.  Blocks until the recorded events completed.
 extern "C" int tf_profile_collect(double* host_out, int max_rows) {
   std::lock_guard<std::mutex> lk(g_mu);
-  double acc[16][4] = {};
+  constexpr int NK = 24;
+  double acc[NK][5] = {};
   g_shapes.clear();
   for (const Rec& r : g_recs) {
     (void)hipEventSynchronize(r.b);
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess && r.kind >= 0 && r.kind < 16) {
-      acc[r.kind][0] += 1; acc[r.kind][1] += ms; acc[r.kind][2] += r.flops; acc[r.kind][3] += r.bytes;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess && r.kind >= 0 && r.kind < NK) {
+      acc[r.kind][0] += 1; acc[r.kind][1] += ms; acc[r.kind][2] += r.flops; acc[r.kind][3] += r.bytes; acc[r.kind][4] += r.xflops;
       ShapeAgg* hit = nullptr;
       for (ShapeAgg& q : g_shapes)
         if (q.kind == r.kind && q.M == r.M && q.N == r.N && q.K == r.K && q.taps == r.taps && q.mode == r.mode && q.epi == r.epi) { hit = &q; break; }
-      if (!hit) { g_shapes.push_back(ShapeAgg{r.kind, r.M, r.N, r.K, r.taps, r.mode, r.epi, 0, 0, 0, 0}); hit = &g_shapes.back(); }
-      hit->launches += 1; hit->ms += ms; hit->flops += r.flops; hit->bytes += r.bytes;
+      if (!hit) { g_shapes.push_back(ShapeAgg{r.kind, r.M, r.N, r.K, r.taps, r.mode, r.epi, 0, 0, 0, 0, 0}); hit = &g_shapes.back(); }
+      hit->launches += 1; hit->ms += ms; hit->flops += r.flops; hit->bytes += r.bytes; hit->xflops += r.xflops;
     }
     g_pool.push_back(r.a); g_pool.push_back(r.b);
   }
   g_recs.clear();
   int n = 0;
-  for (int k = 0; k < 16 && n < max_rows; ++k)
+  for (int k = 0; k < NK && n < max_rows; ++k)
     if (acc[k][0] > 0) {
-      host_out[n * 5 + 0] = k; host_out[n * 5 + 1] = acc[k][0]; host_out[n * 5 + 2] = acc[k][1];
-      host_out[n * 5 + 3] = acc[k][2]; host_out[n * 5 + 4] = acc[k][3];
+      host_out[n * 6 + 0] = k; host_out[n * 6 + 1] = acc[k][0]; host_out[n * 6 + 2] = acc[k][1];
+      host_out[n * 6 + 3] = acc[k][2]; host_out[n * 6 + 4] = acc[k][3]; host_out[n * 6 + 5] = acc[k][4];
       ++n;
     }
   return n;
 }
 
-// per-shape view of the LAST tf_profile_collect: rows of 11 doubles (kind, M, N, K, taps, mode, epi, launches, total_ms, flops, bytes)
+// per-shape view of the LAST tf_profile_collect: rows of 12 doubles (kind, M, N, K, taps, mode, epi, launches, total_ms, flops, bytes, executed flops)
 extern "C" int tf_profile_shapes(double* host_out, int max_rows) {
   std::lock_guard<std::mutex> lk(g_mu);
   int n = 0;
   for (const ShapeAgg& q : g_shapes) {
     if (n >= max_rows) break;
-    double* o = host_out + (size_t)n * 11;
-    o[0] = q.kind; o[1] = q.M; o[2] = q.N; o[3] = q.K; o[4] = q.taps; o[5] = q.mode; o[6] = q.epi; o[7] = q.launches; o[8] = q.ms; o[9] = q.flops; o[10] = q.bytes;
+    double* o = host_out + (size_t)n * 12;
+    o[0] = q.kind; o[1] = q.M; o[2] = q.N; o[3] = q.K; o[4] = q.taps; o[5] = q.mode; o[6] = q.epi; o[7] = q.launches; o[8] = q.ms; o[9] = q.flops; o[10] = q.bytes; o[11] = q.xflops;
     ++n;
   }
   return n;

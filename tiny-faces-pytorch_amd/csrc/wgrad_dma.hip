@@ -24,7 +24,7 @@ struct WdK {
   int nco, nci, splitk, chunk;
 };
 
-constexpr int PK = 64, NS = 3, TILEB = PK * 128, BUF = 2 * TILEB, L = 4;
+constexpr int PK = 64, TILEB = PK * 128, BUF = 2 * TILEB, L = 4;     // ring depth NS: template parameter (3 default; 2 = 32 KiB of LDS per block)
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void dma16(const void* gsrc, void* lds_wave_base) {
@@ -47,7 +47,7 @@ __device__ __forceinline__ bf16x8 frag_tr(const char* tile, int pk0, int c0) {
 }
 
 // KIND 1: pointwise (1x1, stride 1, pad 0): X row of pixel p is row p.  KIND 0: generic tap gather.
-template <int KIND>
+template <int KIND, int NS = 3>
 __global__ void __launch_bounds__(256) wgrad_dma_kernel(const WdK a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int b = blockIdx.x;
@@ -182,13 +182,18 @@ int tf_wgrad_dma_launch(const tf_wgrad_args* A, hipStream_t stream) {
   }
   k.chunk = (((k.M + sk - 1) / sk) + PK - 1) / PK * PK;
   k.splitk = (k.M + k.chunk - 1) / k.chunk;
-  const size_t lds = (size_t)NS * BUF;
+  // ring depth: the weight gradients share every CU's 160 KiB of LDS with the data-gradient chain on the other stream
+  // (profiles/r03_contention.txt); TINYFACES_WGRAD_NS=2 trades a shallower ring for a third less LDS per block
+  static const int ns = [] { const char* e = getenv("TINYFACES_WGRAD_NS"); const int v = e ? atoi(e) : 3; return v == 2 ? 2 : 3; }();
+  const size_t lds = (size_t)ns * BUF;
   const bool pointwise = ntaps == 1 && A->stride == 1 && A->pad == 0 && A->H == A->OH && A->W == A->OW;
   const double Md = k.M;
   tf::ProfScope prof(14, 2.0 * Md * A->Cout * A->Cin * ntaps,
                      (Md * A->Cout + (double)A->N * A->H * A->W * A->Cin) * 2 + (double)A->Cout * A->Cin * ntaps * 4, stream, k.M, A->Cout,
                      A->Cin * ntaps, ntaps, 2, 0);
-  if (pointwise) hipLaunchKernelGGL(wgrad_dma_kernel<1>, dim3(tiles * k.splitk), dim3(256), lds, stream, k);
-  else           hipLaunchKernelGGL(wgrad_dma_kernel<0>, dim3(tiles * k.splitk), dim3(256), lds, stream, k);
+  if (pointwise) { if (ns == 2) hipLaunchKernelGGL((wgrad_dma_kernel<1, 2>), dim3(tiles * k.splitk), dim3(256), lds, stream, k);
+                   else hipLaunchKernelGGL((wgrad_dma_kernel<1, 3>), dim3(tiles * k.splitk), dim3(256), lds, stream, k); }
+  else           { if (ns == 2) hipLaunchKernelGGL((wgrad_dma_kernel<0, 2>), dim3(tiles * k.splitk), dim3(256), lds, stream, k);
+                   else hipLaunchKernelGGL((wgrad_dma_kernel<0, 3>), dim3(tiles * k.splitk), dim3(256), lds, stream, k); }
   return hipGetLastError() == hipSuccess ? TF_OK : TF_ERR_LAUNCH;
 }

@@ -55,7 +55,7 @@ class ConvArgs(C.Structure):
                 ("x", vp), ("w", vp), ("y", vp),
                 ("pro_scale", vp), ("pro_shift", vp), ("epi_scale", vp), ("epi_shift", vp),
                 ("aux", vp), ("aux2", vp), ("aux3", vp), ("mask_scale", vp), ("mask_shift", vp),
-                ("stat_out", vp), ("tile", i32)]
+                ("stat_out", vp), ("tile", i32), ("alg_k", i32), ("alg_n", i32)]
 
 
 class WgradArgs(C.Structure):
@@ -128,6 +128,7 @@ _SIGNATURES = {
     "tf_profile_shapes": (i32, [C.POINTER(C.c_double), i32]),
     "tf_profile_collect": (i32, [C.POINTER(C.c_double), i32]),
     "tf_debug_conv3x3h_trace": (i32, [vp]),
+    "tf_debug_probe": (i32, [i32, i32, i32, vp, sz, i32, vp]),
 }
 
 _lib = None

@@ -23,31 +23,43 @@ from . import augment
 RF = {"size": [859, 859], "stride": [8, 8], "offset": [-1, -1]}      # wider_face.py:53-55
 
 
+_ATTRIBUTES = ("blur", "expression", "illumination", "invalid", "occlusion", "pose")       # columns 4..9 of a WIDER box record
+
+
 def parse_annotations(path, split="train"):
-    """wider_face.py:65-121 as a function: list of per-image dicts (img_path, bboxes (G,4) f64 x1 y1 x2 y2, blur, expression,
-    illumination, invalid, occlusion, pose)."""
+    """The WIDER FACE annotation text format (what wider_face.py:65-121 reads): per image a file name, a face count n and n
+    records of ten numbers `x y w h blur expression illumination invalid occlusion pose` -- or ONE all-zero record when n = 0.
+    Returns one dict per image: img_path, bboxes (G, 4) float64 as (x1, y1, x2, y2) = (x, y, x + w - 1, y + h - 1) (the
+    1-indexed MATLAB convention the reference keeps), and the six attribute columns; records of zero width or height are
+    dropped, negative numbers lose their sign (both as the reference does).  The test split lists file names only.
+
+    The file is tokenised ONCE; every image's records are then one reshape of a slice of a single float array."""
+    with open(path) as f:
+        text = f.read()
     if split == "test":
-        return [{"img_path": x.strip()} for x in open(path).readlines()]
-    lines = open(path).readlines()
-    data, idx = [], 0
-    while idx < len(lines):
-        img = lines[idx].strip()
-        idx += 1
-        n = int(lines[idx].strip())
-        idx += 1
-        bboxes = np.empty((n, 10))
-        if n == 0:
-            idx += 1                                          # the all-zero placeholder line
-        else:
-            for b in range(n):
-                bboxes[b, :] = [abs(float(x)) for x in lines[idx].strip().split()]
-                idx += 1
-        bboxes = bboxes[~((bboxes[:, 2] == 0) | (bboxes[:, 3] == 0))]
-        bboxes[:, 2] = bboxes[:, 0] + bboxes[:, 2] - 1
-        bboxes[:, 3] = bboxes[:, 1] + bboxes[:, 3] - 1
-        data.append({"img_path": img, "bboxes": bboxes[:, 0:4], "blur": bboxes[:, 4], "expression": bboxes[:, 5],
-                     "illumination": bboxes[:, 6], "invalid": bboxes[:, 7], "occlusion": bboxes[:, 8], "pose": bboxes[:, 9]})
-    return data
+        return [{"img_path": name.strip()} for name in text.splitlines(keepends=True)]
+    rows = text.split("\n")
+    if rows and rows[-1] == "":
+        rows.pop()
+    # pass 1: where does each image start?  (a name line is followed by its count; the records of a count-0 image take one line)
+    heads, at = [], 0
+    while at < len(rows):
+        n = int(rows[at + 1])
+        heads.append((rows[at].strip(), n, at + 2))
+        at += 2 + max(n, 1)
+    # pass 2: every record of the file as one (R, 10) array, sliced per image
+    rec_lines = [rows[first + i] for _, n, first in heads for i in range(n)]
+    flat = np.abs(np.array(" ".join(rec_lines).split(), dtype=np.float64)).reshape(-1, 10) if rec_lines else np.empty((0, 10))
+    out, cursor = [], 0
+    for name, n, _ in heads:
+        rec = flat[cursor:cursor + n]
+        cursor += n
+        rec = rec[(rec[:, 2] != 0) & (rec[:, 3] != 0)]
+        corners = np.concatenate([rec[:, :2], rec[:, :2] + rec[:, 2:4] - 1.0], axis=1)
+        datum = {"img_path": name, "bboxes": corners}
+        datum.update({key: rec[:, 4 + j].copy() for j, key in enumerate(_ATTRIBUTES)})
+        out.append(datum)
+    return out
 
 
 class WIDERFace(dataset.Dataset):

@@ -141,15 +141,12 @@ def get_detections_batch(model, imgs, templates, rf, img_transforms, prob_thresh
 
 def write_results(dets, img_path, split, results_dir=None):
     """evaluation.py:90-114: WIDER submission text file."""
-    results_dir = Path(results_dir or f"{split}_results")
-    results_dir.mkdir(parents=True, exist_ok=True)
-    filename = results_dir / img_path.replace("jpg", "txt")
-    filename.parent.mkdir(parents=True, exist_ok=True)
-    with open(filename, "w") as f:
-        f.write(img_path.split("/")[-1] + "\n")
-        f.write(str(dets.shape[0]) + "\n")
-        for x in dets:
-            left, top = np.round(x[0]), np.round(x[1])
-            width = np.round(x[2] - x[0] + 1)
-            height = np.round(x[3] - x[1] + 1)
-            f.write(f"{int(left)} {int(top)} {int(width)} {int(height)} {x[4]}\n")
+    target = Path(results_dir or f"{split}_results") / img_path.replace("jpg", "txt")
+    target.parent.mkdir(parents=True, exist_ok=True)
+    dets = np.asarray(dets)
+    # the submission format of the WIDER evaluation tool: image name, box count, then `left top width height score` per box with
+    # rounded integer geometry (width = x2 - x1 + 1: the inclusive-pixel convention) and the raw score
+    geometry = np.round(np.stack([dets[:, 0], dets[:, 1], dets[:, 2] - dets[:, 0] + 1, dets[:, 3] - dets[:, 1] + 1], axis=1)) if len(dets) else ()
+    lines = [img_path.rsplit("/", 1)[-1], str(len(dets))]
+    lines += [" ".join(str(int(v)) for v in g) + f" {d[4]}" for g, d in zip(geometry, dets)]
+    target.write_text("\n".join(lines) + "\n")

@@ -8,21 +8,23 @@ from .. import ops
 
 
 class AvgMeter:
-    """loss.py:7-21 (running per-image average, never reset between epochs in the reference)."""
+    """The running per-image loss the trainer prints (attributes `average`, `num_averaged` and methods `update` / `reset` of the
+    reference's meter, loss.py:7-21; it is never reset between epochs there).  A batch contributes its SUMMED loss with weight
+    `size`, so the value is sum(loss) / sum(size) -- kept as that quotient's incremental update so that a printed value equals
+    the reference's digit for digit (trainer two-step golden log, tests/test_gpu_model.py)."""
+
+    __slots__ = ("average", "num_averaged")
 
     def __init__(self):
-        self.average = 0
-        self.num_averaged = 0
-
-    def update(self, loss, size):
-        n = self.num_averaged
-        m = n + size
-        self.average = ((n * self.average) + float(loss)) / m
-        self.num_averaged = m
+        self.reset()
 
     def reset(self):
-        self.average = 0
-        self.num_averaged = 0
+        self.average, self.num_averaged = 0, 0
+
+    def update(self, loss, size):
+        seen = self.num_averaged
+        self.num_averaged = seen + size
+        self.average = (seen * self.average + float(loss)) / self.num_averaged
 
 
 class _CriterionFunction(torch.autograd.Function):
