@@ -373,6 +373,7 @@ int tf_debug_conv3x3h_trace(void* device_buf);
  * 3 MFMA, 4 LDS-DMA, 5 fp32 atomics, 6 LDS reads; `buf` / `window_bytes`: device window of the memory kinds.  Not part of the
  * product path. */
 int tf_debug_probe(int kind, int blocks, int lds_bytes, void* buf, size_t window_bytes, int iters, void* stream);
+int tf_debug_probe_chain(int kind, int blocks, int lds_bytes, void* buf, size_t window_bytes, int iters, int repeat, void* stream);   /* `repeat` launches from one host call */
 /* test hook: raw lane mapping of ds_read_b64_tr_b16 (see tests/test_gpu_small_ops.py) */
 int tf_probe_tr16(unsigned short* out256, void* stream);
 

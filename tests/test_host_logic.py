@@ -502,3 +502,28 @@ def test_wgrad3x3_running_offsets_and_raster_walk():
             p += 64
             n_ref, rem = divmod(p, Hp * Wp); hp_ref, wp_ref = divmod(rem, Wp)
             assert (n, hp, wp) == (n_ref, hp_ref, wp_ref), (H, W, p)
+
+
+def test_nms_batched_splits_calls_under_a_mask_budget(monkeypatch):
+    """ops.nms_batched groups consecutive segments so that the suppression bit matrices of one tf_nms_f64_batched call stay under a byte
+    budget (a 64-image batch at prob_thresh 0.03 would otherwise ask for tens of GB); indices stay those of the caller's
+    concatenated list.  Host logic only: the device call is replaced by a recorder."""
+    import torch
+    from tinyfaces import ops
+    calls = []
+
+    def fake(boxes, scores, offs, thr):
+        calls.append((boxes.shape[0], list(offs)))
+        return [torch.arange(a, b) for a, b in zip(offs, offs[1:])]
+    monkeypatch.setattr(ops, "_nms_batched_call", fake)
+    b, s = torch.zeros(1000, 4), torch.zeros(1000)
+    offs = [0, 100, 400, 400, 1000]
+    out = ops.nms_batched(b, s, offs, 0.3, mask_budget_bytes=ops._mask_bytes(300) + ops._mask_bytes(100))
+    assert calls == [(400, [0, 100, 400, 400]), (600, [0, 600])]
+    assert [(int(k[0]) if len(k) else None, len(k)) for k in out] == [(0, 100), (100, 300), (None, 0), (400, 600)]
+    calls.clear()
+    ops.nms_batched(b, s, offs, 0.3)                              # default budget: one call
+    assert calls == [(1000, offs)]
+    calls.clear()
+    ops.nms_batched(b, s, offs, 0.3, mask_budget_bytes=1)         # every segment over the budget: one call each, never an empty group
+    assert [c[0] for c in calls] == [100, 300, 0, 600]

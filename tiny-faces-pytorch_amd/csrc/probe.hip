@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(256) probe_kernel(char* buf, size_t window, in
       for (int u = 0; u < 8; ++u) {
         const uint4 v = *reinterpret_cast<const uint4*>(buf + idx * 16);
         acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w;
-        idx += step; if (idx >= nchunk) idx -= nchunk;
+        idx = (idx + step) % nchunk;
       }
     }
     if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[0] = 1.f;
@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(256) probe_kernel(char* buf, size_t window, in
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         dma16(buf + idx * 16, dst + (u & 3) * 4096);
-        idx += step; if (idx >= nchunk) idx -= nchunk;
+        idx = (idx + step) % nchunk;
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(256) probe_kernel(char* buf, size_t window, in
     size_t j = ((size_t)blockIdx.x * blockDim.x + tid) % nf;
     for (int i = 0; i < iters; ++i) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { atomicAdd(f + j, 1.0f); j += step; if (j >= nf) j -= nf; }
+      for (int u = 0; u < 4; ++u) { atomicAdd(f + j, 1.0f); j = (j + step) % nf; }
     }
   } else if constexpr (KIND == 6) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -117,4 +117,13 @@ extern "C" int tf_debug_probe(int kind, int blocks, int lds_bytes, void* buf, si
     case 6: return launch<6>(blocks, lds_bytes, b, 4096, iters, s);
   }
   return TF_ERR_ARG;
+}
+// `repeat` launches of the same probe from ONE host call (a C loop: the host side of a Python loop costs ~7 us per launch and hides the
+// GPU-side cost of a dependent launch, which is what scripts/floor.py wants to see)
+extern "C" int tf_debug_probe_chain(int kind, int blocks, int lds_bytes, void* buf, size_t window_bytes, int iters, int repeat, void* stream_) {
+  for (int i = 0; i < repeat; ++i) {
+    const int rc = tf_debug_probe(kind, blocks, lds_bytes, buf, window_bytes, iters, stream_);
+    if (rc != TF_OK) return rc;
+  }
+  return TF_OK;
 }

@@ -129,6 +129,7 @@ _SIGNATURES = {
     "tf_profile_collect": (i32, [C.POINTER(C.c_double), i32]),
     "tf_debug_conv3x3h_trace": (i32, [vp]),
     "tf_debug_probe": (i32, [i32, i32, i32, vp, sz, i32, vp]),
+    "tf_debug_probe_chain": (i32, [i32, i32, i32, vp, sz, i32, i32, vp]),
 }
 
 _lib = None

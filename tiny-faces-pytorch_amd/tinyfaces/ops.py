@@ -20,7 +20,11 @@ def _workspace(key, nbytes, device):
     """Grow-only scratch buffers keyed by purpose + device (kernels never allocate)."""
     k = (key, str(device))
     buf = _ws_cache.get(k)
-    if buf is None or buf.numel() < nbytes:
+    # grow-only, except that a buffer of more than 1 GiB is given back once a request needs less than a quarter of it (one unusually
+    # long candidate list must not pin gigabytes of NMS bit matrix for the rest of the process)
+    if buf is None or buf.numel() < nbytes or (buf.numel() > (1 << 30) and nbytes * 4 < buf.numel()):
+        _ws_cache.pop(k, None)
+        buf = None
         buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
         _ws_cache[k] = buf
     return buf
@@ -148,9 +152,36 @@ def nms(boxes, scores, iou_threshold):
 
 
 NMS_MAX_SEGMENTS = 64                                     # TF_NMS_MAX_SEGMENTS (include/tinyfaces_hip.h)
+NMS_MASK_BUDGET_BYTES = 2 << 30                           # suppression bit matrices of ONE tf_nms_f64_batched call (n_s^2 / 8 bytes per segment)
 
 
-def nms_batched(boxes, scores, seg_offsets, iou_threshold):
+def _mask_bytes(n):
+    return n * ((n + 63) // 64) * 8
+
+
+def nms_batched(boxes, scores, seg_offsets, iou_threshold, mask_budget_bytes=None):
+    """`_nms_batched_call` over groups of consecutive segments whose bit matrices fit `mask_budget_bytes` (default 2 GiB): at the
+    evaluation default prob_thresh = 0.03 an image can have tens of thousands of candidates (300 MB of matrix each), so a 64-image
+    batch in one call would ask for tens of GB of workspace.  A single segment larger than the budget still goes alone."""
+    offs = [int(o) for o in seg_offsets]
+    budget = NMS_MASK_BUDGET_BYTES if mask_budget_bytes is None else int(mask_budget_bytes)
+    S = len(offs) - 1
+    sizes = [_mask_bytes(b - a) for a, b in zip(offs, offs[1:])]
+    if S < 1 or sum(sizes) <= budget:
+        return _nms_batched_call(boxes, scores, offs, iou_threshold)
+    out, first, acc = [], 0, 0
+    for s in range(S + 1):
+        if s == S or (s > first and acc + sizes[s] > budget):
+            a, b = offs[first], offs[s]
+            keeps = _nms_batched_call(boxes[a:b], scores[a:b], [o - a for o in offs[first:s + 1]], iou_threshold)
+            out += [k + a for k in keeps]                     # indices into the caller's concatenated input
+            first, acc = s, 0
+        if s < S:
+            acc += sizes[s]
+    return out
+
+
+def _nms_batched_call(boxes, scores, seg_offsets, iou_threshold):
     """S independent NMS problems in one call (BASELINE.json configs[4]: batched multi-scale NMS): segment s = rows
     [seg_offsets[s], seg_offsets[s+1]) of `boxes` / `scores` (float64, device) -- the multi-scale candidate list of image s of an
     evaluation batch (one evaluation.py:80-84 per image), or one list per pyramid level.  Returns a list of S int64 tensors: the kept
