@@ -561,7 +561,9 @@ def main():
             t_ar, t_nc = [float(v) for v in both.tolist()]
             nbytes = g.numel() * 4
             exposed = max(0.0, dt / args.steps - t_nc)
-            comm = {"gradient_bytes": nbytes, "allreduce_ms_standalone": round(t_ar * 1e3, 3),
+            ones = torch.ones(1, device=device)
+            dist.all_reduce(ones)                     # what the collective library itself saw: the sum of one 1 per participating rank
+            comm = {"ranks": int(ones.item()), "backend": dist.get_backend(), "gradient_bytes": nbytes, "allreduce_ms_standalone": round(t_ar * 1e3, 3),
                     "bus_gb_s": round(2 * (world - 1) / world * nbytes / t_ar / 1e9, 1),
                     "ms_per_step_without_exchange": round(t_nc * 1e3, 3), "exposed_ms_per_step": round(exposed * 1e3, 3),
                     "hidden_fraction": round(max(0.0, 1.0 - exposed / t_ar), 3) if t_ar > 0 else None,

@@ -320,7 +320,8 @@ int tf_detnet_set_dual_stream(int on);
  * bottlenecks >= blocks[k] (and of the heads) are enqueued (blocks[k] = -1: at the very end, stem included).  A
  * communication stream that waits on events[k] can all-reduce that bucket while the rest of the backward pass runs
  * (the reference has no distributed path; this serves the 8-GPU data-parallel row of SURVEY.md section 8e).
- * n = 0 clears.  BN gamma/beta gradients of a block are written on the caller's stream BEFORE the fork that precedes the
+ * n = 0 clears.  The registration is process-wide in the library; the Python surface keeps the events in the model object and
+ * installs them around that model's own backward call only (tinyfaces/models/model.py:_run_backward).  BN gamma/beta gradients of a block are written on the caller's stream BEFORE the fork that precedes the
  * event's stream position, so one event covers them too. */
 int tf_detnet_set_grad_events(const int* blocks, void* const* events, int n);
 /* grad_flat (optional): when every entry of `grads` lies inside [grad_flat, grad_flat + grad_flat_bytes) the whole

@@ -123,6 +123,9 @@ def gen_decode(out):
         out[f"{tag}_score_cls"], out[f"{tag}_score_reg"], out[f"{tag}_prob"] = score_cls, score_reg, prob
         out[f"{tag}_scale"], out[f"{tag}_thr"] = np.array(float(scale)), np.array(thr)
         out[f"{tag}_boxes"], out[f"{tag}_scores"] = b, s
+        # refine=False (utils.py:65-66): what the reference ACTUALLY returns -- `bboxes[0]` of a (4, N) array, the x1 row
+        b0, s0 = get_bboxes(score_cls, score_reg, prob.copy(), templates, thr, RF, scale, refine=False)
+        out[f"{tag}_norefine"], out[f"{tag}_norefine_scores"] = np.asarray(b0, dtype=np.float64), s0
         cases.append(tag)
     out["cases"] = np.array(cases)
     # W < 25 -> the reference raises IndexError (defect D1, utils.py:44)

@@ -1,0 +1,68 @@
+#!/bin/bash
+# ONE parameterised entry for everything that runs on the GPU box through gpurun (replaces the one-shot gpu_round2_*.sh / gpu_r3_*.sh files):
+#
+#   gpurun --timeout 900 -- 'bash scripts/gpu_job.sh <job> [args]'        (several jobs: 'bash scripts/gpu_job.sh tests; bash scripts/gpu_job.sh bench')
+#
+#   tests [pytest args]        pytest -m gpu (default: the whole suite)           -> gpurun_out/pytest_gpu.log, parity_report.txt
+#   bench [bench.py args]      the driver's bench line                            -> gpurun_out/bench.json
+#   ab "ENV=.." "ENV=.." ...   alternating A/B of bench.py variants on THIS box    (scripts/gpu_ab.sh; STEPS=20)
+#   prof [train|eval]          rocprofv3 --kernel-trace --stats of the bench cmd   -> gpurun_out/prof/<leg>_kernel_stats.csv
+#   timeline [ENV=..]          kernel trace of 3 steps -> per-queue timeline       -> gpurun_out/timeline[_tag].txt
+#   pmc-traffic                FETCH_SIZE / WRITE_SIZE passes over the bench cmd   -> gpurun_out/pmc_bench/traffic.json (scripts/gpu_pmc_bench.sh)
+#   pmc-sq SCRIPT              one SQ counter pass over `python SCRIPT`            -> gpurun_out/pmc/sq_summary.txt
+#   layer-table                bench.py --layer-table (every MFMA launch bracketed)-> gpurun_out/layer_table.{json,md}
+#   contention | floor | nms   the round-3 micro-benchmarks (scripts/contention.py, floor.py, nms_bench.py under the tracer)
+#   dist-smoke                 RCCL 1-rank group, 2 gloo ranks on one GPU, 2 nccl ranks on one GPU (expected refusal) -> gpurun_out/dist_smoke.txt
+#   final                      tests + bench + prof + pmc-traffic + layer-table + timeline + eval prof + smoke: the artefacts of a round
+set -u
+job=${1:-help}; shift || true
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+mkdir -p "$R/gpurun_out"
+export PYTHONUNBUFFERED=1
+BARGS="--no-cpu-baseline --no-eval --no-profile --no-fp32-path"
+
+trace_cmd() {   # trace_cmd <outdir> <extra rocprof flags> -- <cmd...>   (run from /tmp: rocprofv3 writes beside its cwd otherwise)
+  local out=$1; shift
+  ( cd /tmp && export TMPDIR=/tmp && rm -rf "$out" && timeout ${TRACE_TIMEOUT:-300} rocprofv3 --kernel-trace --output-format csv -d "$out" -o t "$@" ) > "$R/gpurun_out/rocprof_last.log" 2>&1
+  echo "rocprofv3 exit $?"
+}
+
+case "$job" in
+  tests)
+    rm -f "$R/gpurun_out/parity_report.txt"
+    timeout ${TEST_TIMEOUT:-900} python -m pytest tests -q -m gpu -p no:cacheprovider --durations=8 "$@" > "$R/gpurun_out/pytest_gpu.log" 2>&1
+    echo "pytest exit $?" | tee -a "$R/gpurun_out/pytest_gpu.log"; tail -12 "$R/gpurun_out/pytest_gpu.log" ;;
+  bench)
+    timeout ${BENCH_TIMEOUT:-900} python bench.py "$@" > "$R/gpurun_out/bench.json" 2> "$R/gpurun_out/bench.err"
+    echo "bench exit $?"; tail -2 "$R/gpurun_out/bench.err"; python -c "
+import json; d=json.load(open('$R/gpurun_out/bench.json')); r=d.get('roofline',{})
+print(d['value'], d['ms_per_step'], 'frac', r.get('frac'), 'fwd', r.get('forward_pass',{}).get('ms'), 'eval', d.get('eval',{}).get('ms_per_image'), 'hard', d.get('eval_hard',{}).get('ms_per_image'), 'fp32', d.get('fp32_path',{}).get('img_s'), 'cpu', d.get('cpu_baseline',{}).get('value'))" ;;
+  ab)
+    STEPS=${STEPS:-20} bash scripts/gpu_ab.sh "$@" 2>&1 | tee "$R/gpurun_out/ab.txt" ;;
+  prof)
+    leg=${1:-train}
+    if [ "$leg" = eval ]; then cmd="python $R/bench.py --eval-only"; else cmd="python $R/bench.py --steps 7 --warmup 3 $BARGS"; fi
+    trace_cmd /tmp/prof_$leg --stats -- $cmd
+    mkdir -p "$R/gpurun_out/prof"; f=$(find /tmp/prof_$leg -name "*kernel_stats.csv" | head -1); cp "$f" "$R/gpurun_out/prof/${leg}_kernel_stats.csv"; head -12 "$f" | cut -c1-150 ;;
+  timeline)
+    tag=${TAG:-}; trace_cmd /tmp/tl -- env "$@" python $R/bench.py --steps 3 --warmup 2 $BARGS
+    f=$(find /tmp/tl -name "*kernel_trace.csv" | head -1); python scripts/trace_timeline.py "$f" > "$R/gpurun_out/timeline${tag:+_$tag}.txt" 2>&1; head -12 "$R/gpurun_out/timeline${tag:+_$tag}.txt" ;;
+  pmc-traffic) bash scripts/gpu_pmc_bench.sh ;;
+  pmc-sq)
+    mkdir -p "$R/gpurun_out/pmc"
+    ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/pmc_sq && timeout 200 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d /tmp/pmc_sq -o p -- python $R/$1 > /tmp/pmc_sq.log 2>&1 ); echo "pmc exit $?"
+    f=$(find /tmp/pmc_sq -name "*counter_collection.csv" | head -1); python scripts/pmc_summary.py "$f" "${2:-conv|wgrad}" | tee "$R/gpurun_out/pmc/sq_summary.txt" ;;
+  layer-table)
+    timeout 300 python bench.py --steps 10 --warmup 4 --no-cpu-baseline --no-eval --no-fp32-path --layer-table "$R/gpurun_out/layer_table.json" > "$R/gpurun_out/bench_layer.json" 2> "$R/gpurun_out/bench_layer.err"; echo "layer-table exit $?"; head -12 "$R/gpurun_out/layer_table.md" ;;
+  contention) timeout 600 python scripts/contention.py 2>&1 | grep -v amdgpu.ids | tee "$R/gpurun_out/contention.txt" | tail -40 ;;
+  floor)
+    python scripts/floor.py 2>&1 | grep -v amdgpu.ids | tee "$R/gpurun_out/floor.txt"
+    trace_cmd /tmp/fl --stats -- python $R/scripts/floor.py; f=$(find /tmp/fl -name "*kernel_stats.csv" | head -1); head -4 "$f" | cut -c1-160 | tee -a "$R/gpurun_out/floor.txt" ;;
+  nms) bash scripts/gpu_nms.sh ;;
+  dist-smoke) bash scripts/gpu_dist_smoke.sh ;;
+  final)
+    bash "$0" tests; cp "$R/gpurun_out/parity_report.txt" "$R/gpurun_out/parity_report_full.txt" 2>/dev/null
+    bash "$0" bench; bash "$0" prof train; bash "$0" pmc-traffic; bash "$0" layer-table; bash "$0" timeline; bash "$0" prof eval
+    timeout 200 python __graft_entry__.py smoke 2>&1 | tail -2 ;;
+  *) sed -n 2,22p "$0" ;;
+esac

@@ -117,3 +117,38 @@ def test_gradient_bucket_slices_are_final_when_their_event_fires():
         _hip.lib().tf_detnet_set_grad_events(None, None, 0)
     report("grad_slice_finality", buckets=len(ranges), mb=str([round((e - s) * 4 / 2**20, 1) for _, s, e in ranges]), final=str(snaps))
     assert all(all(s) for s in snaps), snaps
+
+
+def test_evaluate_model_two_ranks_write_what_one_process_writes(tmp_path):
+    """Evaluation is "replicas only" (SURVEY.md 8e): under torchrun every rank of evaluate_model.py takes a strided shard of the image
+    list and writes the WIDER result files of its images (the reference loop, evaluate_model.py:56-68, sharded).  Two ranks sharing
+    the box's GPU (gloo rendezvous) must leave exactly the files a single process leaves, byte for byte."""
+    import subprocess
+    import sys
+    PKG = os.path.join(ROOT, "tiny-faces-pytorch_amd")
+    sys.path.insert(0, ROOT); sys.path.insert(0, PKG)
+    from bench import tame_init_
+    from tinyfaces.models.model import DetectionModel
+    m = DetectionModel(num_objects=1, num_templates=25)
+    tame_init_(m, seed=3)
+    with torch.no_grad():
+        for head in (m.score_res3, m.score_res4):
+            head.bias[:25] -= 3.0
+    ck = tmp_path / "tame.pth"
+    torch.save({"epoch": 1, "batch_size": 4, "model": m.state_dict(), "optimizer": {}}, ck)
+    evalm = os.path.join(PKG, "evaluate_model.py")
+    common = ["synthetic", "--checkpoint", str(ck), "--num-images", "3", "--prob_thresh", "0.5"]
+    env = dict(os.environ, PYTHONPATH=PKG + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r1 = subprocess.run([sys.executable, evalm] + common + ["--results_dir", str(tmp_path / "one")], cwd=tmp_path, capture_output=True, text=True,
+                        timeout=400, env=env)
+    assert r1.returncode == 0, r1.stdout[-1000:] + r1.stderr[-3000:]
+    env2 = dict(env, TINYFACES_DIST_BACKEND="gloo", TINYFACES_SHARE_GPU="1")
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                         "--master-port", "29547", evalm] + common + ["--results_dir", str(tmp_path / "two")], cwd=tmp_path, capture_output=True,
+                        text=True, timeout=600, env=env2)
+    assert r2.returncode == 0, r2.stdout[-1000:] + r2.stderr[-3000:]
+    assert "evaluated on 2 ranks" in r2.stdout
+    one, two = tmp_path / "one" / "synthetic", tmp_path / "two" / "synthetic"
+    assert sorted(os.listdir(one)) == sorted(os.listdir(two)) == ["img_0.txt", "img_1.txt", "img_2.txt"]
+    for f in os.listdir(one):
+        assert open(one / f).read() == open(two / f).read(), f

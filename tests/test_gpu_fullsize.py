@@ -220,12 +220,20 @@ def test_get_detections_960x1280_bf16_overlap(pyramid_case):
         return bool((inter / a).max() > 0.9) if dets.shape[0] else False
     hits = np.array([iou_hit(b) for b in ref])
     found = int(hits.sum())
-    # margin analysis (as the fp32 fixture does for its threshold): the random-weight probabilities pile up AT the threshold, and a bf16
-    # logit is off by up to ~1.5e-2 (test_train_step above), so a reference survivor whose logit clears the threshold by less than twice
-    # that may legitimately drop out.  The survivors that clear it by more must (nearly) all be found.
+    # margin analysis (as the fp32 fixture does for its threshold), measured on the GPU box: with these untrained weights EVERY one of the
+    # reference's 668 survivors clears the threshold by less than 3e-2 in logit (`spread` below), i.e. by less than twice the bf16 error of a
+    # logit (1.5e-2, test_train_step above) -- there is no "safe" survivor whose presence a bf16 path could be held to, and candidate
+    # identity is not a meaningful bf16 bar on random weights.  What IS asserted: (a) the bf16 score maps of the 960 x 1280 level against
+    # the CPU oracle, the quantity the detections are derived from, and (b) that the surviving boxes still cover the reference's
+    # (IoU > 0.9 for >= 88 %, measured 604 of 668 = 0.904; 678 vs 668 kept).
     logit_thr = float(np.log(c["thr"] / (1.0 - c["thr"])))
-    safe = ref[:, 4] - logit_thr > 3e-2
-    found_safe = int(hits[safe].sum())
-    report("fullsize_detections[bf16]", kept=dets.shape[0], ref_kept=ref.shape[0], found=found, safe=int(safe.sum()), found_safe=found_safe)
-    assert found >= 0.88 * ref.shape[0] and abs(dets.shape[0] - ref.shape[0]) <= 0.1 * ref.shape[0]     # measured 604 of 668 (0.904)
-    assert safe.sum() > 100 and found_safe >= 0.95 * safe.sum()
+    spread = float((ref[:, 4] - logit_thr).max())
+    mean, std = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1), torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    x = (c["img"].unsqueeze(0) - mean) / std                    # the SAME normalised input for both implementations
+    with torch.no_grad():
+        y_ref = c["om"](x)
+        y_bf = m.eval()(x.cuda()).cpu()
+    dmap = err(y_bf.numpy(), y_ref.numpy())
+    report("fullsize_detections[bf16]", kept=dets.shape[0], ref_kept=ref.shape[0], found=found, survivor_logit_spread=spread, map_maxabs=dmap[0], map_maxref=dmap[1])
+    assert dmap[0] < 1.8e-2                                                                               # bf16 maps at 960 x 1280 vs the oracle
+    assert found >= 0.88 * ref.shape[0] and abs(dets.shape[0] - ref.shape[0]) <= 0.1 * ref.shape[0]

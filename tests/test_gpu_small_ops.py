@@ -146,6 +146,14 @@ def test_decode_golden(golden, ci):
     # kernel rounds an f64 exp to f32.  They differ by <= 1 f32 ulp of exp(), i.e. <= 1.2e-7 * (box size / scale).
     size = float(max((rb[:, 2] - rb[:, 0]).max(), (rb[:, 3] - rb[:, 1]).max()))
     assert np.abs(b - rb).max() <= 1.3e-7 * size
+    # refine=False (utils.py:65-66): the reference returns the x1 ROW of the anchor boxes (`bboxes[0]` of a (4, N) array): same values
+    # exactly (no exp involved), same candidates; unrefined="boxes" gives the (N, 4) anchors whose first column that row is
+    b0, s0 = get_bboxes(g[f"{tag}_score_cls"], g[f"{tag}_score_reg"], g[f"{tag}_prob"].copy(), t, float(g[f"{tag}_thr"]), RF,
+                        float(g[f"{tag}_scale"]), refine=False)
+    assert b0.shape == g[f"{tag}_norefine"].shape and np.array_equal(b0, g[f"{tag}_norefine"]) and np.array_equal(s0, g[f"{tag}_norefine_scores"])
+    b4, _ = get_bboxes(g[f"{tag}_score_cls"], g[f"{tag}_score_reg"], g[f"{tag}_prob"].copy(), t, float(g[f"{tag}_thr"]), RF,
+                       float(g[f"{tag}_scale"]), refine=False, unrefined="boxes")
+    assert b4.shape == rb.shape and np.array_equal(b4[:, 0], b0) and np.all(b4[:, 2] > b4[:, 0])
 
 
 def test_decode_w_lt_25_raises_like_reference(golden):

@@ -103,6 +103,11 @@ __device__ __forceinline__ double wave_sum(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// PRECONDITION of lane_xor_sum / lane_group_sum / wave_sum(float): ALL 64 lanes active (full exec mask).  A DPP row rotation with
+// bound_ctrl = false contributes 0 for a disabled source lane and the row swaps read whatever an inactive lane's register holds, so
+// a divergent caller gets a silently wrong sum.  Every call site is wave-uniform (criterion.hip, the statistic epilogues of
+// conv_dma / conv3x3h, behind block-uniform conditions); a divergent caller must use the __shfl_xor form (wave_sum(double) below).
+// Their summation order differs from the xor butterfly, i.e. results differ from it at ulp level.
 // v + (v of lane ^ O) for O = 8, 16, 32 without the LDS crossbar (`__shfl_xor` is ds_bpermute_b32: an LDS instruction plus an
 // lgkmcnt wait per level): a DPP row rotation folded into the add (8), and the gfx950 row-swap instructions
 // v_permlane16_swap / v_permlane32_swap (with both operands = v they leave "my half" and "the other half" in the two results).

@@ -313,9 +313,10 @@ struct Ctx {
   hipEvent_t mark_side() { if (!side) return nullptr; hipEvent_t e = next_event(); if (e) (void)hipEventRecord(e, side); return e; }
   void wait_on_main(hipEvent_t e) { if (e) (void)hipStreamWaitEvent(stream, e, 0); }
   hipStream_t wstream() const { return side ? side : stream; }
-  void flush_packs() {
-    if (!jobs.empty()) { chk(tf_pack_weights_batched(dtype, jobs.data(), (int)jobs.size(), stream)); jobs.clear(); }
-    if (!jobs2.empty()) { chk(tf_pack_weights_tiled(dtype, jobs2.data(), (int)jobs2.size(), stream)); jobs2.clear(); }
+  void flush_packs(hipStream_t s = nullptr) {
+    if (!s) s = stream;
+    if (!jobs.empty()) { chk(tf_pack_weights_batched(dtype, jobs.data(), (int)jobs.size(), s)); jobs.clear(); }
+    if (!jobs2.empty()) { chk(tf_pack_weights_tiled(dtype, jobs2.data(), (int)jobs2.size(), s)); jobs2.clear(); }
   }
   const float* P(int i) const { return (const float*)params[i]; }
   float* G(int i) const { return grads ? (float*)grads[i] : nullptr; }
@@ -447,6 +448,21 @@ extern "C" int tf_detnet_forward(int dtype, int training, const float* x, int N,
   if (tr && hipMemsetAsync(P.partial, 0, (size_t)TF_STAT_ROWS * 3 * 1024 * 4, c.stream) != hipSuccess) c.chk(TF_ERR_LAUNCH);   // statistic rows start at zero
   // ---- stem: im2col + GEMM (+BN+ReLU) + maxpool
   const int M1 = N * P.H1 * P.W1;
+  // r3 experiment, NEGATIVE, kept behind TINYFACES_PACK_SIDE=1: the weight re-packing of a training step (three launches, ~170 us: 111 MB
+  // of masters read, 2 x 55 MB written) on a second stream BESIDE the stem's im2col (~130 us) -- both are HBM-bound, side by side they
+  // take as long as back to back and the fork / join events cost a little: 1153 / 1153 img/s against 1161 / 1159 inline (A/B on one box).
+  static hipStream_t g_pack_stream = nullptr;
+  static hipEvent_t g_pack_fork = nullptr, g_pack_join = nullptr;
+  static const bool pack_side_env = getenv("TINYFACES_PACK_SIDE") != nullptr;
+  bool pack_side = tr && !ready && pack_side_env;
+  if (pack_side && !g_pack_stream) {
+    if (hipStreamCreateWithFlags(&g_pack_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&g_pack_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&g_pack_join, hipEventDisableTiming) != hipSuccess) { g_pack_stream = nullptr; }
+  }
+  if (!g_pack_stream) pack_side = false;
+  if (pack_side) {           // everything enqueued so far (the previous step's SGD: the masters) precedes the packing
+    if (hipEventRecord(g_pack_fork, c.stream) != hipSuccess || hipStreamWaitEvent(g_pack_stream, g_pack_fork, 0) != hipSuccess) c.chk(TF_ERR_LAUNCH);
+  }
   c.chk(tf_stem_im2col(x, N, H, W, dtype, P.col, kStemK, c.stream));
   // ---- every weight of the pass re-packed from the fp32 master copy in two launches
   if (!ready) {
@@ -466,7 +482,10 @@ extern "C" int tf_detnet_forward(int dtype, int training, const float* x, int N,
     j.src = c.P(A.head4.w); j.dst = P.w_h4; j.dst_t = P.w_h4t; j.cin = 1024; j.cols_pad = 1024; j.rows_pad_t = 1024;
     c.jobs2.push_back(j);
   }
-  c.flush_packs();
+  c.flush_packs(pack_side ? g_pack_stream : nullptr);
+  if (pack_side) {
+    if (hipEventRecord(g_pack_join, g_pack_stream) != hipSuccess || hipStreamWaitEvent(c.stream, g_pack_join, 0) != hipSuccess) c.chk(TF_ERR_LAUNCH);
+  }
   }
   conv_fill(a, dtype, 0, 1, 1, M1, kStemK, 1, M1, 64, 1, 1, 0, 64, P.col, P.wstem, P.cstem);
   a.alg_k = 147;                                  // 7 x 7 x 3 taps*channels, zero-padded to kStemK for the 64-deep K stages

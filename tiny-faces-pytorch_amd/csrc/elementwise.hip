@@ -198,9 +198,12 @@ __global__ void __launch_bounds__(256) maxpool_fwd_kernel(const T* __restrict__ 
         }
       }
     *reinterpret_cast<uint4*>(reinterpret_cast<char*>(y) + i * 16) = tf::pack16<T>(best);
-    if (idx) {
+    if (idx) {                                     // one EPS-byte store per chunk
+      uint8_t ib[EPS];
 #pragma unroll
-      for (int j = 0; j < EPS; ++j) idx[i * EPS + j] = (uint8_t)bi[j];
+      for (int j = 0; j < EPS; ++j) ib[j] = (uint8_t)bi[j];
+      if constexpr (EPS == 8) { uint2 q; __builtin_memcpy(&q, ib, 8); *reinterpret_cast<uint2*>(idx + i * EPS) = q; }
+      else { uint32_t q; __builtin_memcpy(&q, ib, 4); *reinterpret_cast<uint32_t*>(idx + i * EPS) = q; }
     }
   }
 }
@@ -237,9 +240,12 @@ __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const T* __restrict__ 
         const uint4 gv = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(g) + o * 16);
         float gf[EPS];
         tf::unpack16<T>(gv, gf);
-        const uint8_t* ip = idx + o * EPS;
+        // the EPS arg-max bytes of this chunk in ONE load (8 bytes bf16 / 4 bytes fp32) instead of EPS byte loads per window
+        uint8_t ib[EPS];
+        if constexpr (EPS == 8) { const uint2 q = *reinterpret_cast<const uint2*>(idx + o * EPS); __builtin_memcpy(ib, &q, 8); }
+        else { const uint32_t q = *reinterpret_cast<const uint32_t*>(idx + o * EPS); __builtin_memcpy(ib, &q, 4); }
 #pragma unroll
-        for (int j = 0; j < EPS; ++j) if (ip[j] == kh * 3 + kw) acc[j] += gf[j];
+        for (int j = 0; j < EPS; ++j) if (ib[j] == kh * 3 + kw) acc[j] += gf[j];
       }
     }
     const uint4 xv = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(x) + i * 16);

@@ -3,12 +3,13 @@
 random images (no WIDER files needed); results are written in the WIDER submission format by write_results exactly like
 evaluate_model.py:47-68.  The pyramid levels are built on the GPU."""
 import argparse
+import os
 
 import torch
 
 from types import SimpleNamespace
 
-from tinyfaces import transforms
+from tinyfaces import parallel, transforms
 from tinyfaces.datasets import get_dataloader
 from tinyfaces.evaluation import get_detections, get_model, write_results
 
@@ -56,13 +57,26 @@ def main():
     args = arguments()
     if not torch.cuda.is_available():
         raise SystemExit("this build of the tiny-faces hot path runs on MI355X only (no CPU fallback)")
-    device = torch.device("cuda:0")
+    # Multi-GPU evaluation = replicas only: under torchrun every rank takes a strided shard of the image list
+    # (datasets.get_dataloader) and writes the result files of ITS images into the shared results tree; no collective on the
+    # data path, one barrier at the end.  A plain `python evaluate_model.py` is rank 0 of a world of 1, exactly the reference's loop
+    # (evaluate_model.py:56-68).  TINYFACES_DIST_BACKEND=gloo + TINYFACES_SHARE_GPU=1: several ranks on one device (functional tests).
+    distributed = parallel.init_from_env(os.environ.get("TINYFACES_DIST_BACKEND"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    share = os.environ.get("TINYFACES_SHARE_GPU") == "1"
+    device = torch.device(f"cuda:{local % torch.cuda.device_count() if share else local}")
+    torch.cuda.set_device(device)
     val_loader, templates = dataloader(args)
     model = get_model(args.checkpoint, num_templates=templates.shape[0])
     model = model.to(device).eval()
     with torch.no_grad(), model.constant_weights():          # the checkpoint does not change between images: pack the weights once
         run(model, val_loader, templates, args.prob_thresh, args.nms_thresh, device, args.split, results_dir=args.results_dir,
             debug=args.debug or args.dataset == "synthetic")
+    if distributed:
+        torch.distributed.barrier()
+        if parallel.rank() == 0:
+            print(f"evaluated on {parallel.world_size()} ranks")
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -66,7 +66,7 @@ def load_pretrained_trunk(model, path):
     """The reference's default `pretrained_weights=ResNet101_Weights.IMAGENET1K_V1` (model.py:13-14,20) from a local file:
     a torchvision resnet101 state_dict (keys `conv1.weight`, `layer1.0...`, `fc.*`; `layer4.*` is dropped like model.py:23)
     or a checkpoint of this package / the reference (`{"model": {...}}` with `model.`-prefixed keys)."""
-    sd = torch.load(path, map_location="cpu")
+    sd = torch.load(path, map_location="cpu", weights_only=True)      # a state_dict of tensors: nothing else is unpickled
     sd = sd.get("model", sd)
     if any(k.startswith("model.") for k in sd):
         missing, unexpected = model.load_state_dict(sd, strict=False)
@@ -114,6 +114,11 @@ def main():
         for mult, g in zip((1.0, 0.1, 1.0, 0.0), optimizer.param_groups):
             g.setdefault("initial_lr", args.lr * mult)                    # StepLR(last_epoch >= 0) requires it (main.py:81-83)
         scheduler = optim.lr_scheduler.StepLR(optimizer, step_size=LR_STEP, last_epoch=first_epoch - 1)
+        # StepLR's constructor takes one step() from the lr it finds in the groups: a checkpoint saved at a multiple of LR_STEP epochs
+        # already carries the decayed lr and would be decayed AGAIN (the reference has this quirk, main.py:76-83).  Here the fused and
+        # the autograd path must train a resumed run at the SAME lr: put every group on the closed form the fused engine uses.
+        for mult, g in zip((1.0, 0.1, 1.0, 0.0), optimizer.param_groups):
+            g["lr"] = lr_at(args.lr, first_epoch) * mult
 
     for epoch in range(first_epoch, args.epochs):
         if hasattr(train_loader, "set_epoch"):

@@ -21,15 +21,22 @@ def get_dataloader(datapath, args, num_templates=25, template_file="templates.js
 
     Data parallel (one process per GPU, tinyfaces/parallel.py): every rank walks ITS shard of the data -- a
     DistributedSampler for annotation files, a rank-dependent seed for the synthetic crops -- so an epoch is one pass over
-    the data whatever the world size and no two ranks ever differentiate the same images."""
+    the data whatever the world size (up to the sampler's padding of the last shards).  Evaluation loaders shard by stride."""
     from .. import parallel
     templates = load_templates(num_templates)
     world, rank = (parallel.world_size(), parallel.rank()) if parallel.is_distributed() else (1, 0)
     if str(datapath) == "synthetic" or getattr(args, "synthetic", False):
         length = getattr(args, "synthetic_len", 256)
-        ds = SyntheticCrops(templates, length=max(1, length // world), seed=getattr(args, "seed", 0) * world + rank,
-                            train=train, img_transforms=img_transforms)
-        loader = data.DataLoader(ds, batch_size=args.batch_size, shuffle=False, num_workers=0, collate_fn=ds.collate)
+        if train:
+            ds = SyntheticCrops(templates, length=max(1, length // world), seed=getattr(args, "seed", 0) * world + rank,
+                                train=train, img_transforms=img_transforms)
+            loader = data.DataLoader(ds, batch_size=args.batch_size, shuffle=False, num_workers=0, collate_fn=ds.collate)
+            return loader, templates
+        # evaluation: ONE image list whatever the world size; rank r takes images r, r + world, ... (no padding, no duplicates), so the
+        # union of the ranks' result files is exactly what a single process writes (evaluate_model.py:56-68 sharded, "replicas only")
+        ds = SyntheticCrops(templates, length=length, seed=getattr(args, "seed", 0), train=False, img_transforms=img_transforms)
+        loader = data.DataLoader(ds, batch_size=args.batch_size, shuffle=False, sampler=list(range(rank, length, world)) if world > 1 else None,
+                                 num_workers=0, collate_fn=ds.collate)
         return loader, templates
     # datasets/__init__.py:40-52: the WIDER FACE annotation file + image tree
     from pathlib import Path
@@ -38,7 +45,12 @@ def get_dataloader(datapath, args, num_templates=25, template_file="templates.js
                    dataset_root=Path(getattr(args, "dataset_root", "")).expanduser(), debug=getattr(args, "debug", False))
     # decoding runs in the workers (identity collate there); the device half of a batch -- augmentation + targets -- runs in
     # this process, where the GPU context lives
-    sampler = data.distributed.DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=train) if world > 1 else None
+    # training: equal shards (DistributedSampler pads the last ones with repeated samples when len(ds) % world != 0 -- a handful of
+    # images per epoch are then seen by two ranks); evaluation: strided shards without padding, every image exactly once
+    if world > 1:
+        sampler = data.distributed.DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=True) if train else list(range(rank, len(ds), world))
+    else:
+        sampler = None
     inner = data.DataLoader(ds, batch_size=args.batch_size, shuffle=train and sampler is None, sampler=sampler,
                             num_workers=getattr(args, "workers", 0), collate_fn=_identity)
     return DeviceCollatingLoader(inner, ds.collate), templates

@@ -5,7 +5,7 @@ no per-parameter Python loop and no host sync:
     -> [RCCL all-reduce of the flat gradient, overlapped with the backward pass] -> fused SGD (one launch per group)
 
 Data-parallel overlap: the flat gradient is cut along the backward order into buckets of ~`bucket_mb` MB (default 10: heads +
-layer3.21-22 first, then two layer-3 bottlenecks of 4.5 MB each per bucket, ..., finally layer1/2 + stem: SURVEY.md 8e asks for
+layer3.21-22 first, then THREE layer-3 bottlenecks of 4.46 MB each per bucket (two stay under 10 MB), ..., finally layer1/2 + stem: SURVEY.md 8e asks for
 8-12 buckets of ~10 MB in layer 3).  The executor records an event when a bucket's gradients are enqueued
 (tf_detnet_set_grad_events); a communication stream waits on it and starts that bucket's all-reduce while the
 remaining bottlenecks are still being differentiated, so only the last, small bucket is exposed.
@@ -20,9 +20,6 @@ import torch.distributed as dist
 
 from . import ops, parallel
 from ._hip import lib
-
-
-_events_owner = None        # id() of the engine whose events are currently registered with the executor (process-wide state)
 
 
 class TrainEngine:
@@ -90,21 +87,17 @@ class TrainEngine:
             events.append(ev)
         blocks = (C.c_int * len(ranges))(*[r[0] for r in ranges])
         handles = (C.c_void_p * len(ranges))(*[int(ev.cuda_event) for ev in events])
-        rc = lib().tf_detnet_set_grad_events(blocks, handles, len(ranges))
-        if rc != 0:
-            raise RuntimeError(f"tf_detnet_set_grad_events failed: {rc}")
-        global _events_owner
-        _events_owner = id(self)
+        # the events belong to this engine's MODEL: DetectionModel._run_backward hands them to the executor for the duration of its
+        # own backward call (r3: no process-wide registration any more, several engines per process are fine)
+        self.model._grad_events = (blocks, handles, len(ranges))
         self._overlap = dict(ranges=ranges, events=events, comm=torch.cuda.Stream(device=self.device), keep=(blocks, handles))
 
     def close(self):
-        """Detach the gradient-ready events from the executor (they are owned by this engine: the executor must not record
+        """Detach the gradient-ready events from the model (they are owned by this engine: the executor must not record
         handles that are about to be destroyed)."""
-        global _events_owner
         if self._overlap is not None:
-            if _events_owner == id(self):                     # a newer engine may have registered its own events since
-                lib().tf_detnet_set_grad_events(None, None, 0)
-                _events_owner = None
+            if getattr(self.model, "_grad_events", None) is not None and self.model._grad_events[0] is self._overlap["keep"][0]:
+                self.model._grad_events = None
             self._overlap = None
 
     def __del__(self):
@@ -179,8 +172,6 @@ class TrainEngine:
         """Per bucket: the communication stream waits for the executor's gradient-ready event, then the all-reduce is
         issued from it (RCCL's own stream orders itself after the issuing stream); the compute stream only waits at
         the end.  Without the events (not set up): few large buckets after the whole backward pass."""
-        if self._overlap is not None and _events_owner != id(self):
-            raise RuntimeError("another TrainEngine registered its gradient-ready events with the executor: one distributed engine per process")
         if self._overlap is not None:
             ov, works = self._overlap, []
             for (_, start, end), ev in zip(ov["ranges"], ov["events"]):

@@ -120,7 +120,7 @@ class DetectionModel(nn.Module):
         self._session_depth = 0          # constant_weights() nesting
         self._ready_key = None           # (workspace ptr, dtype, table key) whose packed eval weights sit in the workspace
         if isinstance(pretrained_weights, (str, os.PathLike)):           # no network here: a local file only
-            sd = torch.load(pretrained_weights, map_location="cpu")
+            sd = torch.load(pretrained_weights, map_location="cpu", weights_only=True)
             sd = sd.get("model", sd)
             if any(k.startswith("model.") for k in sd):
                 self.load_state_dict(sd, strict=False)
@@ -327,9 +327,19 @@ class DetectionModel(nn.Module):
                 self._persist_table = (gflat.data_ptr(), table)
         else:
             table = cache[1]
+        # gradient-ready events of a data-parallel TrainEngine live in THIS model (`_grad_events`, set by the engine that owns it):
+        # they are handed to the executor for the duration of this model's backward call only, so several models / engines in one
+        # process never see each other's events (the executor's registration is a per-call argument in all but the C signature)
+        ev = getattr(self, "_grad_events", None)
         with torch.cuda.device(x.device):
-            check(lib().tf_detnet_backward(self.compute_dtype, ptr(x), N, H, W, self.num_out, self._param_ptrs, table, ptr(gout),
-                                           ptr(gflat), gflat.numel() * 4, ptr(self._ws), self._ws.numel(), stream()), "tf_detnet_backward")
+            if ev is not None:
+                check(lib().tf_detnet_set_grad_events(ev[0], ev[1], ev[2]), "tf_detnet_set_grad_events")
+            try:
+                check(lib().tf_detnet_backward(self.compute_dtype, ptr(x), N, H, W, self.num_out, self._param_ptrs, table, ptr(gout),
+                                               ptr(gflat), gflat.numel() * 4, ptr(self._ws), self._ws.numel(), stream()), "tf_detnet_backward")
+            finally:
+                if ev is not None:
+                    lib().tf_detnet_set_grad_events(None, None, 0)
         self._last_grad_flat = gflat
         if persistent:
             return gflat

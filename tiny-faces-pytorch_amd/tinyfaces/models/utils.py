@@ -8,13 +8,19 @@ from .. import ops
 
 
 def get_bboxes(score_cls, score_reg, prob_cls, templates, prob_thresh, rf, scale=1, refine=True, mask_axis="w",
-               device="cuda"):
+               device="cuda", unrefined="reference"):
     """utils.py:4-76 with numpy in / numpy out, run on the GPU.
     score_cls / prob_cls (1,H,W,nt) f32, score_reg (1,H,W,4nt) f32 -> (N,4) f64 boxes, (N,1) f32 scores.
     `prob_cls` is only used for its shape: the kernel recomputes sigmoid(score_cls) like
-    evaluation.py:62.  mask_axis='w' reproduces the reference (defect D1, utils.py:44)."""
+    evaluation.py:62.  mask_axis='w' reproduces the reference (defect D1, utils.py:44).
+
+    refine=False (utils.py:65-66, never used by the reference's own callers): the anchor boxes without the regression
+    refinement = the same kernel on zeroed regression channels (cw * exp(0) == cw, cx + cw * 0 == cx: exact).  The reference then
+    takes `bboxes[0]` of a (4, N) array, i.e. it returns only the x1 ROW, shape (N,): reproduced by default (`unrefined="reference"`);
+    `unrefined="boxes"` returns the (N, 4) anchor boxes that were evidently meant."""
     if not refine:
-        raise NotImplementedError("refine=False is not on the evaluated path (utils.py:66-67)")
+        boxes, scores = get_bboxes(score_cls, np.zeros_like(score_reg), prob_cls, templates, prob_thresh, rf, scale, True, mask_axis, device)
+        return (boxes[:, 0].copy() if unrefined == "reference" else boxes), scores
     nt = templates.shape[0]
     _, H, W, _ = score_cls.shape
     vx, vt = ops.template_masks(templates, scale, W, mask_axis)
