@@ -181,6 +181,12 @@ typedef struct tf_conv_args {
   const float* mask_scale; const float* mask_shift;
   float* stat_out;    /* [mtiles][2][ldy] fp32 partial sums, mtiles = tf_conv_mtiles() */
   int tile;           /* 0 = auto; else 1:(128x128) 2:(128x64) 3:(64x64) pixels x channels */
+  /* TF_EPI_STATS only (r3): per-channel value subtracted from every output BEFORE it enters the two sums, so that the consumer computes
+   * var = E[(x-s)^2] - E[x-s]^2 around a shift s close to the mean instead of E[x^2] - mean^2 (which loses (mean/std)^2 of the
+   * significant bits in fp32).  The executor passes the BN's running mean.  stat_shift_out [Cout] receives the shift that was used
+   * (written by the launch's first pixel tile) -- the consumer reads it from there, never from a buffer that is updated meanwhile.
+   * NULL: no shift (sums of x and x^2 as before). */
+  const float* stat_shift; float* stat_shift_out;
   int alg_k, alg_n;   /* measurement hooks only: the UNPADDED reduction length (taps * channels) and output-channel count when the
                          operands are zero-padded (stem: 147 of 192, heads: 125 of 128); 0 = Cin*KH*KW / Cout */
 } tf_conv_args;
@@ -272,6 +278,7 @@ typedef struct tf_bn_fwd_desc {
   const float* gamma; const float* beta;
   float* scale; float* shift; float* mean; float* invstd;        /* published */
   float* running_mean; float* running_var;                        /* updated in place (may be NULL) */
+  const float* stat_shift;           /* [C] the shift the producer subtracted (tf_conv_args.stat_shift_out); NULL: none */
 } tf_bn_fwd_desc;
 typedef struct tf_bn_bwd_desc {
   const float* stat;                 /* [rows][nk][C]: k = 0 sum gz, k = kidx sum gz*x */

@@ -811,3 +811,57 @@ def test_bn_statistics_with_large_mean(ratio):
     d = err(from_nhwc(y.to(dtype).cuda()), ref)
     report(f"bn_large_mean[{ratio}]", var_rel=var_rel, y_maxabs=d[0])
     assert var_rel < 8 * (ratio ** 2 + 1) * 2.0 ** -24 * 4 and d[0] < 4e-6 * (ratio ** 2 + 1) + 1e-5
+
+
+@pytest.mark.parametrize("ratio", [10.0, 100.0])
+def test_bn_statistics_shifted_by_the_running_mean(ratio):
+    """r3: the conv epilogue sums (x - s) and (x - s)^2 with s = the BN's running mean (tf_conv_args.stat_shift) and the
+    consumer's table rebuilds mean = s + E[x - s], var = E[(x-s)^2] - E[x-s]^2.  With |mean| = ratio x std and a shift within one std of
+    the mean the variance is right to fp32 rounding (the unshifted sums of the test above are off by 8 (ratio^2 + 1) 2^-24: 5e-3 at 100);
+    with no shift the old arithmetic is unchanged.  An identity pointwise conv in fp32 (exact MFMA) feeds tf_bn_relu_fused."""
+    import ctypes as C
+    from tinyfaces import _hip, ops
+    from tinyfaces._hip import lib, ptr, stream
+    g = _g(int(ratio) + 7)
+    N, H, W, Cc = 4, 24, 24, 64
+    M = N * H * W
+    center = ratio * (torch.rand(Cc, generator=g) + 0.5)
+    xr = torch.randn(N, Cc, H, W, generator=g) + center.view(1, Cc, 1, 1)
+    x_d = to_nhwc(xr, torch.float32)
+    wp = ops.pack_weight(torch.eye(Cc).view(Cc, Cc, 1, 1).cuda(), torch.float32)
+    var_ref = xr.double().var(dim=(0, 2, 3), unbiased=False)
+    mean_ref = xr.double().mean(dim=(0, 2, 3))
+    out = {}
+    for name, shift in (("none", None), ("running_mean", (center + 0.7 * torch.randn(Cc, generator=g)).cuda())):
+        a = _hip.ConvArgs()
+        a.dtype, a.mode = _hip.TF_F32, 0
+        a.N, a.H, a.W, a.Cin, a.OH, a.OW, a.Cout, a.KH, a.KW, a.stride, a.pad = N, H, W, Cc, H, W, Cc, 1, 1, 1, 0
+        a.ldy, a.epi, a.tile = Cc, _hip.EPI_STATS, 0
+        y = torch.empty(N, H, W, Cc, device="cuda")
+        rows = lib().tf_conv_mtiles(C.byref(a))
+        stat = torch.zeros(rows * 2 + 1, Cc, device="cuda")            # [rows][2][C] + the shift row
+        a.x, a.w, a.y, a.stat_out = ptr(x_d), ptr(wp), ptr(y), ptr(stat)
+        if shift is not None:
+            a.stat_shift, a.stat_shift_out = ptr(shift), stat[rows * 2].data_ptr()
+        assert lib().tf_conv2d(C.byref(a), stream()) == 0
+        assert torch.equal(y, x_d)                                    # identity conv, exact fp32 MFMA
+        vec = [torch.zeros(Cc, device="cuda") for _ in range(6)]
+        gam, bet = torch.ones(Cc, device="cuda"), torch.zeros(Cc, device="cuda")
+        d = _hip.BnFwdDesc()
+        d.stat, d.gamma, d.beta = ptr(stat), ptr(gam), ptr(bet)
+        d.scale, d.shift, d.mean, d.invstd, d.running_mean, d.running_var = [ptr(v) for v in vec]
+        d.stat_shift = stat[rows * 2].data_ptr()
+        z = torch.empty_like(y)
+        assert lib().tf_bn_relu_fused(_hip.TF_F32, ptr(y), C.byref(d), rows, M, Cc, float(M), 1e-5, 0.1, ptr(z), stream()) == 0
+        torch.cuda.synchronize()
+        if shift is not None:
+            assert torch.equal(stat[rows * 2], shift)                 # the producer recorded what it subtracted
+        var = 1.0 / vec[3].cpu().double() ** 2 - 1e-5
+        out[name] = (float(((var - var_ref).abs() / var_ref).max()), float((vec[2].cpu().double() - mean_ref).abs().max()))
+        zr = torch.relu(F.batch_norm(xr, None, None, torch.ones(Cc), torch.zeros(Cc), True, 0.1, 1e-5))
+        out[name + "_y"] = err(from_nhwc(z), zr)[0]
+    report(f"bn_stat_shift[{ratio}]", var_rel_none=out["none"][0], var_rel_shift=out["running_mean"][0], mean_abs_none=out["none"][1],
+           mean_abs_shift=out["running_mean"][1], y_none=out["none_y"], y_shift=out["running_mean_y"])
+    assert out["running_mean"][0] < 2e-5 and out["running_mean_y"] < 2e-5          # fp32 rounding of the sums, whatever the ratio
+    assert out["none"][0] < 8 * (ratio ** 2 + 1) * 2.0 ** -24 * 4                  # unchanged without a shift (bound of the test above)
+    assert out["running_mean"][0] < out["none"][0] or out["none"][0] < 1e-5

@@ -22,6 +22,7 @@ struct FwdBn {
   const float* stat;             // [R][2][C]: sum, sum of squares over the batch
   const float* gamma; const float* beta;
   float* scale; float* shift; float* mean; float* invstd; float* rmean; float* rvar;
+  const float* sshift;           // [C] what the producer subtracted before summing (NULL: nothing)
 };
 struct BwdBn {
   const float* stat;             // [R][nk][C]: row 0 = sum gz, row kidx = sum gz*x
@@ -51,8 +52,12 @@ __device__ __forceinline__ void fwd_table(const FwdBn& d, int R, int C, float co
   double s = 0.0, q = 0.0;
 #pragma unroll
   for (int r = 0; r < RT; ++r) { s += (double)sv[r]; q += (double)qv[r]; }
-  const double mean = s / count;
-  double var = q / count - mean * mean;
+  // s, q = sums of (x - m0), (x - m0)^2 with the producer's shift m0 (0 without one): var = E[(x-m0)^2] - E[x-m0]^2 cancels only
+  // ((mean - m0) / std)^2 of the bits of the fp32 sums instead of (mean / std)^2 (r3; m0 = the BN's running mean in the executor)
+  const double m0 = d.sshift ? (double)d.sshift[c] : 0.0;
+  const double dm = s / count;
+  const double mean = m0 + dm;
+  double var = q / count - dm * dm;
   if (var < 0.0) var = 0.0;
   const float invstd = (float)(1.0 / sqrt(var + (double)eps));
   const float sc = ga * invstd;
@@ -281,7 +286,7 @@ extern "C" int tf_bn_relu_fused(int dtype, const void* x, const tf_bn_fwd_desc* 
                                 float momentum, void* y, void* stream) {
   if (!x || !y || !bn || !bn->stat || !bn->gamma || !bn->beta || !bn->scale || !bn->shift || !bn->mean || !bn->invstd) return TF_ERR_ARG;
   if (rows < 1 || rows > TF_STAT_ROWS || !fused_shape_ok(C, dtype)) return TF_ERR_ARG;
-  const FwdBn d{bn->stat, bn->gamma, bn->beta, bn->scale, bn->shift, bn->mean, bn->invstd, bn->running_mean, bn->running_var};
+  const FwdBn d{bn->stat, bn->gamma, bn->beta, bn->scale, bn->shift, bn->mean, bn->invstd, bn->running_mean, bn->running_var, bn->stat_shift};
   DISPATCH_T(dtype, hipLaunchKernelGGL((bn_relu_fused_kernel<T, RT>), fused_grid(M, C, dtype), dim3(256), 0, (hipStream_t)stream, (const T*)x, d, rows,
                                        (size_t)M, C, count, eps, momentum, (T*)y));
   TF_CHECK_LAUNCH();
@@ -293,9 +298,9 @@ extern "C" int tf_bn_add_relu_fused(int dtype, const void* x, const tf_bn_fwd_de
   if (!x || !r || !y || !bn || !bn->stat || !bn->gamma || !bn->beta || !bn->scale || !bn->shift || !bn->mean || !bn->invstd) return TF_ERR_ARG;
   if (bn_r && (!bn_r->stat || !bn_r->gamma || !bn_r->beta || !bn_r->scale || !bn_r->shift || !bn_r->mean || !bn_r->invstd)) return TF_ERR_ARG;
   if (rows < 1 || rows > TF_STAT_ROWS || !fused_shape_ok(C, dtype)) return TF_ERR_ARG;
-  const FwdBn d1{bn->stat, bn->gamma, bn->beta, bn->scale, bn->shift, bn->mean, bn->invstd, bn->running_mean, bn->running_var};
+  const FwdBn d1{bn->stat, bn->gamma, bn->beta, bn->scale, bn->shift, bn->mean, bn->invstd, bn->running_mean, bn->running_var, bn->stat_shift};
   FwdBn d2 = d1;
-  if (bn_r) d2 = FwdBn{bn_r->stat, bn_r->gamma, bn_r->beta, bn_r->scale, bn_r->shift, bn_r->mean, bn_r->invstd, bn_r->running_mean, bn_r->running_var};
+  if (bn_r) d2 = FwdBn{bn_r->stat, bn_r->gamma, bn_r->beta, bn_r->scale, bn_r->shift, bn_r->mean, bn_r->invstd, bn_r->running_mean, bn_r->running_var, bn_r->stat_shift};
   if (bn_r) {
     DISPATCH_T(dtype, hipLaunchKernelGGL((bn_add_relu_fused_kernel<T, true, RT>), fused_grid(M, C, dtype), dim3(256), 0, (hipStream_t)stream, (const T*)x,
                                          d1, (const T*)r, d2, rows, (size_t)M, C, count, eps, momentum, (T*)y));

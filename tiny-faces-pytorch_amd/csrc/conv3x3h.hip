@@ -54,7 +54,7 @@ struct HK {
   const float* epi_scale; const float* epi_shift;
   const char* aux; const char* aux2; const char* aux3;
   const float* mask_scale; const float* mask_shift;
-  float* stat_out;
+  float* stat_out; const float* stat_shift; float* stat_shift_out;
   int H, W, C, ldy, Ktot, cpt, nst, ntiles, epi, srows, mtiles, rtiles, ctiles, sign, dbg;
   unsigned long long* trace;
 };
@@ -274,10 +274,14 @@ __global__ void __launch_bounds__(NT, 2) conv3x3h_kernel(const HK a) {
   const int chunk8 = tid % CPR, tc = tid / CPR;
   const int ch0 = n0 + chunk8 * EPS;
   const bool cok = ch0 < a.ldy;
-  float es[EPS], eh[EPS], ms[EPS], mh[EPS], s1[EPS], s2[EPS];
+  float es[EPS], eh[EPS], ms[EPS], mh[EPS], s1[EPS], s2[EPS], sft[EPS];
 #pragma unroll
-  for (int j = 0; j < EPS; ++j) { es[j] = 1.f; eh[j] = 0.f; ms[j] = 0.f; mh[j] = 0.f; s1[j] = 0.f; s2[j] = 0.f; }
+  for (int j = 0; j < EPS; ++j) { es[j] = 1.f; eh[j] = 0.f; ms[j] = 0.f; mh[j] = 0.f; s1[j] = 0.f; s2[j] = 0.f; sft[j] = 0.f; }
   if (cok) {
+    if ((a.epi & TF_EPI_STATS) && a.stat_shift) {    // sums of (x - shift), (x - shift)^2: see tf_conv_args.stat_shift
+#pragma unroll
+      for (int j = 0; j < EPS; ++j) sft[j] = a.stat_shift[ch0 + j];
+    }
     if (a.epi & TF_EPI_AFFINE) {
 #pragma unroll
       for (int j = 0; j < EPS; ++j) { es[j] = a.epi_scale[ch0 + j]; eh[j] = a.epi_shift[ch0 + j]; }
@@ -306,7 +310,7 @@ __global__ void __launch_bounds__(NT, 2) conv3x3h_kernel(const HK a) {
     }
     if (a.epi & TF_EPI_STATS) {
 #pragma unroll
-      for (int j = 0; j < EPS; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
+      for (int j = 0; j < EPS; ++j) { const float t = v[j] - sft[j]; s1[j] += t; s2[j] += t * t; }
     }
     const size_t o = ((((size_t)img * a.H + oh) * a.W + ow) * a.ldy + ch0) * sizeof(T);
     float ax[EPS];
@@ -364,6 +368,10 @@ __global__ void __launch_bounds__(NT, 2) conv3x3h_kernel(const HK a) {
       for (int j = 0; j < EPS; ++j) { red[(wave * 2 + 0) * BN + lane * EPS + j] = s1[j]; red[(wave * 2 + 1) * BN + lane * EPS + j] = s2[j]; }
     }
     __syncthreads();
+    if ((a.epi & TF_EPI_STATS) && a.stat_shift && a.stat_shift_out && mt == 0) {
+      for (int cl = tid; cl < BN; cl += NT)
+        if (n0 + cl < a.ldy) a.stat_shift_out[n0 + cl] = a.stat_shift[n0 + cl];
+    }
     for (int e = tid; e < 2 * BN; e += NT) {
       const int k = e / BN, cl = e - k * BN, c = n0 + cl;
       if (c < a.ldy) {
@@ -419,6 +427,7 @@ int launch(const tf_conv_args* A, hipStream_t stream) {
   k.epi_scale = A->epi_scale; k.epi_shift = A->epi_shift;
   k.aux = (const char*)A->aux; k.aux2 = (const char*)A->aux2; k.aux3 = (const char*)A->aux3;
   k.mask_scale = A->mask_scale; k.mask_shift = A->mask_shift; k.stat_out = A->stat_out;
+  k.stat_shift = A->stat_shift; k.stat_shift_out = A->stat_shift_out;
   k.H = A->OH; k.W = A->OW; k.C = A->Cin; k.ldy = A->ldy; k.Ktot = 9 * A->Cin; k.cpt = A->Cin / 64; k.nst = 9 * k.cpt;
   k.ntiles = A->Cout / BN; k.epi = A->epi; k.srows = tf_get_stat_rows();
   k.rtiles = (A->OH + TR - 1) / TR; k.ctiles = (A->OW + TC - 1) / TC; k.mtiles = A->N * k.rtiles * k.ctiles;

@@ -33,9 +33,10 @@ struct DmaK {
   const float* epi_scale; const float* epi_shift;
   const char* aux; const char* aux2; const char* aux3;
   const float* mask_scale; const float* mask_shift;
-  float* stat_out;
+  float* stat_out; const float* stat_shift; float* stat_shift_out;
   int H, W, Cin, OH, OW, KW, stride, pad, sshift;
   int M, OHW, ldy, Ktot, cpt, nstages, ntiles, mode, epi, srows, mtiles, dbg;
+  int scat, sc_hw, sc_w, sc_OH, sc_OW;   // scattered rows (1x1 / stride-2 data gradient): GEMM row p = (n, h, w) of the gradient raster -> output pixel (n, 2h, 2w)
 };
 
 __device__ __forceinline__ int swz(int row) { return ((row >> 1) & 1) ^ (((row >> 2) & 1) << 2) ^ (((row >> 3) & 1) * 6); }
@@ -174,6 +175,14 @@ __global__ void __launch_bounds__(256, MMA == 32 ? 2 : (NS == 1 && BM == 128 ? 4
   }
   const int mt = logical / a.ntiles, nt = logical - mt * a.ntiles;
   const int m0 = mt * BM, n0 = nt * BN;
+  // output row of GEMM row p: identity, or (r3) the even-even pixel of the 2x larger raster for the data gradient of a 1x1 / stride-2 conv.
+  // That gradient is nonzero ONLY there; the generic transposed gather (KIND 2) visits all four parities of the output raster and reads the
+  // zero page for three of them: 4x the rows, DMAs and MFMAs (layer2.0 / layer3.0 downsample: 141 / 136 us -> see launch_kind).
+  auto orow = [&](int p) -> size_t {
+    if (!a.scat) return (size_t)p;
+    const int n = p / a.sc_hw, rem = p - n * a.sc_hw, h = rem / a.sc_w, w = rem - h * a.sc_w;
+    return ((size_t)n * a.sc_OH + 2 * h) * a.sc_OW + 2 * w;
+  };
   const int tid = threadIdx.x, lrow = tid >> 3, pslot = tid & 7;
   const int wave_byte = (tid & ~63) * 16;            // LDS byte offset of this wave's 1 KiB piece inside a 256-thread pass
 
@@ -222,7 +231,7 @@ __global__ void __launch_bounds__(256, MMA == 32 ? 2 : (NS == 1 && BM == 128 ? 4
     for (int ps = 0; ps < P_PASSES; ++ps) {
       const int p = m0 + prl + ps * P_RPP;
       const bool ok = p < a.M && pc0 < a.ldy;
-      const size_t o = ((size_t)(ok ? p : 0) * a.ldy + (ok ? pc0 : 0)) * sizeof(T);
+      const size_t o = (orow(ok ? p : 0) * a.ldy + (ok ? pc0 : 0)) * sizeof(T);
       pf1[ps] = (ok && w1) ? *reinterpret_cast<const uint4*>(a.aux + o) : make_uint4(0, 0, 0, 0);
       pf2[ps] = (ok && w2) ? *reinterpret_cast<const uint4*>(a.aux2 + o) : make_uint4(0, 0, 0, 0);
     }
@@ -334,10 +343,14 @@ __global__ void __launch_bounds__(256, MMA == 32 ? 2 : (NS == 1 && BM == 128 ? 4
   const int chunk = tid % CPR, rlane = tid / CPR;
   const int c0 = n0 + chunk * EPS;
   const bool cok = c0 < a.ldy;
-  float es[EPS], eh[EPS], ms[EPS], mh[EPS], s1[EPS], s2[EPS];
+  float es[EPS], eh[EPS], ms[EPS], mh[EPS], s1[EPS], s2[EPS], sft[EPS];
 #pragma unroll
-  for (int j = 0; j < EPS; ++j) { es[j] = 1.f; eh[j] = 0.f; ms[j] = 0.f; mh[j] = 0.f; s1[j] = 0.f; s2[j] = 0.f; }
+  for (int j = 0; j < EPS; ++j) { es[j] = 1.f; eh[j] = 0.f; ms[j] = 0.f; mh[j] = 0.f; s1[j] = 0.f; s2[j] = 0.f; sft[j] = 0.f; }
   if (cok) {
+    if ((a.epi & TF_EPI_STATS) && a.stat_shift) {    // sums of (x - shift), (x - shift)^2: see tf_conv_args.stat_shift
+#pragma unroll
+      for (int j = 0; j < EPS; ++j) sft[j] = a.stat_shift[c0 + j];
+    }
     if (a.epi & TF_EPI_AFFINE) {
 #pragma unroll
       for (int j = 0; j < EPS; ++j) { es[j] = a.epi_scale[c0 + j]; eh[j] = a.epi_shift[c0 + j]; }
@@ -357,12 +370,12 @@ __global__ void __launch_bounds__(256, MMA == 32 ? 2 : (NS == 1 && BM == 128 ? 4
       const f32x4 t = *reinterpret_cast<const f32x4*>(stg + row * PITCH + chunk * EPS + j);
       v[j] = t[0]; v[j + 1] = t[1]; v[j + 2] = t[2]; v[j + 3] = t[3];
     }
-    if (a.epi & TF_EPI_STATS) {
+    if ((a.epi & TF_EPI_STATS) && p < a.M) {        // (rows >= M hold exact zeros, but not after the shift)
 #pragma unroll
-      for (int j = 0; j < EPS; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }      // rows >= M are exactly 0
+      for (int j = 0; j < EPS; ++j) { const float t = v[j] - sft[j]; s1[j] += t; s2[j] += t * t; }
     }
     if (p < a.M && cok) {
-      const size_t o = ((size_t)p * a.ldy + c0) * sizeof(T);
+      const size_t o = (orow(p) * a.ldy + c0) * sizeof(T);
       float ax[EPS];
       if (a.epi & (TF_EPI_RES | TF_EPI_MASK | TF_EPI_STATS2)) {
         if constexpr (PREF) tf::unpack16<T>(pf1[ps], ax); else tf::unpack16<T>(*reinterpret_cast<const uint4*>(a.aux + o), ax);
@@ -429,6 +442,10 @@ __global__ void __launch_bounds__(256, MMA == 32 ? 2 : (NS == 1 && BM == 128 ? 4
       for (int j = 0; j < EPS; ++j) { red[(wave * 2 + 0) * BN + lane * EPS + j] = s1[j]; red[(wave * 2 + 1) * BN + lane * EPS + j] = s2[j]; }
     }
     __syncthreads();
+    if ((a.epi & TF_EPI_STATS) && a.stat_shift && a.stat_shift_out && mt == 0) {   // the shift this launch used, once per channel
+      for (int cl = tid; cl < BN; cl += 256)
+        if (n0 + cl < a.ldy) a.stat_shift_out[n0 + cl] = a.stat_shift[n0 + cl];
+    }
     for (int e = tid; e < 2 * BN; e += 256) {
       const int k = e / BN, cl = e - k * BN, c = n0 + cl;
       if (c < a.ldy) {
@@ -450,9 +467,14 @@ int launch_kind(const tf_conv_args* A, hipStream_t stream) {
   k.epi_scale = A->epi_scale; k.epi_shift = A->epi_shift;
   k.aux = (const char*)A->aux; k.aux2 = (const char*)A->aux2; k.aux3 = (const char*)A->aux3;
   k.mask_scale = A->mask_scale; k.mask_shift = A->mask_shift; k.stat_out = A->stat_out;
+  k.stat_shift = A->stat_shift; k.stat_shift_out = A->stat_shift_out;
   k.H = A->H; k.W = A->W; k.Cin = A->Cin; k.OH = A->OH; k.OW = A->OW; k.KW = A->KW; k.stride = A->stride; k.pad = A->pad;
   k.sshift = A->stride == 2 ? 1 : 0;
   k.M = A->N * A->OH * A->OW; k.OHW = A->OH * A->OW; k.ldy = A->ldy;
+  k.scat = 0; k.sc_hw = k.sc_w = k.sc_OH = k.sc_OW = 1;
+  if (KIND == 1 && A->mode == 1 && A->stride == 2) {      // scattered pointwise data gradient (see launch()): rows = the GRADIENT raster
+    k.scat = 1; k.M = A->N * A->H * A->W; k.sc_hw = A->H * A->W; k.sc_w = A->W; k.sc_OH = A->OH; k.sc_OW = A->OW;
+  }
   k.cpt = A->Cin / KCH; k.Ktot = A->KH * A->KW * A->Cin; k.nstages = A->KH * A->KW * k.cpt;
   k.ntiles = (A->Cout + BN - 1) / BN; k.mode = A->mode; k.epi = A->epi;
   const int mtiles = (k.M + BM - 1) / BM;
@@ -477,7 +499,7 @@ int launch_kind(const tf_conv_args* A, hipStream_t stream) {
   }
   {
     const double es = sizeof(T), M = k.M, Kt = k.Ktot;
-    double bytes = ((double)A->N * A->H * A->W * A->Cin + (double)A->Cout * Kt + M * A->Cout) * es;
+    double bytes = ((double)A->N * A->H * A->W * A->Cin + (double)A->Cout * Kt + (double)A->N * A->OH * A->OW * A->Cout) * es;
     if (A->epi & (TF_EPI_RES | TF_EPI_MASK | TF_EPI_STATS2)) bytes += M * A->Cout * es;
     if (A->epi & TF_EPI_JOIN) bytes += 2 * M * A->Cout * es;
     if (A->epi & TF_EPI_MASK2) bytes += M * A->Cout * es;
@@ -489,6 +511,12 @@ int launch_kind(const tf_conv_args* A, hipStream_t stream) {
     const double alg_m = A->mode == 1 ? (double)A->N * A->H * A->W : M;
     tf::ProfScope prof(A->dtype == TF_F32 ? 12 : (A->dtype == TF_BF16 ? 13 : 15), 2.0 * alg_m * alg_n * alg_k, bytes, stream, k.M, A->Cout, k.Ktot,
                        A->KH * A->KW, A->mode, A->epi, 2.0 * M * A->Cout * Kt);   // 12 = conv_dma f32, 13 = conv_dma bf16, 15 = conv_dma f16
+    if (k.scat) {
+      // the three other parities of the output raster: zero, or the residual operand itself (y = 0 + aux there)
+      const size_t ybytes = (size_t)A->N * A->OH * A->OW * A->ldy * sizeof(T);
+      const hipError_t e = (A->epi & TF_EPI_RES) ? hipMemcpyAsync(A->y, A->aux, ybytes, hipMemcpyDeviceToDevice, stream) : hipMemsetAsync(A->y, 0, ybytes, stream);
+      if (e != hipSuccess) return TF_ERR_LAUNCH;
+    }
     hipLaunchKernelGGL((conv_dma_kernel<T, BM, BN, NS, KIND, MMA>), dim3(mtiles * k.ntiles), dim3(256), lds, stream, k);
   }
   return hipGetLastError() == hipSuccess ? TF_OK : TF_ERR_LAUNCH;
@@ -498,6 +526,14 @@ template <typename T, int BM, int BN, int NS, int MMA = 16>
 int launch(const tf_conv_args* A, hipStream_t stream) {
   const bool pointwise = A->KH == 1 && A->KW == 1 && A->stride == 1 && A->pad == 0 && A->H == A->OH && A->W == A->OW;
   if (pointwise) return launch_kind<T, BM, BN, NS, 1, MMA>(A, stream);
+  // r3: the data gradient of a 1x1 / stride-2 / pad-0 conv (the downsample branches of layer2.0 and layer3.0) is the pointwise GEMM over the
+  // gradient's own pixels, scattered to the even-even positions of the 2x larger output raster (the rest is zero, or the residual
+  // operand): the pointwise kernel with a row map instead of the transposed gather over all four parities.  Epilogues that reduce over
+  // the output raster (statistics) or read a mask there keep the generic kernel; TINYFACES_SCATTER_DGRAD_OFF=1: A/B knob.
+  static const bool scat_off = getenv("TINYFACES_SCATTER_DGRAD_OFF") != nullptr;
+  if (!scat_off && A->mode == 1 && A->KH == 1 && A->KW == 1 && A->stride == 2 && A->pad == 0 && A->OH >= 2 * A->H - 1 && A->OW >= 2 * A->W - 1 &&
+      !(A->epi & ~(TF_EPI_RES | TF_EPI_AFFINE)) && A->ldy == A->Cout)
+    return launch_kind<T, BM, BN, NS, 1, MMA>(A, stream);
   return A->mode == 0 ? launch_kind<T, BM, BN, NS, 0, MMA>(A, stream) : launch_kind<T, BM, BN, NS, 2, MMA>(A, stream);
 }
 

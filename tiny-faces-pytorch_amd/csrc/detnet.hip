@@ -216,13 +216,14 @@ void build_plan(Plan& P, Arena& ar, int dtype, int N, int H, int W, int nout, in
       if (A.blocks[i].has_ds) bns.push_back(&b.bd);
     }
     size_t nf = 0, nb = 0;
-    for (BnBuf* q : bns) { nf += (size_t)TF_STAT_ROWS * 2 * q->C; nb += (size_t)TF_STAT_ROWS * 3 * q->C; }
+    // forward region of a BN: TF_STAT_ROWS x (sum, sum of squares) + ONE row holding the shift the producer subtracted (r3)
+    for (BnBuf* q : bns) { nf += (size_t)(TF_STAT_ROWS * 2 + 1) * q->C; nb += (size_t)TF_STAT_ROWS * 3 * q->C; }
     P.stat_fwd_floats = training ? nf : 0; P.stat_bwd_floats = training ? nb : 0;
     P.stat_fwd = ar.f32(P.stat_fwd_floats); P.stat_bwd = ar.f32(P.stat_bwd_floats);
     size_t of = 0, ob = 0;
     for (BnBuf* q : bns) {
       q->fst = training && P.stat_fwd ? P.stat_fwd + of : nullptr; q->bst = training && P.stat_bwd ? P.stat_bwd + ob : nullptr;
-      of += (size_t)TF_STAT_ROWS * 2 * q->C; ob += (size_t)TF_STAT_ROWS * 3 * q->C;
+      of += (size_t)(TF_STAT_ROWS * 2 + 1) * q->C; ob += (size_t)TF_STAT_ROWS * 3 * q->C;
     }
   }
   // ---- activations
@@ -363,11 +364,22 @@ void bn_forward(Ctx& c, const ConvUnit& u, int C, BnBuf& b, bool training, const
   }
 }
 
+// r3: the conv that produces a BN's statistics subtracts the BN's running mean before summing (sum (x - s), sum (x - s)^2) and records
+// s in the extra row of the BN's statistic region, where the consumer's table picks it up (fused flow only; bn_fused.hip fwd_table).
+// E[x^2] - mean^2 from fp32 sums loses (mean / std)^2 of the significant bits; around the running mean it loses ((mean - s) / std)^2.
+void stat_shift(tf_conv_args& a, const Ctx& c, const ConvUnit& u, const BnBuf& b, bool fused) {
+  static const bool off = getenv("TINYFACES_STAT_SHIFT_OFF") != nullptr;       // A/B + parity knob
+  if (!fused || off || !b.fst || u.rmean < 0) return;
+  a.stat_shift = (const float*)c.params[u.rmean];
+  a.stat_shift_out = b.fst + (size_t)TF_STAT_ROWS * 2 * b.C;
+}
+
 tf_bn_fwd_desc fwd_desc(const Ctx& c, const ConvUnit& u, const BnBuf& b) {
   tf_bn_fwd_desc d;
   d.stat = b.fst; d.gamma = c.P(u.gamma); d.beta = c.P(u.beta);
   d.scale = b.scale; d.shift = b.shift; d.mean = b.mean; d.invstd = b.invstd;
   d.running_mean = (float*)c.params[u.rmean]; d.running_var = (float*)c.params[u.rvar];
+  d.stat_shift = b.fst ? b.fst + (size_t)TF_STAT_ROWS * 2 * b.C : nullptr;      // zero (memset) unless the producer recorded a shift
   return d;
 }
 tf_bn_bwd_desc bwd_desc(const Ctx& c, const ConvUnit& u, const BnBuf& b, const float* stat, int nk, int kidx) {
@@ -508,7 +520,7 @@ extern "C" int tf_detnet_forward(int dtype, int training, const float* x, int N,
     const int Min = N * b.Hin * b.Win, Mout = N * b.Hout * b.Wout;
     // conv1 1x1
     conv_fill(a, dtype, 0, N, b.Hin, b.Win, B.cin, b.Hin, b.Win, pl, 1, 1, 0, pl, yin, b.w1, b.c1);
-    if (tr) { a.epi = TF_EPI_STATS; a.stat_out = fused ? b.b1.fst : P.partial; }
+    if (tr) { a.epi = TF_EPI_STATS; a.stat_out = fused ? b.b1.fst : P.partial; stat_shift(a, c, B.c1, b.b1, fused); }
     else { bn_forward(c, B.c1, pl, b.b1, false, nullptr, nullptr, 0, eps, mom); a.epi = TF_EPI_AFFINE | TF_EPI_RELU; a.epi_scale = b.b1.scale; a.epi_shift = b.b1.shift; }
     c.chk(tf_conv2d(&a, c.stream));
     // a1 = relu(bn1(c1)), materialised on purpose: every consumer (conv2, its weight gradient) uses the LDS-DMA pipeline
@@ -521,14 +533,14 @@ extern "C" int tf_detnet_forward(int dtype, int training, const float* x, int N,
     }
     // conv2 3x3 (stride here)
     conv_fill(a, dtype, 0, N, b.Hin, b.Win, pl, b.Hout, b.Wout, pl, 3, B.stride, 1, pl, tr ? b.a1 : b.c1, b.w2, b.c2);
-    if (tr) { a.epi = TF_EPI_STATS; a.stat_out = fused ? b.b2.fst : P.partial; }
+    if (tr) { a.epi = TF_EPI_STATS; a.stat_out = fused ? b.b2.fst : P.partial; stat_shift(a, c, B.c2, b.b2, fused); }
     else { bn_forward(c, B.c2, pl, b.b2, false, nullptr, nullptr, 0, eps, mom); a.epi = TF_EPI_AFFINE | TF_EPI_RELU; a.epi_scale = b.b2.scale; a.epi_shift = b.b2.shift; }
     c.chk(tf_conv2d(&a, c.stream));
     if (tr && !fused) bn_forward(c, B.c2, pl, b.b2, true, &a, P.partial, (float)Mout, eps, mom);
     // downsample 1x1 (stride)
     if (B.has_ds) {
       conv_fill(a, dtype, 0, N, b.Hin, b.Win, B.cin, b.Hout, b.Wout, c4, 1, B.stride, 0, c4, yin, b.wd, b.d);
-      if (tr) { a.epi = TF_EPI_STATS; a.stat_out = fused ? b.bd.fst : P.partial; }
+      if (tr) { a.epi = TF_EPI_STATS; a.stat_out = fused ? b.bd.fst : P.partial; stat_shift(a, c, B.ds, b.bd, fused); }
       else { bn_forward(c, B.ds, c4, b.bd, false, nullptr, nullptr, 0, eps, mom); a.epi = TF_EPI_AFFINE; a.epi_scale = b.bd.scale; a.epi_shift = b.bd.shift; }
       c.chk(tf_conv2d(&a, c.stream));
       if (tr && !fused) bn_forward(c, B.ds, c4, b.bd, true, &a, P.partial, (float)Mout, eps, mom);
@@ -542,7 +554,7 @@ extern "C" int tf_detnet_forward(int dtype, int training, const float* x, int N,
     }
     // conv3 1x1 (+ BN + residual + ReLU)
     conv_fill(a, dtype, 0, N, b.Hout, b.Wout, pl, b.Hout, b.Wout, c4, 1, 1, 0, c4, tr ? b.a2 : b.c2, b.w3, tr ? b.c3 : b.y);
-    if (tr) { a.epi = TF_EPI_STATS; a.stat_out = fused ? b.b3.fst : P.partial; }
+    if (tr) { a.epi = TF_EPI_STATS; a.stat_out = fused ? b.b3.fst : P.partial; stat_shift(a, c, B.c3, b.b3, fused); }
     else {
       bn_forward(c, B.c3, c4, b.b3, false, nullptr, nullptr, 0, eps, mom);
       a.epi = TF_EPI_AFFINE | TF_EPI_RES | TF_EPI_RELU; a.epi_scale = b.b3.scale; a.epi_shift = b.b3.shift; a.aux = B.has_ds ? b.d : yin;

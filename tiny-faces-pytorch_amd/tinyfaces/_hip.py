@@ -39,7 +39,7 @@ class Pack2Job(C.Structure):
 class BnFwdDesc(C.Structure):
     """tf_bn_fwd_desc (include/tinyfaces_hip.h)."""
     _fields_ = [("stat", vp), ("gamma", vp), ("beta", vp), ("scale", vp), ("shift", vp), ("mean", vp), ("invstd", vp),
-                ("running_mean", vp), ("running_var", vp)]
+                ("running_mean", vp), ("running_var", vp), ("stat_shift", vp)]
 
 
 class BnBwdDesc(C.Structure):
@@ -55,7 +55,7 @@ class ConvArgs(C.Structure):
                 ("x", vp), ("w", vp), ("y", vp),
                 ("pro_scale", vp), ("pro_shift", vp), ("epi_scale", vp), ("epi_shift", vp),
                 ("aux", vp), ("aux2", vp), ("aux3", vp), ("mask_scale", vp), ("mask_shift", vp),
-                ("stat_out", vp), ("tile", i32), ("alg_k", i32), ("alg_n", i32)]
+                ("stat_out", vp), ("tile", i32), ("stat_shift", vp), ("stat_shift_out", vp), ("alg_k", i32), ("alg_n", i32)]
 
 
 class WgradArgs(C.Structure):
