@@ -111,3 +111,39 @@ def test_kernel_selection_queries_host_side(hip):
     assert w1 <= (256 + 16) * tile_bytes                          # fits the executor's scratch (csrc/detnet.hip: P.dwp_floats)
     assert wgrad_ws(12, 32, 32, 256, 1024, 1) == 0                # pointwise: atomics, no workspace
     assert wgrad_ws(12, 63, 63, 128, 128, 3, stride=2) == 0       # strided 3x3: the per-tap kernel
+
+
+def test_conv_pwx_inline_asm_loads_are_untouched_until_their_wait(tmp_path):
+    """csrc/conv_pwx.hip loads its pixel operand with inline-asm global_load_dwordx4 (hipcc must not count them: it would drain the
+    LDS-DMA weight ring with vmcnt(0) every stage).  hipcc believes such a destination register holds its value from the asm statement
+    on, so it is free to COPY it before the data lands -- a first version of the kernel did exactly that on one branch (phi copies above
+    the wait: stale 16-byte pieces for the cache lines that arrive last, NaNs in two of 64 rows).  ISA audit of every instantiation:
+    between an asm load and the next hand-written `s_waitcnt vmcnt` no instruction may read or write the load's destination."""
+    import re
+    import subprocess
+    src = os.path.join(ROOT, "tiny-faces-pytorch_amd", "csrc", "conv_pwx.hip")
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-save-temps", "-c", src, "-o", str(tmp_path / "pwx.o")],
+                       cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    asm = open(tmp_path / "conv_pwx-hip-amdgcn-amd-amdhsa-gfx950.s").read()
+    names = re.findall(r"^(_ZN12_GLOBAL__N_115conv_pwx_kernel\w+):", asm, re.M)
+    assert len(names) == 4
+    checked = 0
+    for name in names:
+        body = re.search(re.escape(name) + r":(.*?)\.Lfunc_end", asm, re.S).group(1)
+        assert ".vgpr_spill_count" not in body                         # (metadata lives elsewhere; the body itself must hold no scratch traffic)
+        assert "scratch_" not in body, name
+        lines = [l.strip() for l in body.split("\n")]
+        for i, l in enumerate(lines):
+            if not (l.startswith("global_load_dwordx4") and lines[i - 1].startswith(";;#ASMSTART")):
+                continue
+            lo, hi = map(int, re.search(r"v\[(\d+):(\d+)\]", l).groups())
+            j = i + 2
+            while not (lines[j].startswith("s_waitcnt vmcnt") and lines[j - 1].startswith(";;#ASMSTART")):
+                t = lines[j]
+                if t and not t.startswith(";") and not (t.startswith("global_load_dwordx4") and lines[j - 1].startswith(";;#ASMSTART")):
+                    regs = [int(x) for x in re.findall(r"\bv(\d+)\b", t)] + [q for a, b in re.findall(r"v\[(\d+):(\d+)\]", t) for q in range(int(a), int(b) + 1)]
+                    assert not any(lo <= q <= hi for q in regs), (name, l, t)
+                j += 1
+            checked += 1
+    assert checked >= 12          # prologue + steady-state loads of the four instantiations

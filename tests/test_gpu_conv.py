@@ -865,3 +865,78 @@ def test_bn_statistics_shifted_by_the_running_mean(ratio):
     assert out["running_mean"][0] < 2e-5 and out["running_mean_y"] < 2e-5          # fp32 rounding of the sums, whatever the ratio
     assert out["none"][0] < 8 * (ratio ** 2 + 1) * 2.0 ** -24 * 4                  # unchanged without a shift (bound of the test above)
     assert out["running_mean"][0] < out["none"][0] or out["none"][0] < 1e-5
+
+
+@pytest.mark.parametrize("case", [(2, 9, 11, 256, 128), (1, 16, 16, 512, 256), (3, 7, 13, 1024, 256), (2, 8, 8, 128, 128)])
+def test_conv_pwx_bn_backward_prologue(case):
+    """r3, csrc/conv_pwx.hip: tf_conv2d_bnbwd == tf_bn_bwd_apply_fused followed by the pointwise data gradient (conv_dma) on the applied
+    tensor, in ONE launch: the side output T1 = A*g + B*x + D (bf16), the masked gradient with its BN-backward sums (MASK | STATS2), the
+    published dgamma / dbeta -- and the plain form of the kernel (tile 60, no prologue, STATS epilogue) == conv_dma.  M is not a multiple of
+    the 64-pixel tile in three of the four cases."""
+    import ctypes as C
+    from tinyfaces import _hip, ops
+    from tinyfaces._hip import lib, ptr, stream
+    N, H, W, K, Co = case
+    M = N * H * W
+    g = _g(sum(case))
+    dt = torch.bfloat16
+    gz = torch.randn(N, H, W, K, generator=g).to(dt).cuda()
+    x2 = (torch.randn(N, H, W, K, generator=g) * 1.5 + 0.3).to(dt).cuda()
+    w = torch.randn(K, Co, 1, 1, generator=g) / K ** 0.5                       # forward weight [Cout_fwd = K][Cin_fwd = Co]: the data gradient maps K -> Co
+    wt = ops.pack_weight(w.cuda(), dt, transpose=True)
+    cprev = torch.randn(N, H, W, Co, generator=g).to(dt).cuda()                # the tensor behind the ReLU mask (c2)
+    ms, mh = (torch.rand(Co, generator=g) + 0.5).cuda(), (torch.randn(Co, generator=g) * 0.2).cuda()
+    rows = lib().tf_get_stat_rows()
+    stat = (torch.randn(rows, 2, K, generator=g) * 3).cuda()
+    gamma, mean, invstd = (torch.rand(K, generator=g) + 0.5).cuda(), (torch.randn(K, generator=g) * 0.3).cuda(), (torch.rand(K, generator=g) + 0.5).cuda()
+
+    def desc(dgam, dbet):
+        d = _hip.BnBwdDesc()
+        d.stat, d.gamma, d.mean, d.invstd, d.dgamma, d.dbeta, d.nk, d.kidx = ptr(stat), ptr(gamma), ptr(mean), ptr(invstd), ptr(dgam), ptr(dbet), 2, 1
+        return d
+
+    def conv_args(x, y, st, tile=0):
+        a = _hip.ConvArgs()
+        a.dtype, a.mode = _hip.TF_BF16, 1
+        a.N, a.H, a.W, a.Cin, a.OH, a.OW, a.Cout, a.KH, a.KW, a.stride, a.pad = N, H, W, K, H, W, Co, 1, 1, 1, 0
+        a.ldy, a.epi, a.tile = Co, _hip.EPI_MASK | _hip.EPI_STATS2, tile
+        a.x, a.w, a.y, a.aux, a.mask_scale, a.mask_shift, a.stat_out = ptr(x), ptr(wt), ptr(y), ptr(cprev), ptr(ms), ptr(mh), ptr(st)
+        return a
+    # reference: two launches
+    t1_ref = torch.empty_like(gz)
+    dg_ref, db_ref = torch.zeros(K, device="cuda"), torch.zeros(K, device="cuda")
+    d0 = desc(dg_ref, db_ref)
+    assert lib().tf_bn_bwd_apply_fused(_hip.TF_BF16, ptr(gz), None, ptr(x2), C.byref(d0), rows, M, K, float(M), ptr(t1_ref), stream()) == 0
+    y_ref = torch.empty(N, H, W, Co, dtype=dt, device="cuda")
+    a0 = conv_args(t1_ref, y_ref, None, tile=13)
+    st_ref = torch.zeros(lib().tf_conv_mtiles(C.byref(a0)), 2, Co, device="cuda")
+    a0.stat_out = ptr(st_ref)
+    assert lib().tf_conv2d(C.byref(a0), stream()) == 0
+    # fused: one launch
+    t1 = torch.zeros_like(gz)
+    dg, db = torch.zeros(K, device="cuda"), torch.zeros(K, device="cuda")
+    d1 = desc(dg, db)
+    y = torch.empty_like(y_ref)
+    mt = min(rows, (M + 63) // 64)
+    st = torch.zeros(mt, 2, Co, device="cuda")
+    a1 = conv_args(gz, y, st)
+    assert lib().tf_conv2d_bnbwd(C.byref(a1), C.byref(d1), ptr(x2), ptr(t1), rows, float(M), stream()) == 0
+    torch.cuda.synchronize()
+    d_t1 = err(t1.float().cpu(), t1_ref.float().cpu())
+    d_y = err(y.float().cpu(), y_ref.float().cpu())
+    s_f, s_r = st.sum(0).cpu(), st_ref.sum(0).cpu()
+    d_s = float((s_f - s_r).abs().max() / (s_r.abs().max() + 1e-30))
+    report(f"conv_pwx_bnbwd[{case}]", t1_rel=d_t1[2], y_rel=d_y[2], stat_rel=d_s, dgamma=float((dg - dg_ref).abs().max()), dbeta=float((db - db_ref).abs().max()))
+    assert d_t1[2] < 8e-3                      # one bf16 rounding of the applied tensor (the two kernels may contract the FMAs differently)
+    assert torch.equal(dg, dg_ref) and torch.equal(db, db_ref)
+    assert d_y[2] < 2e-2 and d_s < 2e-2        # bf16 operands that differ by <= 1 ulp in a few places, fp32 accumulation
+    # independent check of the gradient against torch on the fused kernel's own T1 (exactly representable operands)
+    ref = F.conv_transpose2d(t1.float().cpu().permute(0, 3, 1, 2), q(w, dt)) if False else torch.einsum("nhwk,kc->nhwc", t1.float().cpu(), q(w, dt)[:, :, 0, 0])
+    ref = torch.where(cprev.float().cpu() * ms.cpu() + mh.cpu() > 0, ref, torch.zeros_like(ref))
+    assert err(y.float().cpu(), ref)[2] < 6e-3
+    # plain form (tile 60, forward-style STATS epilogue) == conv_dma
+    wf = ops.pack_weight(torch.randn(Co, K, 1, 1, generator=g).cuda() / K ** 0.5, dt)
+    ya, sa = ops.conv2d_nhwc(gz, wf, Co, 1, 1, 1, 0, epi=_hip.EPI_STATS, want_stats=True, tile=13)
+    yb, sb = ops.conv2d_nhwc(gz, wf, Co, 1, 1, 1, 0, epi=_hip.EPI_STATS, want_stats=True, tile=60)
+    assert err(yb.float().cpu(), ya.float().cpu())[2] < 4e-3
+    assert float((sa.sum(0) - sb.sum(0)).abs().max() / sa.sum(0).abs().max()) < 1e-3

@@ -11,7 +11,7 @@ static const char* const kSymbols[] = {
     "tf_conv_mtiles", "tf_conv2d", "tf_pack_weight", "tf_pack_weights_batched", "tf_pack_weights_tiled", "tf_conv2d_wgrad", "tf_wgrad_workspace_bytes", "tf_unpack_dw",
     "tf_stem_im2col", "tf_maxpool_fwd", "tf_maxpool_bwd", "tf_colstats_blocks", "tf_colstats",
     "tf_bn_finalize", "tf_bn_fold", "tf_bn_bwd_finalize", "tf_bn_bwd_apply", "tf_bn_relu", "tf_bn_add_relu",
-    "tf_bn_relu_fused", "tf_bn_add_relu_fused", "tf_bn_bwd_apply_fused",
+    "tf_bn_relu_fused", "tf_bn_add_relu_fused", "tf_bn_bwd_apply_fused", "tf_conv2d_bnbwd",
     "tf_upsample_add_crop", "tf_upsample_add_crop_bwd", "tf_reduce_partials",
     "tf_detnet_num_params", "tf_detnet_param_name", "tf_detnet_param_numel", "tf_detnet_workspace_bytes",
     "tf_detnet_out_shape", "tf_detnet_param_region_bytes", "tf_detnet_forward", "tf_detnet_backward", "tf_detnet_set_dual_stream", "tf_detnet_set_grad_events",

@@ -28,6 +28,9 @@ int tf_conv_dma_launch(const tf_conv_args* a, int tile, int depth, hipStream_t s
 bool tf_conv3x3h_applicable(const tf_conv_args* a, bool forced);                              // conv3x3h.hip
 int tf_conv3x3h_mtiles(const tf_conv_args* a);
 int tf_conv3x3h_launch(const tf_conv_args* a, hipStream_t stream);
+bool tf_conv_pwx_applicable(const tf_conv_args* a);                                            // conv_pwx.hip
+int tf_conv_pwx_mtiles(const tf_conv_args* a);
+int tf_conv_pwx_launch(const tf_conv_args* a, const tf_bn_bwd_desc* pro, const void* pro_x2, void* pro_out, int pro_rows, float pro_count, hipStream_t stream);
 
 namespace {
 
@@ -358,6 +361,10 @@ int launch_conv(const tf_conv_args* A, hipStream_t stream) {
 // 50 = halo-resident 3x3 / stride 1 kernel (conv3x3h.hip).  0 = auto.
 int pick_tile(const tf_conv_args* a) {
   if (a->tile) return a->tile;
+  // 60 = conv_pwx (8 waves, 64 pixels x all output channels, register-staged pixel operand): only on request so far
+  // (TINYFACES_PWX_FWD=1: the pointwise convs with 128 / 256 output channels and K >= 128, A/B knob)
+  static const bool pwx_fwd = getenv("TINYFACES_PWX_FWD") != nullptr;
+  if (pwx_fwd && tf_conv_pwx_applicable(a) && a->Cin >= 512) return 60;
   // measured on the bs=12 500x500 layer shapes (scripts/microbench.py): 128 pixels x 64 channels wins on every
   // layer (more, smaller tiles -> more blocks in flight per CU); 64x64 only when even that leaves CUs idle.
   const long M = (long)a->N * a->OH * a->OW;
@@ -391,6 +398,7 @@ extern "C" int tf_conv_mtiles(const tf_conv_args* a) {
   const long M = (long)a->N * a->OH * a->OW;
   const int t = pick_tile(a);
   if (t == 50) { const int mt = tf_conv3x3h_mtiles(a); return mt > tf_get_stat_rows() ? tf_get_stat_rows() : mt; }
+  if (t == 60) { const int mt = tf_conv_pwx_mtiles(a); return mt > tf_get_stat_rows() ? tf_get_stat_rows() : mt; }
   const int bm = tile_bm(t);
   const int mt = (int)((M + bm - 1) / bm);
   return (t >= 10 && mt > tf_get_stat_rows()) ? tf_get_stat_rows() : mt;     // the DMA kernel folds its tiles into <= TF_STAT_ROWS rows
@@ -419,6 +427,7 @@ extern "C" int tf_conv2d(const tf_conv_args* a, void* stream_) {
   if (a->pro_scale && !a->pro_shift) return TF_ERR_ARG;
   const int t = pick_tile(a);
   if (t == 50) return tf_conv3x3h_applicable(a, true) ? tf_conv3x3h_launch(a, stream) : TF_ERR_UNSUPPORTED;
+  if (t == 60) return tf_conv_pwx_launch(a, nullptr, nullptr, nullptr, 0, 0.f, stream);
   if (t >= 10) {
     if (a->pro_scale) return TF_ERR_UNSUPPORTED;
     return tf_conv_dma_launch(a, t % 10, t >= 40 ? 2 : (t >= 30 ? 1 : (t >= 20 ? 4 : 3)), stream);
@@ -432,4 +441,18 @@ extern "C" int tf_conv2d(const tf_conv_args* a, void* stream_) {
   if (t == 1) return launch_conv<float, 128, 128>(a, stream);
   if (t == 2) return launch_conv<float, 128, 64>(a, stream);
   return launch_conv<float, 64, 64>(a, stream);
+}
+
+// tf_bn_bwd_apply_fused + tf_conv2d (pointwise, mode 0 or 1) in ONE launch: the conv's pixel operand is A*x + B*x2 + D with the
+// BatchNorm-backward coefficients of `bn` (derived in-kernel from its statistic rows), the applied tensor also goes to `applied_out`
+// (the weight gradient's operand).  conv_pwx.hip; TF_ERR_UNSUPPORTED for shapes it does not take (the caller runs the two kernels).
+extern "C" int tf_conv2d_bnbwd(const tf_conv_args* a, const tf_bn_bwd_desc* bn, const void* x2, void* applied_out, int rows, float count, void* stream_) {
+  if (!a || !a->x || !a->w || !a->y || !bn || !x2) return TF_ERR_ARG;
+  if ((a->epi & (TF_EPI_STATS | TF_EPI_STATS2 | TF_EPI_STATS3)) && !a->stat_out) return TF_ERR_ARG;
+  if ((a->epi & (TF_EPI_RES | TF_EPI_MASK | TF_EPI_STATS2)) && !a->aux) return TF_ERR_ARG;
+  if ((a->epi & TF_EPI_MASK) && (!a->mask_scale || !a->mask_shift)) return TF_ERR_ARG;
+  if ((a->epi & TF_EPI_MASK2) && !a->aux2) return TF_ERR_ARG;
+  if ((a->epi & TF_EPI_STATS3) && !a->aux3) return TF_ERR_ARG;
+  if (rows < 1 || rows > TF_STAT_ROWS) return TF_ERR_ARG;
+  return tf_conv_pwx_launch(a, bn, x2, applied_out, rows, count, (hipStream_t)stream_);
 }

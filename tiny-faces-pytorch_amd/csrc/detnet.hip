@@ -49,6 +49,7 @@ int tf_bn_relu(int, const void*, const float*, const float*, int64_t, int, void*
 int tf_upsample_add_crop(int, const void*, const void*, const float*, int, int, int, int, int, int, int, float*, void*);
 int tf_upsample_add_crop_bwd(int, const float*, const float*, int, int, int, int, int, int, int, void*, void*, void*);
 int tf_reduce_partials(const float*, int, int, int, int, int, float*, int, void*);
+int tf_conv2d_bnbwd(const tf_conv_args*, const tf_bn_bwd_desc*, const void*, void*, int, float, void*);
 }
 
 namespace {
@@ -762,8 +763,27 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
     const int nk = B.has_ds ? 3 : 2;
     if (!fused) c.chk(tf_colstats(dtype, Gcur, b.y, b.c3, b.d, Mout, c4, c4, P.partial, c.stream));
     else if (B.has_ds) c.chk(tf_colstats(dtype, Gcur, nullptr, b.c3, b.d, Mout, c4, c4, b.b3.bst, c.stream));   // Gcur is already masked
-    // (2) g_c3 -> T1
-    if (fused) {
+    // (2) g_c3 -> T1.  r3: in bf16 the apply can ride on the operand path of the data gradient that consumes it (tf_conv2d_bnbwd,
+    //     conv_pwx.hip): steps (2) and (4) in ONE launch, T1 its side output for the weight gradient.  Measured (scripts/microbench_pwx.py,
+    //     profiles/r03_conv_pwx.txt): layer 2 (M = 47 628, K = 512 -> 128) 37.2 us against 43.1 for the two launches; layer 3 (M = 12 288,
+    //     K = 1024 -> 256) 31.6 against 29.8 -- 192 one-per-CU blocks pay the coefficient table and the register-staged operand where the
+    //     elementwise kernel has thousands of threads in flight.  So: the identity bottlenecks of layer 2 only (TINYFACES_PWX_ALL=1: every
+    //     eligible one, TINYFACES_PWX_OFF=1: none; the step is the same within noise either way, 1160 img/s).
+    static const bool pwx_off = getenv("TINYFACES_PWX_OFF") != nullptr, pwx_all = getenv("TINYFACES_PWX_ALL") != nullptr;
+    bool fused24 = false;
+    if (fused && !pwx_off && dtype == TF_BF16 && !B.has_ds && pl % 128 == 0 && (pl == 128 || pwx_all)) {
+      const tf_bn_bwd_desc d = bwd_desc(c, B.c3, b.b3, b.b3.bst, nk, 1);
+      conv_fill(a, dtype, 1, N, b.Hout, b.Wout, c4, b.Hout, b.Wout, pl, 1, 1, 0, pl, Gcur, b.w3t, T2);
+      a.epi = TF_EPI_MASK | TF_EPI_STATS2; a.aux = b.c2; a.mask_scale = b.b2.scale; a.mask_shift = b.b2.shift; a.stat_out = b.b2.bst;
+      if (fork_each && !late) c.arm_fork();
+      const int rc = tf_conv2d_bnbwd(&a, &d, b.c3, T1, srows, (float)Mout, c.stream);
+      if (rc == TF_OK) fused24 = true;
+      else if (rc != TF_ERR_UNSUPPORTED) c.chk(rc);
+      else if (tf::take_next_stop_event()) c.pending = nullptr;       // the armed event was not consumed: arm again below
+    }
+    if (fused24) {
+      // nothing: T1 and T2 are on their way
+    } else if (fused) {
       const tf_bn_bwd_desc d = bwd_desc(c, B.c3, b.b3, b.b3.bst, nk, 1);
       if (fork_each && !late) c.arm_fork();
       c.chk(tf_bn_bwd_apply_fused(dtype, Gcur, nullptr, b.c3, &d, srows, Mout, c4, (float)Mout, T1, c.stream));
@@ -776,10 +796,12 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
     auto wg3 = [&]() { wgrad(c, B.c3, c4, N, b.Hout, b.Wout, b.Hout, b.Wout, b.a2, pl, T1, c4, nullptr); };
     if (fork_each && !late) { c.fork_armed(); wg3(); }
     // (4) dgrad conv3 -> gz2 in T2 (masked by relu(bn2(c2))) + BN-backward sums
-    conv_fill(a, dtype, 1, N, b.Hout, b.Wout, c4, b.Hout, b.Wout, pl, 1, 1, 0, pl, T1, b.w3t, T2);
-    a.epi = TF_EPI_MASK | TF_EPI_STATS2; a.aux = b.c2; a.mask_scale = b.b2.scale; a.mask_shift = b.b2.shift;
-    a.stat_out = fused ? b.b2.bst : P.partial;
-    c.chk(tf_conv2d(&a, c.stream));
+    if (!fused24) {
+      conv_fill(a, dtype, 1, N, b.Hout, b.Wout, c4, b.Hout, b.Wout, pl, 1, 1, 0, pl, T1, b.w3t, T2);
+      a.epi = TF_EPI_MASK | TF_EPI_STATS2; a.aux = b.c2; a.mask_scale = b.b2.scale; a.mask_shift = b.b2.shift;
+      a.stat_out = fused ? b.b2.bst : P.partial;
+      c.chk(tf_conv2d(&a, c.stream));
+    }
     // (5) g_c2 in place
     if (fused) {
       const tf_bn_bwd_desc d = bwd_desc(c, B.c2, b.b2, b.b2.bst, 2, 1);
