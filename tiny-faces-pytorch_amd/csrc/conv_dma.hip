@@ -36,7 +36,8 @@ struct DmaK {
   float* stat_out; const float* stat_shift; float* stat_shift_out;
   int H, W, Cin, OH, OW, KW, stride, pad, sshift;
   int M, OHW, ldy, Ktot, cpt, nstages, ntiles, mode, epi, srows, mtiles, dbg;
-  int scat, sc_hw, sc_w, sc_OH, sc_OW;   // scattered rows (1x1 / stride-2 data gradient): GEMM row p = (n, h, w) of the gradient raster -> output pixel (n, 2h, 2w)
+  int scat, sc_hw, sc_w, sc_OH, sc_OW;   // scattered rows (stride-2 data gradients): GEMM row p = (n, h, w) of a half-resolution raster -> output pixel (n, 2h + ph, 2w + pw)
+  int ph, pw, kh0, kw0;                  // scat == 2 (KIND 2): parity class of the output pixels and its first tap (taps kh0, kh0+2, .. x kw0, kw0+2, ..)
 };
 
 __device__ __forceinline__ int swz(int row) { return ((row >> 1) & 1) ^ (((row >> 2) & 1) << 2) ^ (((row >> 3) & 1) * 6); }
@@ -181,7 +182,7 @@ __global__ void __launch_bounds__(256, MMA == 32 ? 2 : (NS == 1 && BM == 128 ? 4
   auto orow = [&](int p) -> size_t {
     if (!a.scat) return (size_t)p;
     const int n = p / a.sc_hw, rem = p - n * a.sc_hw, h = rem / a.sc_w, w = rem - h * a.sc_w;
-    return ((size_t)n * a.sc_OH + 2 * h) * a.sc_OW + 2 * w;
+    return ((size_t)n * a.sc_OH + 2 * h + a.ph) * a.sc_OW + 2 * w + a.pw;
   };
   const int tid = threadIdx.x, lrow = tid >> 3, pslot = tid & 7;
   const int wave_byte = (tid & ~63) * 16;            // LDS byte offset of this wave's 1 KiB piece inside a 256-thread pass
@@ -203,7 +204,13 @@ __global__ void __launch_bounds__(256, MMA == 32 ? 2 : (NS == 1 && BM == 128 ? 4
         rowptr[i] = a.x + (size_t)p * a.Cin * sizeof(T) + xs_;
         rstep[i] = KCH * (int)sizeof(T);
       } else {
-        const int n = p / a.OHW, rem = p - n * a.OHW, oh = rem / a.OW, ow = rem - oh * a.OW;
+        int n, oh, ow;
+        if (KIND == 2 && a.scat == 2) {              // row of the parity class's half-resolution raster -> its pixel of the output raster
+          n = p / a.sc_hw; const int rem = p - n * a.sc_hw, sh = rem / a.sc_w;
+          oh = 2 * sh + a.ph; ow = 2 * (rem - sh * a.sc_w) + a.pw;
+        } else {
+          n = p / a.OHW; const int rem = p - n * a.OHW; oh = rem / a.OW; ow = rem - oh * a.OW;
+        }
         if (KIND == 0) { rb_h[i] = oh * a.stride - a.pad; rb_w[i] = ow * a.stride - a.pad; }
         else           { rb_h[i] = oh + a.pad;            rb_w[i] = ow + a.pad; }
         rowptr[i] = a.x + (size_t)n * a.H * a.W * a.Cin * sizeof(T) + xs_;
@@ -238,7 +245,9 @@ __global__ void __launch_bounds__(256, MMA == 32 ? 2 : (NS == 1 && BM == 128 ? 4
   }
 
   // stage iterator (scalar): stages are issued in order, so (slot, chunk, kw, kh) advance incrementally
-  int is_slot = 0, is_c = 0, is_kw = 0, is_kh = 0;
+  const bool par = KIND == 2 && a.scat == 2;       // parity class: only the taps kh0 + 2i, kw0 + 2j exist for these output pixels
+  const int tstep = par ? 2 : 1;
+  int is_slot = 0, is_c = 0, is_kw = par ? a.kw0 : 0, is_kh = par ? a.kh0 : 0;
   auto issue = [&]() {
     char* xs = smem + is_slot * BUF;
     char* ws = xs + XBYTES;
@@ -264,10 +273,16 @@ __global__ void __launch_bounds__(256, MMA == 32 ? 2 : (NS == 1 && BM == 128 ? 4
         dma16(reinterpret_cast<const void*>(src), xs + i * 4096 + wave_byte);
       }
     }
+    if (par) {                                     // the weight slab of (tap, chunk): taps are not consecutive in K
+      const size_t wo = ((size_t)(is_kh * a.KW + is_kw) * a.Cin + (size_t)is_c * KCH) * sizeof(T);
 #pragma unroll
-    for (int i = 0; i < WR; ++i) { dma16(wsrc[i], ws + i * 4096 + wave_byte); wsrc[i] += KCH * sizeof(T); }
+      for (int i = 0; i < WR; ++i) dma16(wsrc[i] + wo, ws + i * 4096 + wave_byte);
+    } else {
+#pragma unroll
+      for (int i = 0; i < WR; ++i) { dma16(wsrc[i], ws + i * 4096 + wave_byte); wsrc[i] += KCH * sizeof(T); }
+    }
     if (++is_slot == NS) is_slot = 0;
-    if (KIND != 1 && ++is_c == a.cpt) { is_c = 0; if (++is_kw == a.KW) { is_kw = 0; ++is_kh; } }
+    if (KIND != 1 && ++is_c == a.cpt) { is_c = 0; is_kw += tstep; if (is_kw >= a.KW) { is_kw = par ? a.kw0 : 0; is_kh += tstep; } }
   };
 
   typedef typename std::conditional<MMA == 32, f32x16, f32x4>::type acc_t;
@@ -452,15 +467,17 @@ __global__ void __launch_bounds__(256, MMA == 32 ? 2 : (NS == 1 && BM == 128 ? 4
         // at most TF_STAT_ROWS partial rows per launch: tile mt accumulates into row mt % TF_STAT_ROWS (fp32 atomics;
         // rows start at zero: the finalize kernels clear what they consumed), so the finalize reads 64 rows, not thousands
         const float v = red[(0 * 2 + k) * BN + cl] + red[(1 * 2 + k) * BN + cl] + red[(2 * 2 + k) * BN + cl] + red[(3 * 2 + k) * BN + cl];
-        if (a.mtiles > a.srows) atomicAdd(&a.stat_out[((size_t)(mt % a.srows) * 2 + k) * a.ldy + c], v);
+        // (several launches of a parity-decomposed gradient fold into the same rows: always accumulate there)
+        if (a.mtiles > a.srows || a.scat == 2) atomicAdd(&a.stat_out[((size_t)(mt % a.srows) * 2 + k) * a.ldy + c], v);
         else a.stat_out[((size_t)mt * 2 + k) * a.ldy + c] = v;
       }
     }
   }
 }
 
+// pcls: -1 = the whole launch; 0..3 = parity class (ph = pcls >> 1, pw = pcls & 1) of a 3x3 / stride-2 / pad-1 data gradient (KIND 2)
 template <typename T, int BM, int BN, int NS, int KIND, int MMA = 16>
-int launch_kind(const tf_conv_args* A, hipStream_t stream) {
+int launch_kind(const tf_conv_args* A, hipStream_t stream, int pcls = -1) {
   constexpr int KCH = MmaD<T>::KCH;
   DmaK k;
   k.x = (const char*)A->x; k.w = (const char*)A->w; k.y = (char*)A->y;
@@ -471,11 +488,20 @@ int launch_kind(const tf_conv_args* A, hipStream_t stream) {
   k.H = A->H; k.W = A->W; k.Cin = A->Cin; k.OH = A->OH; k.OW = A->OW; k.KW = A->KW; k.stride = A->stride; k.pad = A->pad;
   k.sshift = A->stride == 2 ? 1 : 0;
   k.M = A->N * A->OH * A->OW; k.OHW = A->OH * A->OW; k.ldy = A->ldy;
-  k.scat = 0; k.sc_hw = k.sc_w = k.sc_OH = k.sc_OW = 1;
+  k.scat = 0; k.sc_hw = k.sc_w = k.sc_OH = k.sc_OW = 1; k.ph = k.pw = k.kh0 = k.kw0 = 0;
   if (KIND == 1 && A->mode == 1 && A->stride == 2) {      // scattered pointwise data gradient (see launch()): rows = the GRADIENT raster
     k.scat = 1; k.M = A->N * A->H * A->W; k.sc_hw = A->H * A->W; k.sc_w = A->W; k.sc_OH = A->OH; k.sc_OW = A->OW;
   }
   k.cpt = A->Cin / KCH; k.Ktot = A->KH * A->KW * A->Cin; k.nstages = A->KH * A->KW * k.cpt;
+  if (KIND == 2 && pcls >= 0) {                           // one parity class of the output raster (see launch())
+    k.scat = 2; k.ph = pcls >> 1; k.pw = pcls & 1;
+    const int soh = (A->OH - k.ph + 1) / 2, sow = (A->OW - k.pw + 1) / 2;
+    k.sc_hw = soh * sow; k.sc_w = sow; k.sc_OH = A->OH; k.sc_OW = A->OW; k.M = A->N * soh * sow;
+    // taps with (oh + pad - kh) even: kh = kh0, kh0 + 2, ...
+    k.kh0 = ((k.ph + A->pad) & 1); k.kw0 = ((k.pw + A->pad) & 1);
+    const int nkh = (A->KH - k.kh0 + 1) / 2, nkw = (A->KW - k.kw0 + 1) / 2;
+    k.nstages = nkh * nkw * k.cpt;
+  }
   k.ntiles = (A->Cout + BN - 1) / BN; k.mode = A->mode; k.epi = A->epi;
   const int mtiles = (k.M + BM - 1) / BM;
   k.mtiles = mtiles; k.srows = tf_get_stat_rows();
@@ -509,9 +535,14 @@ int launch_kind(const tf_conv_args* A, hipStream_t stream) {
     // stride-2 one executes the zero-inserted gather over its 4x larger output raster; padded K / N (stem, heads) count as what they hold
     const double alg_k = A->alg_k > 0 ? A->alg_k : Kt, alg_n = A->alg_n > 0 ? A->alg_n : A->Cout;
     const double alg_m = A->mode == 1 ? (double)A->N * A->H * A->W : M;
-    tf::ProfScope prof(A->dtype == TF_F32 ? 12 : (A->dtype == TF_BF16 ? 13 : 15), 2.0 * alg_m * alg_n * alg_k, bytes, stream, k.M, A->Cout, k.Ktot,
-                       A->KH * A->KW, A->mode, A->epi, 2.0 * M * A->Cout * Kt);   // 12 = conv_dma f32, 13 = conv_dma bf16, 15 = conv_dma f16
-    if (k.scat) {
+    // executed = the GEMM this launch runs (M rows x Cout x the K it walks); a parity-class launch walks only the taps that exist for its
+    // pixels, so its executed work IS algorithmic work (the four classes add up to the forward conv's MACs, borders aside)
+    const double exec_fl = 2.0 * M * A->Cout * (double)k.nstages * KCH;
+    const double alg_fl = pcls >= 0 ? exec_fl : 2.0 * alg_m * alg_n * alg_k;
+    if (pcls >= 0) bytes = ((double)A->N * A->H * A->W * A->Cin + (double)A->Cout * Kt) * es / 4 + M * A->Cout * es * (1 + ((A->epi & (TF_EPI_RES | TF_EPI_MASK | TF_EPI_STATS2)) ? 1 : 0));
+    tf::ProfScope prof(A->dtype == TF_F32 ? 12 : (A->dtype == TF_BF16 ? 13 : 15), alg_fl, bytes, stream, k.M, A->Cout, k.Ktot,
+                       A->KH * A->KW, A->mode, A->epi, exec_fl);   // 12 = conv_dma f32, 13 = conv_dma bf16, 15 = conv_dma f16
+    if (k.scat == 1) {
       // the three other parities of the output raster: zero, or the residual operand itself (y = 0 + aux there)
       const size_t ybytes = (size_t)A->N * A->OH * A->OW * A->ldy * sizeof(T);
       const hipError_t e = (A->epi & TF_EPI_RES) ? hipMemcpyAsync(A->y, A->aux, ybytes, hipMemcpyDeviceToDevice, stream) : hipMemsetAsync(A->y, 0, ybytes, stream);
@@ -534,6 +565,20 @@ int launch(const tf_conv_args* A, hipStream_t stream) {
   if (!scat_off && A->mode == 1 && A->KH == 1 && A->KW == 1 && A->stride == 2 && A->pad == 0 && A->OH >= 2 * A->H - 1 && A->OW >= 2 * A->W - 1 &&
       !(A->epi & ~(TF_EPI_RES | TF_EPI_AFFINE)) && A->ldy == A->Cout)
     return launch_kind<T, BM, BN, NS, 1, MMA>(A, stream);
+  // r3: the data gradient of a 3x3 / stride-2 / pad-1 conv (conv2 of layer2.0 / layer3.0), by PARITY CLASS of the output pixel.  An output
+  // pixel (ih, iw) only receives the taps with (ih + 1 - kh) and (iw + 1 - kw) even: 1, 2, 2 or 4 of the 9; the generic transposed gather
+  // walks all 9 for every pixel and reads the zero page for the rest (4x the stages, DMAs and MFMAs: 134 and 113 us per launch at
+  // bs = 12, 8-13x over their roofline, profiles/r02_layer_table.md).  Four launches, each a gather over its class's half-resolution
+  // raster with its own tap list; rows scatter back to (2h + ph, 2w + pw); statistic sums fold into the same rows by atomics.
+  static const bool par_off = getenv("TINYFACES_PARITY_DGRAD_OFF") != nullptr;
+  if (!par_off && A->mode == 1 && A->stride == 2 && A->KH == 3 && A->KW == 3 && A->pad == 1 && A->OH >= 2 && A->OW >= 2 &&
+      (tf_get_stat_rows() <= TF_STAT_ROWS || !(A->epi & (TF_EPI_STATS | TF_EPI_STATS2 | TF_EPI_STATS3)))) {
+    for (int pc = 0; pc < 4; ++pc) {
+      const int rc = launch_kind<T, BM, BN, NS, 2, MMA>(A, stream, pc);
+      if (rc != TF_OK) return rc;
+    }
+    return TF_OK;
+  }
   return A->mode == 0 ? launch_kind<T, BM, BN, NS, 0, MMA>(A, stream) : launch_kind<T, BM, BN, NS, 2, MMA>(A, stream);
 }
 
