@@ -168,6 +168,7 @@ int tf_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n,
 int tf_set_stat_rows(int rows);
 int tf_get_stat_rows(void);
 
+struct tf_bn_fwd_desc;
 typedef struct tf_conv_args {
   int dtype, mode;
   int N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad;
@@ -187,6 +188,11 @@ typedef struct tf_conv_args {
    * (written by the launch's first pixel tile) -- the consumer reads it from there, never from a buffer that is updated meanwhile.
    * NULL: no shift (sums of x and x^2 as before). */
   const float* stat_shift; float* stat_shift_out;
+  /* r3: training-mode BatchNorm + ReLU of the conv's INPUT applied inside the conv (x := relu(bn(x)) with the batch statistics of `bnf`
+   * finalized in-kernel, exactly tf_bn_relu_fused followed by this conv): bf16, 1x1 / stride 1 with Cin <= 256 only (the ring-less
+   * LDS-DMA kernel fixes its pixel tile up in LDS after the DMA landed); bnf_out [M][Cin] receives the activated tensor (the weight
+   * gradient's operand; may be NULL).  TF_ERR_UNSUPPORTED for other shapes: run tf_bn_relu_fused + tf_conv2d.  NULL: off. */
+  const struct tf_bn_fwd_desc* bnf; void* bnf_out; int bnf_rows; float bnf_count, bnf_eps, bnf_momentum;
   int alg_k, alg_n;   /* measurement hooks only: the UNPADDED reduction length (taps * channels) and output-channel count when the
                          operands are zero-padded (stem: 147 of 192, heads: 125 of 128); 0 = Cin*KH*KW / Cout */
 } tf_conv_args;

@@ -940,3 +940,70 @@ def test_conv_pwx_bn_backward_prologue(case):
     yb, sb = ops.conv2d_nhwc(gz, wf, Co, 1, 1, 1, 0, epi=_hip.EPI_STATS, want_stats=True, tile=60)
     assert err(yb.float().cpu(), ya.float().cpu())[2] < 4e-3
     assert float((sa.sum(0) - sb.sum(0)).abs().max() / sa.sum(0).abs().max()) < 1e-3
+
+
+@pytest.mark.parametrize("case", [(2, 9, 11, 64, 256, False), (1, 16, 16, 128, 512, True), (3, 7, 13, 256, 1024, True), (2, 8, 8, 64, 64, False)])
+def test_conv_bn_relu_forward_prologue_in_lds(case):
+    """r3, conv_dma.hip (ring-less pointwise kernel, tf_conv_args.bnf): tf_conv2d with the BatchNorm + ReLU of its input applied to the pixel
+    tile in LDS == tf_bn_relu_fused followed by the same tf_conv2d, BIT for bit: the activated tensor (bnf_out), the conv output, its
+    statistic rows, and everything tf_bn_relu_fused publishes (scale / shift / mean / invstd, running statistics).  M is not a multiple of
+    the 128-pixel tile in two of the cases; with and without the statistic shift row."""
+    import ctypes as C
+    from tinyfaces import _hip, ops
+    from tinyfaces._hip import lib, ptr, stream
+    N, H, W, K, Co, shifted = case
+    M = N * H * W
+    g = _g(sum(case[:5]))
+    dt = torch.bfloat16
+    x = (torch.randn(N, H, W, K, generator=g) * 1.3 + 0.4).to(dt).cuda()
+    w = ops.pack_weight((torch.randn(Co, K, 1, 1, generator=g) / K ** 0.5).cuda(), dt)
+    rows = 5
+    stat = torch.zeros(rows * 2 + 1, K, device="cuda")
+    xs = x.float().view(M, K)
+    sh = (torch.randn(K, generator=g) * 0.2 + 0.4).cuda() if shifted else torch.zeros(K, device="cuda")
+    for r in range(rows):                                             # statistic rows of a producer that folded its tiles into 5 rows
+        part = xs[r::rows] - sh
+        stat[2 * r], stat[2 * r + 1] = part.sum(0), (part * part).sum(0)
+    stat[rows * 2] = sh
+    gam, bet = (torch.rand(K, generator=g) + 0.5).cuda(), (torch.randn(K, generator=g) * 0.3).cuda()
+
+    def run(fused):
+        vec = [torch.zeros(K, device="cuda") for _ in range(4)] + [torch.full((K,), 0.25, device="cuda"), torch.full((K,), 2.0, device="cuda")]
+        d = _hip.BnFwdDesc()
+        d.stat, d.gamma, d.beta = ptr(stat), ptr(gam), ptr(bet)
+        d.scale, d.shift, d.mean, d.invstd, d.running_mean, d.running_var = [ptr(v) for v in vec]
+        if shifted:
+            d.stat_shift = stat[rows * 2].data_ptr()
+        act = torch.zeros(N, H, W, K, dtype=dt, device="cuda")
+        y = torch.zeros(N, H, W, Co, dtype=dt, device="cuda")
+        a = _hip.ConvArgs()
+        a.dtype, a.mode = _hip.TF_BF16, 0
+        a.N, a.H, a.W, a.Cin, a.OH, a.OW, a.Cout, a.KH, a.KW, a.stride, a.pad = N, H, W, K, H, W, Co, 1, 1, 1, 0
+        a.ldy, a.epi, a.tile = Co, _hip.EPI_STATS, 0
+        srows = lib().tf_conv_mtiles(C.byref(a))
+        so = torch.zeros(srows * 2, Co, device="cuda")
+        a.w, a.y, a.stat_out = ptr(w), ptr(y), ptr(so)
+        if fused:
+            a.x, a.bnf, a.bnf_out, a.bnf_rows, a.bnf_count, a.bnf_eps, a.bnf_momentum = ptr(x), C.addressof(d), ptr(act), rows, float(M), 1e-5, 0.1
+        else:
+            assert lib().tf_bn_relu_fused(_hip.TF_BF16, ptr(x), C.byref(d), rows, M, K, float(M), 1e-5, 0.1, ptr(act), stream()) == 0
+            a.x = ptr(act)
+        assert lib().tf_conv2d(C.byref(a), stream()) == 0
+        torch.cuda.synchronize()
+        return [act, y, so] + vec
+
+    two, one = run(False), run(True)
+    names = ["activated", "y", "stat_rows", "scale", "shift", "mean", "invstd", "running_mean", "running_var"]
+    for nm, p, q in zip(names, two, one):
+        assert torch.equal(p, q), (nm, float((p.float() - q.float()).abs().max()))
+    ref = torch.relu((xs - xs.mean(0)) / torch.sqrt(xs.var(0, unbiased=False) + 1e-5) * gam + bet)
+    assert err(one[0].float().view(M, K).cpu(), ref.cpu())[0] < 2e-2
+    # a shape the ring-less kernel does not take says so instead of ignoring the descriptor
+    a = _hip.ConvArgs()
+    a.dtype, a.mode = _hip.TF_BF16, 0
+    a.N, a.H, a.W, a.Cin, a.OH, a.OW, a.Cout, a.KH, a.KW, a.stride, a.pad = 1, 8, 8, 512, 8, 8, 64, 1, 1, 1, 0
+    a.ldy = 64
+    xx, ww, yy = torch.zeros(64, 512, dtype=dt, device="cuda"), torch.zeros(512 * 64, dtype=dt, device="cuda"), torch.zeros(64, 64, dtype=dt, device="cuda")
+    d = _hip.BnFwdDesc()
+    a.x, a.w, a.y, a.bnf = ptr(xx), ptr(ww), ptr(yy), C.addressof(d)
+    assert lib().tf_conv2d(C.byref(a), stream()) == -3                # TF_ERR_UNSUPPORTED

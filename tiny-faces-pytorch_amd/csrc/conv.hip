@@ -426,6 +426,7 @@ extern "C" int tf_conv2d(const tf_conv_args* a, void* stream_) {
   if ((a->epi & TF_EPI_MASK) && (!a->mask_scale || !a->mask_shift)) return TF_ERR_ARG;
   if (a->pro_scale && !a->pro_shift) return TF_ERR_ARG;
   const int t = pick_tile(a);
+  if (a->bnf && !(t == 32 && a->mode == 0 && a->KH == 1 && a->KW == 1 && a->stride == 1 && a->Cin <= 256)) return TF_ERR_UNSUPPORTED;
   if (t == 50) return tf_conv3x3h_applicable(a, true) ? tf_conv3x3h_launch(a, stream) : TF_ERR_UNSUPPORTED;
   if (t == 60) return tf_conv_pwx_launch(a, nullptr, nullptr, nullptr, 0, 0.f, stream);
   if (t >= 10) {

@@ -38,6 +38,10 @@ struct DmaK {
   int M, OHW, ldy, Ktot, cpt, nstages, ntiles, mode, epi, srows, mtiles, dbg;
   int scat, sc_hw, sc_w, sc_OH, sc_OW;   // scattered rows (stride-2 data gradients): GEMM row p = (n, h, w) of a half-resolution raster -> output pixel (n, 2h + ph, 2w + pw)
   int ph, pw, kh0, kw0;                  // scat == 2 (KIND 2): parity class of the output pixels and its first tap (taps kh0, kh0+2, .. x kw0, kw0+2, ..)
+  // pro == 1 (ring-less pointwise, 2-byte types): x := relu(bn(x)) applied to the pixel tile in LDS after its DMA landed (tf_conv_args.bnf)
+  int pro, pf_rows; float pf_count, pf_eps, pf_mom;
+  const float* pf_stat; const float* pf_gamma; const float* pf_beta; const float* pf_sshift;
+  float* pf_scale; float* pf_shift; float* pf_mean; float* pf_invstd; float* pf_rmean; float* pf_rvar; char* pf_out;
 };
 
 __device__ __forceinline__ int swz(int row) { return ((row >> 1) & 1) ^ (((row >> 2) & 1) << 2) ^ (((row >> 3) & 1) * 6); }
@@ -299,13 +303,68 @@ __global__ void __launch_bounds__(256, MMA == 32 ? 2 : (NS == 1 && BM == 128 ? 4
 
   const int nst = a.nstages;
   if constexpr (NS == 1) {
-    // no ring: one 16 KiB stage buffer (the epilogue staging tile is larger), eight blocks per CU hide each other's
-    // load latency -- for the 1-4 stage convs whose time is dispatch + prologue + epilogue
+    // r3: the BatchNorm + ReLU in front of this conv (tf_conv_args.bnf), applied to the pixel tile IN LDS after its DMA landed: the
+    // thread that requested a 16-byte piece reads it back, activates its 8 channels and stores it again (and, for the first channel
+    // tile, to bnf_out: the weight gradient's operand), one more barrier per stage.  This kernel waits for every stage's DMA anyway
+    // (ring-less, 1-4 stages, latency-bound with 4 blocks per CU), so the fix-up rides in time other blocks spend waiting, and the
+    // separate bn_relu launch (one per bottleneck on the forward chain) disappears.  Coefficients: bn_fused.hip fwd_table, all Cin <= 256
+    // channels per block, in a 2 KiB table behind the staging tile; block 0 publishes scale / shift / mean / invstd + running statistics.
+    constexpr bool FIX = KIND == 1 && sizeof(T) == 2;
+    constexpr int TAB_AT = (BUF > BM * (BN + 4) * 4 ? BUF : BM * (BN + 4) * 4);
+    float* ctab = reinterpret_cast<float*>(smem + TAB_AT);
+    if constexpr (FIX) {
+      if (a.pro) {
+        const bool writer = logical == 0;
+        for (int c = tid; c < a.Cin; c += 256) {
+          double s = 0.0, q = 0.0;
+          for (int r = 0; r < a.pf_rows; ++r) { s += (double)a.pf_stat[(size_t)(r * 2) * a.Cin + c]; q += (double)a.pf_stat[(size_t)(r * 2 + 1) * a.Cin + c]; }
+          const double m0s = a.pf_sshift ? (double)a.pf_sshift[c] : 0.0;
+          const double dm = s / a.pf_count, mean = m0s + dm;
+          double var = q / a.pf_count - dm * dm;
+          if (var < 0.0) var = 0.0;
+          const float invstd = (float)(1.0 / sqrt(var + (double)a.pf_eps));
+          const float sc = a.pf_gamma[c] * invstd, sh = a.pf_beta[c] - (float)mean * sc;
+          ctab[c] = sc; ctab[256 + c] = sh;
+          if (writer) {
+            a.pf_scale[c] = sc; a.pf_shift[c] = sh; a.pf_mean[c] = (float)mean; a.pf_invstd[c] = invstd;
+            if (a.pf_rmean) {
+              const double unbiased = a.pf_count > 1.f ? var * a.pf_count / (a.pf_count - 1.0) : var;
+              a.pf_rmean[c] = (1.f - a.pf_mom) * a.pf_rmean[c] + a.pf_mom * (float)mean;
+              a.pf_rvar[c] = (1.f - a.pf_mom) * a.pf_rvar[c] + a.pf_mom * (float)unbiased;
+            }
+          }
+        }
+      }
+    }
     for (int st = 0; st < nst; ++st) {
       if (st) __builtin_amdgcn_s_barrier();         // everyone finished reading the previous stage
       issue();
       wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();
+      __syncthreads();                              // (r3: also publishes the coefficient table written above)
+      if constexpr (FIX) {
+        if (a.pro) {
+#pragma unroll
+          for (int i = 0; i < XR; ++i) {
+            const int row = lrow + i * 32, p = m0 + row;
+            if (p < a.M) {
+              char* piece = smem + row * 128 + pslot * 16;
+              const int k0 = st * 64 + ((pslot ^ swz(row)) << 3);
+              float f[8];
+              tf::unpack16<T>(*reinterpret_cast<const uint4*>(piece), f);
+#pragma unroll
+              for (int j = 0; j < 8; j += 4) {
+                const f32x4 vs = *reinterpret_cast<const f32x4*>(ctab + k0 + j), vh = *reinterpret_cast<const f32x4*>(ctab + 256 + k0 + j);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) f[j + q] = fmaxf(f[j + q] * vs[q] + vh[q], 0.f);
+              }
+              const uint4 o = tf::pack16<T>(f);
+              *reinterpret_cast<uint4*>(piece) = o;
+              if (a.pf_out && nt == 0) *reinterpret_cast<uint4*>(a.pf_out + ((size_t)p * a.Cin + k0) * sizeof(T)) = o;
+            }
+          }
+          __syncthreads();
+        }
+      }
       compute(smem);
     }
   } else {
@@ -485,6 +544,17 @@ int launch_kind(const tf_conv_args* A, hipStream_t stream, int pcls = -1) {
   k.aux = (const char*)A->aux; k.aux2 = (const char*)A->aux2; k.aux3 = (const char*)A->aux3;
   k.mask_scale = A->mask_scale; k.mask_shift = A->mask_shift; k.stat_out = A->stat_out;
   k.stat_shift = A->stat_shift; k.stat_shift_out = A->stat_shift_out;
+  k.pro = 0; k.pf_rows = 0; k.pf_count = k.pf_eps = k.pf_mom = 0.f;
+  k.pf_stat = k.pf_gamma = k.pf_beta = k.pf_sshift = nullptr; k.pf_scale = k.pf_shift = k.pf_mean = k.pf_invstd = k.pf_rmean = k.pf_rvar = nullptr; k.pf_out = nullptr;
+  if (A->bnf) {
+    if (!(NS == 1 && KIND == 1 && sizeof(T) == 2) || A->Cin > 256) return TF_ERR_UNSUPPORTED;
+    const tf_bn_fwd_desc* d = A->bnf;
+    if (!d->stat || !d->gamma || !d->beta || !d->scale || !d->shift || !d->mean || !d->invstd || A->bnf_rows < 1) return TF_ERR_ARG;
+    k.pro = 1; k.pf_rows = A->bnf_rows; k.pf_count = A->bnf_count; k.pf_eps = A->bnf_eps; k.pf_mom = A->bnf_momentum;
+    k.pf_stat = d->stat; k.pf_gamma = d->gamma; k.pf_beta = d->beta; k.pf_sshift = d->stat_shift;
+    k.pf_scale = d->scale; k.pf_shift = d->shift; k.pf_mean = d->mean; k.pf_invstd = d->invstd; k.pf_rmean = d->running_mean; k.pf_rvar = d->running_var;
+    k.pf_out = (char*)A->bnf_out;
+  }
   k.H = A->H; k.W = A->W; k.Cin = A->Cin; k.OH = A->OH; k.OW = A->OW; k.KW = A->KW; k.stride = A->stride; k.pad = A->pad;
   k.sshift = A->stride == 2 ? 1 : 0;
   k.M = A->N * A->OH * A->OW; k.OHW = A->OH * A->OW; k.ldy = A->ldy;
@@ -518,6 +588,7 @@ int launch_kind(const tf_conv_args* A, hipStream_t stream, int pcls = -1) {
   size_t lds = (size_t)NS * (BM + BN) * 128;
   const size_t stg = (size_t)BM * (BN + 4) * 4;
   if (stg > lds) lds = stg;
+  if (k.pro) lds += 2048;                            // scale / shift of up to 256 input channels behind the staging tile
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<T, BM, BN, NS, KIND, MMA>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -546,15 +546,23 @@ extern "C" int tf_detnet_forward(int dtype, int training, const float* x, int N,
       c.chk(tf_conv2d(&a, c.stream));
       if (tr && !fused) bn_forward(c, B.ds, c4, b.bd, true, &a, P.partial, (float)Mout, eps, mom);
     }
-    // a2 = relu(bn2(c2))
-    if (fused) {
-      const tf_bn_fwd_desc d = fwd_desc(c, B.c2, b.b2);
-      c.chk(tf_bn_relu_fused(dtype, b.c2, &d, srows, Mout, pl, (float)Mout, eps, mom, b.a2, c.stream));
-    } else if (tr) {
+    // a2 = relu(bn2(c2)): a launch of its own.  Folding it into conv3 (r3, tf_conv_args.bnf: the ring-less pointwise kernel activates its
+    // pixel tile in LDS and writes a2 for the weight gradient; bit-identical, tests/test_gpu_conv.py) removes 33 launches from the
+    // forward chain but LOSES 1.3 % on the step (A/B 1101 vs 1116 img/s): each of the 4-16 channel tiles of a pixel tile repeats the
+    // activation and the table derivation, and the extra barrier per stage sits in a launch that is latency-bound already.
+    // TINYFACES_BNF=1 turns it on (kept for the eval-sized shapes where pixel tiles >> channel tiles).
+    static const bool bnf_on = getenv("TINYFACES_BNF") != nullptr;
+    const bool bnf = fused && bnf_on && dtype != TF_F32 && pl <= 256;
+    tf_bn_fwd_desc d2;
+    if (fused) d2 = fwd_desc(c, B.c2, b.b2);
+    if (fused && !bnf) {
+      c.chk(tf_bn_relu_fused(dtype, b.c2, &d2, srows, Mout, pl, (float)Mout, eps, mom, b.a2, c.stream));
+    } else if (tr && !fused) {
       c.chk(tf_bn_relu(dtype, b.c2, b.b2.scale, b.b2.shift, Mout, pl, b.a2, c.stream));
     }
     // conv3 1x1 (+ BN + residual + ReLU)
-    conv_fill(a, dtype, 0, N, b.Hout, b.Wout, pl, b.Hout, b.Wout, c4, 1, 1, 0, c4, tr ? b.a2 : b.c2, b.w3, tr ? b.c3 : b.y);
+    conv_fill(a, dtype, 0, N, b.Hout, b.Wout, pl, b.Hout, b.Wout, c4, 1, 1, 0, c4, bnf ? b.c2 : (tr ? b.a2 : b.c2), b.w3, tr ? b.c3 : b.y);
+    if (bnf) { a.bnf = &d2; a.bnf_out = b.a2; a.bnf_rows = srows; a.bnf_count = (float)Mout; a.bnf_eps = eps; a.bnf_momentum = mom; }
     if (tr) { a.epi = TF_EPI_STATS; a.stat_out = fused ? b.b3.fst : P.partial; stat_shift(a, c, B.c3, b.b3, fused); }
     else {
       bn_forward(c, B.c3, c4, b.b3, false, nullptr, nullptr, 0, eps, mom);

@@ -55,7 +55,9 @@ class ConvArgs(C.Structure):
                 ("x", vp), ("w", vp), ("y", vp),
                 ("pro_scale", vp), ("pro_shift", vp), ("epi_scale", vp), ("epi_shift", vp),
                 ("aux", vp), ("aux2", vp), ("aux3", vp), ("mask_scale", vp), ("mask_shift", vp),
-                ("stat_out", vp), ("tile", i32), ("stat_shift", vp), ("stat_shift_out", vp), ("alg_k", i32), ("alg_n", i32)]
+                ("stat_out", vp), ("tile", i32), ("stat_shift", vp), ("stat_shift_out", vp),
+                ("bnf", vp), ("bnf_out", vp), ("bnf_rows", i32), ("bnf_count", f32), ("bnf_eps", f32), ("bnf_momentum", f32),
+                ("alg_k", i32), ("alg_n", i32)]
 
 
 class WgradArgs(C.Structure):
