@@ -257,13 +257,10 @@ def bench_eval(model, templates, device, runs=20):       # warm, m
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             count = torch.zeros(1, dtype=torch.int32, device=device)
-            outs = []
-            for s, x in levels:
-                out = model(x)
-                if thr is None:
-                    outs.append(out)
-                    continue
-                ops.decode_compact(out[0], t_d, masks[s][0], masks[s][1], thr, s, dets, count)
+            outs = model.forward_levels([x for _, x in levels])       # the levels side by side on the model's lanes (evaluation._decode_levels)
+            if thr is not None:
+                for (s, x), out in zip(levels, outs):
+                    ops.decode_compact(out[0], t_d, masks[s][0], masks[s][1], thr, s, dets, count)
             if thr is None:        # calibrate the threshold once so that N is a few thousand candidates (random weights)
                 allp = torch.cat([torch.sigmoid(o[0, :25]).flatten() for o in outs])
                 thr = float(torch.quantile(allp[torch.randperm(allp.numel(), device=device)[:1000000]], 0.995))
@@ -276,7 +273,7 @@ def bench_eval(model, templates, device, runs=20):       # warm, m
             n_cand, n_keep = n, res.shape[0]
     ms = float(np.median(times[1:])) * 1e3
     gflop = 1829.4
-    return {"ms_per_image": round(ms, 3), "pyramid": "480x640+960x1280+1920x2560", "candidates": n_cand, "kept": n_keep,
+    return {"ms_per_image": round(ms, 3), "pyramid": "480x640+960x1280+1920x2560", "lanes": max(1, len(model._lanes) + 1), "candidates": n_cand, "kept": n_keep,
             "prob_thresh": round(thr, 5),
             "threshold_note": "calibrated once per run to the 99.5th percentile of the sigmoid scores of the three maps (random weights have no "
                               "WIDER-like sparsity, SURVEY.md 8d); the timed images reuse it",
@@ -355,12 +352,9 @@ def bench_eval_hard(model, templates, device, runs=5):
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 count = torch.zeros(1, dtype=torch.int32, device=device)
-                outs = []
-                for s, x in levels:
-                    out = model(x)
-                    if thr is None:
-                        outs.append(out)
-                    else:
+                outs = model.forward_levels([x for _, x in levels])
+                if thr is not None:
+                    for (s, x), out in zip(levels, outs):
                         ops.decode_compact(out[0], t_d, masks[s][0], masks[s][1], thr, s, dets, count)
                 if thr is None:
                     allp = torch.cat([torch.sigmoid(o[0, :25]).flatten() for o in outs])
@@ -466,7 +460,15 @@ def main():
     torch.manual_seed(0)
     model = tame_init_(DetectionModel(num_objects=1, num_templates=25)).set_compute_dtype(args.dtype)
     if args.eval_only:
-        os.write(json_fd, (json.dumps({"eval": bench_eval(model.to(device), templates, device, runs=10)}) + "\n").encode())
+        if args.layer_table:              # per-shape table of the pyramid's conv launches (HIP events around every launch)
+            _hip.lib().tf_profile_enable(1)
+        t0 = time.perf_counter()
+        ev = bench_eval(model.to(device), templates, device, runs=10)
+        if args.layer_table:
+            _hip.lib().tf_profile_enable(0)
+            _hip.lib().tf_profile_collect((C.c_double * (6 * 24))(), 24)
+            write_layer_table(_hip, args.layer_table, 12, time.perf_counter() - t0)      # 12 images: 10 timed + calibration + warm-up
+        os.write(json_fd, (json.dumps({"eval": ev}) + "\n").encode())
         return
     crit = DetectionCriterion(25, seed=rank, lazy_meters=True)
     eng = TrainEngine(model, crit, lr=1e-4, momentum=0.9, weight_decay=5e-4, device=device)

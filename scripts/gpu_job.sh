@@ -11,6 +11,7 @@
 #   pmc-traffic                FETCH_SIZE / WRITE_SIZE passes over the bench cmd   -> gpurun_out/pmc_bench/traffic.json (scripts/gpu_pmc_bench.sh)
 #   pmc-sq SCRIPT              one SQ counter pass over `python SCRIPT`            -> gpurun_out/pmc/sq_summary.txt
 #   layer-table                bench.py --layer-table (every MFMA launch bracketed)-> gpurun_out/layer_table.{json,md}
+#   eval-table                 the same table for the configs[1] pyramid (per image)-> gpurun_out/eval_layer_table.{json,md}
 #   contention | floor | nms   the round-3 micro-benchmarks (scripts/contention.py, floor.py, nms_bench.py under the tracer)
 #   dist-smoke                 RCCL 1-rank group, 2 gloo ranks on one GPU, 2 nccl ranks on one GPU (expected refusal) -> gpurun_out/dist_smoke.txt
 #   final                      tests + bench + prof + pmc-traffic + layer-table + timeline + eval prof + smoke: the artefacts of a round
@@ -54,6 +55,8 @@ print(d['value'], d['ms_per_step'], 'frac', r.get('frac'), 'fwd', r.get('forward
     f=$(find /tmp/pmc_sq -name "*counter_collection.csv" | head -1); python scripts/pmc_summary.py "$f" "${2:-conv|wgrad}" | tee "$R/gpurun_out/pmc/sq_summary.txt" ;;
   layer-table)
     timeout 300 python bench.py --steps 10 --warmup 4 --no-cpu-baseline --no-eval --no-fp32-path --layer-table "$R/gpurun_out/layer_table.json" > "$R/gpurun_out/bench_layer.json" 2> "$R/gpurun_out/bench_layer.err"; echo "layer-table exit $?"; head -12 "$R/gpurun_out/layer_table.md" ;;
+  eval-table)
+    timeout 300 python bench.py --eval-only --layer-table "$R/gpurun_out/eval_layer_table.json" > "$R/gpurun_out/bench_eval_layer.json" 2> "$R/gpurun_out/bench_eval_layer.err"; echo "eval-table exit $?"; head -40 "$R/gpurun_out/eval_layer_table.md" ;;
   contention) timeout 600 python scripts/contention.py 2>&1 | grep -v amdgpu.ids | tee "$R/gpurun_out/contention.txt" | tail -40 ;;
   floor)
     python scripts/floor.py 2>&1 | grep -v amdgpu.ids | tee "$R/gpurun_out/floor.txt"

@@ -371,6 +371,45 @@ def test_constant_weights_session_is_bit_identical(models, dtype):
             w.data.copy_(old)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_forward_levels_on_lanes_is_bit_identical(models, dtype):
+    """DetectionModel.forward_levels: the pyramid levels of an image side by side on 2-3 HIP streams, each lane with its own workspace
+    and packed weights == the sequential loop bit for bit, for every lane count, twice in one session (second pass: WEIGHTS_READY in
+    every lane), with a level list whose order is not by size; a weight edit between sessions reaches the lanes' packed copies; outside
+    a session / lanes=1 / training mode it IS the sequential loop."""
+    m, _ = models
+    m.set_compute_dtype(dtype).eval()
+    g = torch.Generator().manual_seed(11)
+    xs = [torch.randn(1, 3, h, w, generator=g).cuda() for h, w in [(64, 96), (260, 200), (128, 136), (33, 47), (200, 260)]]
+    try:
+        with torch.no_grad():
+            ref = [m(x).clone() for x in xs]
+            for lanes in (2, 3, 4):
+                with m.constant_weights(reserve=(1, 260, 200)):
+                    for _ in range(2):
+                        got = m.forward_levels(xs, lanes=lanes)
+                        torch.cuda.synchronize()
+                        for a, b in zip(ref, got):
+                            assert torch.equal(a, b), (lanes, float((a - b).abs().max()))
+                assert len(m._lanes) >= lanes - 1
+            got = m.forward_levels(xs)                     # no session: sequential
+            for a, b in zip(ref, got):
+                assert torch.equal(a, b)
+            w = m.score_res3.bias
+            old = w.detach().clone()
+            try:
+                w.data.add_(1.0)
+                with m.constant_weights():
+                    y2 = m.forward_levels(xs, lanes=3)
+                torch.cuda.synchronize()
+                for a, b in zip(ref, y2):
+                    assert float((a - b).abs().max()) > 0.5
+            finally:
+                w.data.copy_(old)
+    finally:
+        m.set_compute_dtype(torch.float32)
+
+
 def test_grad_ready_events_are_recorded_in_backward_order():
     """tf_detnet_set_grad_events (data-parallel overlap): the executor records the caller's events while enqueuing the
     backward pass.  The event of a LATER bucket (lower block index) must not complete before an earlier one, all of them

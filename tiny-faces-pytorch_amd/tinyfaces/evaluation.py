@@ -61,9 +61,11 @@ def _level_capacity(levels, nt):
 
 
 def _decode_levels(model, levels, templates, t_d, rf, prob_thresh, mask_axis, dets, count, device):
-    """Forward + sigmoid / threshold / ordered compaction / refinement of every level, appended to dets[count...]."""
-    for scale, x in levels:
-        out = model(x.to(device, non_blocking=True))                  # (1, 5nt, H', W')
+    """Forward + sigmoid / threshold / ordered compaction / refinement of every level, appended to dets[count...].
+    The forwards of the levels run side by side on the model's lanes (DetectionModel.forward_levels); the decodes follow in level
+    order on the caller's stream, so the candidate list is the sequential loop's row for row."""
+    outs = model.forward_levels([x.to(device, non_blocking=True) for _, x in levels])
+    for (scale, x), out in zip(levels, outs):                         # (1, 5nt, H', W')
         _, _, H, W = out.shape
         vx, vt = ops.template_masks(templates, scale, W, mask_axis)
         ops.decode_compact(out[0], t_d, torch.from_numpy(vx).to(device), torch.from_numpy(vt).to(device),

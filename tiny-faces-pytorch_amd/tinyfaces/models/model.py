@@ -119,6 +119,7 @@ class DetectionModel(nn.Module):
         self._table_key = None
         self._session_depth = 0          # constant_weights() nesting
         self._ready_key = None           # (workspace ptr, dtype, table key) whose packed eval weights sit in the workspace
+        self._lanes = []                 # forward_levels: extra (workspace, HIP stream, ready key) triples beside the model's own
         if isinstance(pretrained_weights, (str, os.PathLike)):           # no network here: a local file only
             sd = torch.load(pretrained_weights, map_location="cpu", weights_only=True)
             sd = sd.get("model", sd)
@@ -170,6 +171,73 @@ class DetectionModel(nn.Module):
             params = [p for p in self._grad_params]
             return _DetNetFunction.apply(x, self, *params)
         return self._run_forward(x, training=self.training)
+
+    def forward_levels(self, xs, lanes=None):
+        """`[self(x) for x in xs]` for the pyramid levels of ONE image (evaluation.py:49-68 runs them one after the other), eval mode only,
+        with the levels spread over `lanes` HIP streams so that they run SIDE BY SIDE: the forward of a 1/4- or 1/16-size level is a chain
+        of ~110 launches of 10-20 us each that fill a fraction of the 256 CUs (M = 1200-4800 pixels at layer 3: latency-bound whatever the
+        kernel), and it hides completely beside the full-size level, which is throughput-bound.  Every lane owns a workspace (its packed
+        weights + its activations: the executor is stateless beyond `ws`), the largest level runs on the caller's stream in the model's
+        own workspace, the rest are dealt to the other lanes by decreasing size; the caller's stream waits for all lanes at the end.
+        The outputs are those of the sequential loop bit for bit (same kernels, same launch geometry; tests/test_gpu_model.py).
+        TINYFACES_EVAL_LANES (default 3) / lanes=1: the sequential loop."""
+        xs = list(xs)
+        n_lanes = int(os.environ.get("TINYFACES_EVAL_LANES", "3")) if lanes is None else int(lanes)
+        if self.training or len(xs) < 2 or n_lanes < 2 or self._session_depth == 0:
+            return [self(x) for x in xs]
+        for x in xs:
+            if not x.is_cuda:
+                raise RuntimeError("DetectionModel.forward_levels: input is on the CPU (no CPU path)")
+        xs = [x.contiguous().float() for x in xs]
+        dev = xs[0].device
+        self._sync_tables(dev)
+        order = sorted(range(len(xs)), key=lambda i: -xs[i].shape[0] * xs[i].shape[2] * xs[i].shape[3])
+        load = [0] * n_lanes
+        lane_of = {}
+        for i in order:                                                   # largest -> lane 0, then always the least loaded lane
+            ln = 0 if not lane_of else min(range(n_lanes), key=lambda k: (load[k], k))
+            lane_of[i] = ln
+            load[ln] += xs[i].shape[0] * xs[i].shape[2] * xs[i].shape[3]
+        while len(self._lanes) < n_lanes - 1:
+            self._lanes.append({"ws": None, "stream": torch.cuda.Stream(device=dev), "ready": None})
+        cur = torch.cuda.current_stream(dev)
+        inputs_ready = cur.record_event()                                 # the level tensors were produced on the caller's stream
+        outs = [None] * len(xs)
+        used = set()
+        big_first = os.environ.get("TINYFACES_EVAL_LANES_ORDER", "big") == "big"
+        for i in (order if big_first else order[::-1]):                   # by decreasing size: the full-size level is enqueued first
+            ln = lane_of[i]
+            if ln == 0:
+                outs[i] = self._run_forward(xs[i], training=False)
+                continue
+            lane = self._lanes[ln - 1]
+            if ln not in used:
+                lane["stream"].wait_event(inputs_ready)
+                used.add(ln)
+            outs[i] = self._run_eval_lane(xs[i], lane)
+        for ln in used:
+            cur.wait_stream(self._lanes[ln - 1]["stream"])
+        return outs
+
+    def _run_eval_lane(self, x, lane):
+        """Eval-mode tf_detnet_forward of one level on a lane's own stream and workspace (forward_levels)."""
+        N, _, H, W = x.shape
+        H3, W3 = C.c_int(), C.c_int()
+        lib().tf_detnet_out_shape(H, W, C.byref(H3), C.byref(W3))
+        nbytes = lib().tf_detnet_workspace_bytes(self.compute_dtype, N, H, W, self.num_out, 0)
+        if lane["ws"] is None or lane["ws"].device != x.device or lane["ws"].numel() < nbytes:
+            lane["ws"] = None
+            lane["ws"] = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        ws = lane["ws"]
+        out = torch.empty(N, self.num_out, H3.value, W3.value, dtype=torch.float32, device=x.device)
+        key = (ws.data_ptr(), self.compute_dtype, self._table_key, self._session_serial)
+        flags = TF_DETNET_WEIGHTS_READY if key == lane["ready"] else 0
+        lane["ready"] = key
+        bn = self.model.bn1
+        with torch.cuda.device(x.device):
+            check(lib().tf_detnet_forward(self.compute_dtype, 0, ptr(x), N, H, W, self.num_out, self._param_ptrs, float(bn.eps), float(bn.momentum),
+                                          ptr(out), ptr(ws), ws.numel(), flags, lane["stream"].cuda_stream), "tf_detnet_forward")
+        return out
 
     # ---- executor plumbing ---------------------------------------------------------------
     def _named_tensors(self):
@@ -265,6 +333,7 @@ class DetectionModel(nn.Module):
             self._workspace(dev, lib().tf_detnet_workspace_bytes(self.compute_dtype, *reserve, self.num_out, 0))
         if self._session_depth == 0:
             self._ready_key = None
+            self._session_serial = getattr(self, "_session_serial", 0) + 1     # the lanes of forward_levels re-pack once per session too
         self._session_depth += 1
         try:
             yield self
