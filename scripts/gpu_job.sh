@@ -31,7 +31,8 @@ trace_cmd() {   # trace_cmd <outdir> <extra rocprof flags> -- <cmd...>   (run fr
 case "$job" in
   tests)
     rm -f "$R/gpurun_out/parity_report.txt"
-    timeout ${TEST_TIMEOUT:-900} python -m pytest tests -q -m gpu -p no:cacheprovider --durations=8 "$@" > "$R/gpurun_out/pytest_gpu.log" 2>&1
+    sel=tests; case "${1:-}" in tests/*) sel=; esac          # explicit test files replace the whole suite
+    timeout ${TEST_TIMEOUT:-900} python -m pytest $sel -q -m gpu -p no:cacheprovider --durations=8 "$@" > "$R/gpurun_out/pytest_gpu.log" 2>&1
     echo "pytest exit $?" | tee -a "$R/gpurun_out/pytest_gpu.log"; tail -12 "$R/gpurun_out/pytest_gpu.log" ;;
   bench)
     timeout ${BENCH_TIMEOUT:-900} python bench.py "$@" > "$R/gpurun_out/bench.json" 2> "$R/gpurun_out/bench.err"
@@ -65,7 +66,7 @@ print(d['value'], d['ms_per_step'], 'frac', r.get('frac'), 'fwd', r.get('forward
   dist-smoke) bash scripts/gpu_dist_smoke.sh ;;
   final)
     bash "$0" tests; cp "$R/gpurun_out/parity_report.txt" "$R/gpurun_out/parity_report_full.txt" 2>/dev/null
-    bash "$0" bench; bash "$0" prof train; bash "$0" pmc-traffic; bash "$0" layer-table; bash "$0" timeline; bash "$0" prof eval
+    bash "$0" bench; bash "$0" prof train; bash "$0" pmc-traffic; bash "$0" layer-table; bash "$0" timeline; bash "$0" prof eval; bash "$0" eval-table
     timeout 200 python __graft_entry__.py smoke 2>&1 | tail -2 ;;
   *) sed -n 2,22p "$0" ;;
 esac

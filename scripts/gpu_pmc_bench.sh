@@ -5,7 +5,7 @@ mkdir -p $GRAFT_REPO_ROOT/gpurun_out/pmc_bench
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmcb_$c
-  timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmcb_$c -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-eval --no-profile > /tmp/pmcb_$c.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmcb_$c -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-eval --no-profile --no-fp32-path > /tmp/pmcb_$c.log 2>&1
   echo "pmc $c exit $?"
   f=$(find /tmp/pmcb_$c -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && cp "$f" /tmp/pmcb_$c.csv

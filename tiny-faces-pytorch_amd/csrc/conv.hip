@@ -375,6 +375,11 @@ int pick_tile(const tf_conv_args* a) {
     // everything else 64x64 with the ring depth chosen by K.  The choice lives HERE so that tf_conv_mtiles agrees with the launch.
     static const bool t12_off = getenv("TINYFACES_T12_SHORTK_OFF") != nullptr;
     const int nst = a->KH * a->KW * (a->Cin / 64);
+    // r3: ... except where the launch is big enough to be throughput-bound: from M = 16 384 pixels on, 64 pixels x 128 channels on
+    // 32x32x16 fragments with a 2-deep ring moves the same bytes faster (1920x2560 pyramid level: 256 -> 1024 at M = 19 200 35.6 -> 30.7 us,
+    // 128 -> 512 at M = 76 800 49.1 -> 40.8 us, 64 -> 256 at M = 307 200 103 -> 95 us; profiles/r03_microbench_eval.txt)
+    static const bool t46_off = getenv("TINYFACES_T46_SHORTK_OFF") != nullptr;
+    if (!t46_off && a->dtype != TF_F32 && nst <= 4 && M >= 16384 && a->Cout % 128 == 0 && a->Cout >= 256) return 46;
     if (!t12_off && a->dtype != TF_F32 && nst <= 4) return 32;
     // 32x32x16 fragments (64 pixels x 128 channels per block, 32 x 64 per wave, 2-deep ring) win where a launch still has several
     // blocks per CU AND a long K loop: 3x3 convs / K >= 576 with M >= 16 384 pixels -- layer 2 at bs = 12 (26.3 vs 32.9 us forward,
