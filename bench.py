@@ -473,6 +473,8 @@ def main():
     crit = DetectionCriterion(25, seed=rank, lazy_meters=True)
     eng = TrainEngine(model, crit, lr=1e-4, momentum=0.9, weight_decay=5e-4, device=device)
 
+    if os.environ.get("TINYFACES_BENCH_SKIP_ALLREDUCE"):      # diagnostic: the process group exists, the steps never use it
+        eng.skip_allreduce = True
     pool = [synthetic_batch(1000 * s + rank, args.batch, device, t_d) for s in range(4)]
 
     raw = None
@@ -484,7 +486,11 @@ def main():
                 random_boxes(np.random.RandomState(50 + k + 100 * rank)) * np.array([1024 / 500, 768 / 500] * 2)) for k in range(args.batch)]
         arng = np.random.RandomState(rank)
 
-    in_stream = torch.cuda.Stream(device=device) if raw is not None else None
+    # --with-augment builds the batch (pixels + targets) on an input stream of its own, like the product loader does
+    # (tinyfaces/datasets/wider_face.py: the collate runs on `_in_stream`, the training stream waits for it).  The resident-input bench
+    # line assigns its targets on the training stream (rounds 1-2); TINYFACES_BENCH_TARGETS_STREAM=1 moves them to an input stream
+    # too (with the host a step ahead they then run beside the previous backward pass: within noise, A/B r3).
+    in_stream = torch.cuda.Stream(device=device) if (raw is not None or os.environ.get("TINYFACES_BENCH_TARGETS_STREAM")) else None
 
     def build_batch(i):
         """Input pipeline of one step on its OWN stream: its small blocking H2D copies (boxes, offsets) then wait for this
@@ -498,7 +504,25 @@ def main():
             cm, rm = ops.dense_overlap_targets(boxes, templates, paste_boxes=pastes, flips=flips, seed=i * world + rank, device=device)
         return x, cm, rm
 
+    # diagnostic: N more streams with a token amount of work per step, forked from / joined to the training stream --
+    # how many HIP streams one process can keep busy before they start sharing hardware queues
+    extra = [torch.cuda.Stream(device=device) for _ in range(int(os.environ.get("TINYFACES_BENCH_EXTRA_STREAMS", "0")))]
+    token = torch.zeros(64, device=device)
+
     def step(i):
+        if extra:
+            cur = torch.cuda.current_stream()
+            for s in extra:
+                s.wait_stream(cur)
+                with torch.cuda.stream(s):
+                    token.add_(1.0)
+            out = step_(i)
+            for s in extra:
+                cur.wait_stream(s)
+            return out
+        return step_(i)
+
+    def step_(i):
         if raw is not None:               # the real input pipeline of a training step, minus the JPEG decode
             x, cm, rm = build_batch(i)
             cur = torch.cuda.current_stream()
@@ -507,7 +531,14 @@ def main():
                 t.record_stream(cur)
             return eng.step(x, cm, rm)
         b = pool[i % len(pool)]
-        cm, rm = ops.dense_overlap_targets_device(b["boxes"], b["offs"], b["total"], t_d, paste_d=b["paste"], seed=i * world + rank)
+        if in_stream is None:
+            cm, rm = ops.dense_overlap_targets_device(b["boxes"], b["offs"], b["total"], t_d, paste_d=b["paste"], seed=i * world + rank)
+            return eng.step(b["x"], cm, rm)
+        with torch.cuda.stream(in_stream):
+            cm, rm = ops.dense_overlap_targets_device(b["boxes"], b["offs"], b["total"], t_d, paste_d=b["paste"], seed=i * world + rank)
+        cur = torch.cuda.current_stream()
+        cur.wait_stream(in_stream)
+        cm.record_stream(cur); rm.record_stream(cur)
         return eng.step(b["x"], cm, rm)
 
     for i in range(args.warmup):

@@ -344,6 +344,12 @@ int tf_detnet_set_dual_stream(int on);
  * installs them around that model's own backward call only (tinyfaces/models/model.py:_run_backward).  BN gamma/beta gradients of a block are written on the caller's stream BEFORE the fork that precedes the
  * event's stream position, so one event covers them too. */
 int tf_detnet_set_grad_events(const int* blocks, void* const* events, int n);
+/* r3: `fn(block, stream, user)` is called from inside tf_detnet_backward, on the calling thread, at every point registered with
+ * tf_detnet_set_grad_events (whose events[k] may now be NULL), with the stream that carries the bucket's gradients: work the callee
+ * enqueues on `stream` (or orders behind it) sees the bucket final.  The data-parallel engine issues the bucket's all-reduce there
+ * (reference: loss.backward() + optimizer.step() of trainer.py:86-87 under DistributedDataParallel-style averaging).  NULL: off. */
+typedef void (*tf_grad_ready_fn)(int block, void* stream, void* user);
+int tf_detnet_set_grad_callback(tf_grad_ready_fn fn, void* user);
 /* grad_flat (optional): when every entry of `grads` lies inside [grad_flat, grad_flat + grad_flat_bytes) the whole
  * range is zeroed with ONE memset instead of one per weight gradient. */
 int tf_detnet_backward(int dtype, const float* x_nchw, int N, int H, int W, int num_out,

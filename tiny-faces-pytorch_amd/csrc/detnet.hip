@@ -436,6 +436,35 @@ extern "C" size_t tf_detnet_param_region_bytes(int dtype, int nout, int training
   return P.param_bytes;
 }
 
+// The executor's second stream (weight gradients of the backward pass; r3: the packing of the layer-3 weights beside the start of the
+// forward pass), one per device, created on first use at the DEFAULT priority.
+// Rounds 1-2 created it at the LOWEST priority ("the weight gradients are off the critical chain"; +0.4 % on the step, A/B r3: 1135.7 vs
+// 1131.6 img/s).  r3 found what that costs as soon as the process has a few more busy queues: with three more streams carrying a token
+// kernel per step -- or with RCCL in the process and its collectives overlapping the backward pass, i.e. the data-parallel path -- the
+// kernels of BOTH queues stretch ~1.6x and the step takes 16.7-17.6 ms instead of 10.6 (profiles/r03_stream_priority.txt; GPU_MAX_HW_QUEUES,
+// creation order and the number of streams of our own made no difference, the priority does).  The round-2 CU-mask experiment
+// (hipExtStreamCreateWithCUMask: 603 img/s whatever the mask) looked the same.  TINYFACES_SIDE_PRIO_LOW=1 brings the low priority back.
+static bool g_force_single = false;      // tf_detnet_set_dual_stream(0): everything on the caller's stream
+namespace {
+hipStream_t side_stream() {               // one per device (a process normally drives one GPU; the binding may load before set_device)
+  static hipStream_t streams[64] = {};
+  static bool tried_dev[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  hipStream_t& g_side = streams[dev];
+  bool& tried = tried_dev[dev];
+  if (tried) return g_side;
+  tried = true;
+  int least = 0, greatest = 0;
+  static const bool low_prio = getenv("TINYFACES_SIDE_PRIO_LOW") != nullptr;      // A/B knob (the default of rounds 1-2)
+  if (!low_prio || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess ||
+      hipStreamCreateWithPriority(&g_side, hipStreamNonBlocking, least) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) != hipSuccess) g_side = nullptr;
+  }
+  return g_side;
+}
+}  // namespace
+
 extern "C" int tf_detnet_forward(int dtype, int training, const float* x, int N, int H, int W, int nout, void* const* params, float eps,
                                  float mom, float* out, void* ws, size_t ws_bytes, int flags, void* stream_) {
   if (!x || !params || !out || !ws || nout <= 0 || nout > kHeadLd) return TF_ERR_ARG;
@@ -464,13 +493,20 @@ extern "C" int tf_detnet_forward(int dtype, int training, const float* x, int N,
   // r3 experiment, NEGATIVE, kept behind TINYFACES_PACK_SIDE=1: the weight re-packing of a training step (three launches, ~170 us: 111 MB
   // of masters read, 2 x 55 MB written) on a second stream BESIDE the stem's im2col (~130 us) -- both are HBM-bound, side by side they
   // take as long as back to back and the fork / join events cost a little: 1153 / 1153 img/s against 1161 / 1159 inline (A/B on one box).
-  static hipStream_t g_pack_stream = nullptr;
+  static hipStream_t g_pack_stream = nullptr;      // = the executor's second stream: idle during the forward pass, no further hardware queue
   static hipEvent_t g_pack_fork = nullptr, g_pack_join = nullptr;
   static const bool pack_side_env = getenv("TINYFACES_PACK_SIDE") != nullptr;
-  bool pack_side = tr && !ready && pack_side_env;
-  if (pack_side && !g_pack_stream) {
-    if (hipStreamCreateWithFlags(&g_pack_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&g_pack_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&g_pack_join, hipEventDisableTiming) != hipSuccess) { g_pack_stream = nullptr; }
+  // r3, second form: only the weights of layer 3 and of the heads (62 % of the bytes) go to the second stream, forked at the top of the step
+  // and joined in front of the first layer-3 bottleneck: they are packed beside the stem and layers 1-2, whose launches are latency-bound
+  // at bs = 12, instead of in front of them.  TINYFACES_PACK_SPLIT_OFF=1: everything inline.
+  static const bool pack_split_off = getenv("TINYFACES_PACK_SPLIT_OFF") != nullptr;
+  static const bool single_env = getenv("TINYFACES_SINGLE_STREAM") != nullptr;
+  const bool pack_split = tr && !ready && !pack_side_env && !pack_split_off && !single_env && !g_force_single;
+  bool pack_side = tr && !ready && (pack_side_env || pack_split);
+  if (pack_side) {
+    g_pack_stream = side_stream();
+    if (g_pack_stream && !g_pack_fork && (hipEventCreateWithFlags(&g_pack_fork, hipEventDisableTiming) != hipSuccess ||
+                                          hipEventCreateWithFlags(&g_pack_join, hipEventDisableTiming) != hipSuccess)) g_pack_stream = nullptr;
   }
   if (!g_pack_stream) pack_side = false;
   if (pack_side) {           // everything enqueued so far (the previous step's SGD: the masters) precedes the packing
@@ -484,6 +520,7 @@ extern "C" int tf_detnet_forward(int dtype, int training, const float* x, int N,
   for (size_t i = 0; i < A.blocks.size(); ++i) {
     const Block& B = A.blocks[i];
     Plan::Blk& b = P.blk[i];
+    if (pack_side && pack_split && (int)i == A.layer_end[1] + 1) c.flush_packs();      // stem + layers 1-2: inline, needed first
     pack2(c, B.c1, B.planes, b.w1, b.w1t); pack2(c, B.c2, B.planes, b.w2, b.w2t); pack2(c, B.c3, B.planes * 4, b.w3, b.w3t);
     if (B.has_ds) pack2(c, B.ds, B.planes * 4, b.wd, b.wdt);
   }
@@ -497,7 +534,8 @@ extern "C" int tf_detnet_forward(int dtype, int training, const float* x, int N,
   }
   c.flush_packs(pack_side ? g_pack_stream : nullptr);
   if (pack_side) {
-    if (hipEventRecord(g_pack_join, g_pack_stream) != hipSuccess || hipStreamWaitEvent(c.stream, g_pack_join, 0) != hipSuccess) c.chk(TF_ERR_LAUNCH);
+    if (hipEventRecord(g_pack_join, g_pack_stream) != hipSuccess) c.chk(TF_ERR_LAUNCH);
+    if (!pack_split && hipStreamWaitEvent(c.stream, g_pack_join, 0) != hipSuccess) c.chk(TF_ERR_LAUNCH);
   }
   }
   conv_fill(a, dtype, 0, 1, 1, M1, kStemK, 1, M1, 64, 1, 1, 0, 64, P.col, P.wstem, P.cstem);
@@ -519,6 +557,7 @@ extern "C" int tf_detnet_forward(int dtype, int training, const float* x, int N,
     Plan::Blk& b = P.blk[i];
     const int pl = B.planes, c4 = pl * 4;
     const int Min = N * b.Hin * b.Win, Mout = N * b.Hout * b.Wout;
+    if (pack_side && pack_split && (int)i == A.layer_end[1] + 1 && hipStreamWaitEvent(c.stream, g_pack_join, 0) != hipSuccess) c.chk(TF_ERR_LAUNCH);
     // conv1 1x1
     conv_fill(a, dtype, 0, N, b.Hin, b.Win, B.cin, b.Hin, b.Win, pl, 1, 1, 0, pl, yin, b.w1, b.c1);
     if (tr) { a.epi = TF_EPI_STATS; a.stat_out = fused ? b.b1.fst : P.partial; stat_shift(a, c, B.c1, b.b1, fused); }
@@ -646,23 +685,30 @@ void wgrad(Ctx& c, const ConvUnit& u, int cout, int N, int H, int W, int OH, int
 
 }  // namespace
 
-static bool g_force_single = false;
 // gradient-ready events (data-parallel overlap): after the weight gradients of bottleneck `block` (backward order: the
 // LAST block of a bucket) are enqueued, the caller's event is recorded on the stream that carries them, so a communication
 // stream can start reducing that bucket while the rest of the backward pass runs.  block -1 = the very end (stem done).
 static std::vector<std::pair<int, hipEvent_t>> g_grad_events;
 extern "C" int tf_detnet_set_grad_events(const int* blocks, void* const* events, int n) {
   g_grad_events.clear();
-  if (n < 0 || (n > 0 && (!blocks || !events))) return TF_ERR_ARG;
-  for (int k = 0; k < n; ++k) {
-    if (!events[k]) return TF_ERR_ARG;
-    g_grad_events.emplace_back(blocks[k], (hipEvent_t)events[k]);
-  }
+  if (n < 0 || (n > 0 && (!blocks || !events))) return TF_ERR_ARG;       // (events[k] itself may be NULL)
+  for (int k = 0; k < n; ++k) g_grad_events.emplace_back(blocks[k], (hipEvent_t)events[k]);      // a NULL event: the callback only
   return TF_OK;
 }
+// r3: ... or the caller's FUNCTION is called at that point with the stream that carries the bucket (tf_detnet_set_grad_callback): whatever it
+// enqueues there -- the bucket's all-reduce -- is stream-ordered behind the bucket's last gradient kernel with no stream of its own in
+// between (the event form needs a communication stream that does nothing but wait for the events).
+static tf_grad_ready_fn g_grad_cb = nullptr;
+static void* g_grad_cb_user = nullptr;
+extern "C" int tf_detnet_set_grad_callback(tf_grad_ready_fn fn, void* user) { g_grad_cb = fn; g_grad_cb_user = user; return TF_OK; }
 static void record_grad_events(int block, hipStream_t s, int& rc) {
+  bool registered = false;
   for (const auto& e : g_grad_events)
-    if (e.first == block && hipEventRecord(e.second, s) != hipSuccess && rc == TF_OK) rc = TF_ERR_LAUNCH;
+    if (e.first == block) {
+      registered = true;
+      if (e.second && hipEventRecord(e.second, s) != hipSuccess && rc == TF_OK) rc = TF_ERR_LAUNCH;
+    }
+  if (registered && g_grad_cb) g_grad_cb(block, (void*)s, g_grad_cb_user);
 }
 // 1 = weight gradients on a second stream (default), 0 = everything on the caller's stream (A/B + race tests)
 extern "C" int tf_detnet_set_dual_stream(int on) { g_force_single = !on; return TF_OK; }
@@ -676,21 +722,10 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
   build_plan(P, ar, dtype, N, H, W, nout, 1);
   if (!ar.ok) return TF_ERR_WORKSPACE;
   Ctx c{dtype, (hipStream_t)stream_, params, grads, TF_OK};   // (grads_zeroed / jobs default-initialised)
-  static hipStream_t g_side = nullptr;
   static std::vector<hipEvent_t> g_events;
   static const bool g_single_env = getenv("TINYFACES_SINGLE_STREAM") != nullptr;
   if (!g_single_env && !g_force_single) {
-    if (!g_side) {
-      // the weight gradients are off the critical chain: lowest priority, so the data-gradient chain's workgroups are placed first
-      int least = 0, greatest = 0;
-      static const bool flat_prio = getenv("TINYFACES_SIDE_PRIO_DEFAULT") != nullptr;      // A/B knob
-      // (A CU mask on this stream -- hipExtStreamCreateWithCUMask, 160-224 of the 256 CUs, to keep CUs free for the data-gradient
-      //  chain -- was measured: 603 img/s instead of 1054 whatever the mask, the masked queue no longer overlaps the other one.)
-      if (flat_prio || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess ||
-          hipStreamCreateWithPriority(&g_side, hipStreamNonBlocking, least) != hipSuccess) {
-        if (hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) != hipSuccess) g_side = nullptr;
-      }
-    }
+    hipStream_t g_side = side_stream();
     c.side = g_side; c.events = &g_events;
   }
   tf_conv_args a;

@@ -124,6 +124,7 @@ _SIGNATURES = {
     "tf_pack_weights_batched": (i32, [i32, vp, i32, vp]),
     "tf_pack_weights_tiled": (i32, [i32, vp, i32, vp]),
     "tf_detnet_set_dual_stream": (i32, [i32]),
+    "tf_detnet_set_grad_callback": (i32, [vp, vp]),
     "tf_probe_tr16": (i32, [vp, vp]),
     "tf_set_stat_rows": (i32, [i32]),
     "tf_get_stat_rows": (i32, []),

@@ -14,6 +14,7 @@ Semantics are those of main.py:67-70 (SGD momentum 0.9, weight decay 5e-4, the 4
 model.py:67-87) and of DetectionCriterion (loss.py).  `trainer.train` (autograd + torch.optim) remains the
 drop-in path; this engine is what bench.py and the bundled main.py use."""
 import ctypes as C
+import os
 
 import torch
 import torch.distributed as dist
@@ -37,7 +38,14 @@ class TrainEngine:
         self.steps = 0
         self.skip_allreduce = False          # measurement knob (bench.py): a step without the exchange, to size what the overlap hides
         self._overlap = None
-        if parallel.is_distributed():
+        # r3 experiment, NEGATIVE, opt-in (TINYFACES_SGD_PER_BUCKET=1): the gradient buckets (and the events the executor records when a
+        # bucket is final) also drive the optimizer -- the SGD update of a bucket on the communication stream as soon as the bucket is
+        # final (after its all-reduce when data-parallel), beside the rest of the backward pass, instead of over all 42.5 M parameters
+        # at the end of the step.  Same numbers bit for bit; 1113-1117 img/s against 1118-1123 at the end (A/B on one box): the update
+        # is HBM-bound (850 MB) and takes from the backward pass what it saves at the tail.
+        import os
+        self.sgd_per_bucket = bool(os.environ.get("TINYFACES_SGD_PER_BUCKET"))
+        if parallel.is_distributed() or self.sgd_per_bucket:
             self._setup_overlap()
 
     # first bottleneck (executor index: layer1 0-2, layer2 3-6, layer3 7-29) of each bucket, in backward order: the coarse
@@ -90,7 +98,36 @@ class TrainEngine:
         # the events belong to this engine's MODEL: DetectionModel._run_backward hands them to the executor for the duration of its
         # own backward call (r3: no process-wide registration any more, several engines per process are fine)
         self.model._grad_events = (blocks, handles, len(ranges))
-        self._overlap = dict(ranges=ranges, events=events, comm=torch.cuda.Stream(device=self.device), keep=(blocks, handles))
+        # r3: the all-reduce of a bucket is issued from INSIDE the backward call (tf_detnet_set_grad_callback), under the stream that
+        # carries the bucket's last gradient kernel; the process group orders its own stream behind that point.  No communication stream
+        # of ours any more (TINYFACES_ALLREDUCE_COMM_STREAM=1 brings the event-waiting stream of rounds 1-2 back).  Checked on one GPU with
+        # a 1-rank RCCL group (TINYFACES_FORCE_DIST=1): 1106 img/s against 1124 without the collectives.
+        self._use_comm_stream = bool(os.environ.get("TINYFACES_ALLREDUCE_COMM_STREAM")) or bool(os.environ.get("TINYFACES_ALLREDUCE_ON_MAIN"))
+        self._works, self._cb_error, self._ext_streams = [], None, {}
+        self._block_range = {r[0]: (r[1], r[2]) for r in ranges}
+        self._cb = C.CFUNCTYPE(None, C.c_int, C.c_void_p, C.c_void_p)(self._on_bucket)
+        self.model._grad_callback = None if self._use_comm_stream else self._cb
+        self._overlap = dict(ranges=ranges, events=events, comm=torch.cuda.Stream(device=self.device) if self._use_comm_stream or self.sgd_per_bucket else None,
+                             keep=(blocks, handles))
+
+    def _on_bucket(self, block, stream_ptr, _user):
+        """Called by the executor while it enqueues the backward pass: bucket `block` is final at the tail of `stream_ptr`."""
+        try:
+            if not (parallel.is_distributed() and not self.skip_allreduce) or self.sgd_per_bucket:
+                return
+            start, end = self._block_range[block]
+            g = self.model._grad_flat_persistent
+            cur = torch.cuda.current_stream(self.device)
+            if (stream_ptr or 0) == cur.cuda_stream:
+                self._works.append(dist.all_reduce(g[start:end], op=dist.ReduceOp.SUM, async_op=True))
+                return
+            ext = self._ext_streams.get(stream_ptr)
+            if ext is None:
+                ext = self._ext_streams[stream_ptr] = torch.cuda.ExternalStream(stream_ptr, device=self.device)
+            with torch.cuda.stream(ext):
+                self._works.append(dist.all_reduce(g[start:end], op=dist.ReduceOp.SUM, async_op=True))
+        except BaseException as e:       # an exception must not unwind through the C frames of the executor
+            self._cb_error = e
 
     def close(self):
         """Detach the gradient-ready events from the model (they are owned by this engine: the executor must not record
@@ -98,6 +135,7 @@ class TrainEngine:
         if self._overlap is not None:
             if getattr(self.model, "_grad_events", None) is not None and self.model._grad_events[0] is self._overlap["keep"][0]:
                 self.model._grad_events = None
+                self.model._grad_callback = None
             self._overlap = None
 
     def __del__(self):
@@ -172,14 +210,36 @@ class TrainEngine:
         """Per bucket: the communication stream waits for the executor's gradient-ready event, then the all-reduce is
         issued from it (RCCL's own stream orders itself after the issuing stream); the compute stream only waits at
         the end.  Without the events (not set up): few large buckets after the whole backward pass."""
-        if self._overlap is not None:
-            ov, works = self._overlap, []
-            for (_, start, end), ev in zip(ov["ranges"], ov["events"]):
-                with torch.cuda.stream(ov["comm"]):
-                    ov["comm"].wait_event(ev)
-                    works.append(dist.all_reduce(gflat[start:end], op=dist.ReduceOp.SUM, async_op=True))
+        if os.environ.get("TINYFACES_ALLREDUCE_ON_MAIN"):      # diagnostic: no communication stream, one synchronous collective per bucket behind the backward pass
+            for (_, start, end) in (self._overlap["ranges"] if self._overlap is not None else [(0, 0, gflat.numel())]):
+                dist.all_reduce(gflat[start:end], op=dist.ReduceOp.SUM)
+            return
+        if self._overlap is not None and not self._use_comm_stream:
+            # the collectives were issued by _on_bucket during the backward call: the training stream waits for them here
+            works, self._works = self._works, []
+            err, self._cb_error = self._cb_error, None
+            if err is not None:
+                raise err
+            if len(works) != len(self._overlap["ranges"]):
+                raise RuntimeError(f"data-parallel step: {len(works)} of {len(self._overlap['ranges'])} gradient buckets were reduced")
             for w in works:
                 w.wait()
+            return
+        if self._overlap is not None:
+            ov, works = self._overlap, []
+            comm, cur = ov["comm"], torch.cuda.current_stream(self.device)
+            sync_ops = not os.environ.get("TINYFACES_ALLREDUCE_ASYNC_OPS")
+            for (_, start, end), ev in zip(ov["ranges"], ov["events"]):
+                with torch.cuda.stream(comm):
+                    comm.wait_event(ev)
+                    # a SYNCHRONOUS collective issued under the communication stream: ProcessGroupNCCL (torch >= 2.8) launches it on the
+                    # current stream, i.e. on `comm` itself, stream-ordered behind the event wait, and the host does not block
+                    w = dist.all_reduce(gflat[start:end], op=dist.ReduceOp.SUM, async_op=not sync_ops)
+                    if w is not None:
+                        works.append(w)
+            for w in works:
+                w.wait()
+            cur.wait_stream(comm)
             return
         works, end = [], gflat.numel()
         while end > 0:
@@ -188,6 +248,28 @@ class TrainEngine:
             end = start
         for w in works:
             w.wait()
+
+    def _bucket_updates(self, gflat, scale, reduce):
+        """Per bucket, on the second stream: wait for the executor's gradient-ready event, all-reduce the bucket (data-parallel), then
+        the SGD update of the bucket's parameters -- every (group ∩ bucket) range with the group's lr multiplier (model.py:67-87); the
+        compute stream waits for that stream once, at the end of the step.  The masters of a bucket are only read again by the NEXT
+        step's weight packing (the backward pass works on the packed copies and has left the bucket's layers when the event fires)."""
+        ov = self._overlap
+        comm, cur = ov["comm"], torch.cuda.current_stream(self.device)
+        works = []
+        for (_, start, end), ev in zip(ov["ranges"], ov["events"]):
+            with torch.cuda.stream(comm):
+                comm.wait_event(ev)
+                works.append(dist.all_reduce(gflat[start:end], op=dist.ReduceOp.SUM, async_op=True) if reduce else None)
+        for (_, start, end), w in zip(ov["ranges"], works):
+            with torch.cuda.stream(comm):
+                if w is not None:
+                    w.wait()                              # the second stream (not the host, with RCCL) waits for this bucket's sum
+                for s, e, mult in self.groups:
+                    a, b = max(s, start), min(e, end)
+                    if mult != 0.0 and b > a:
+                        ops.sgd_step(self.flat_p[a:b], gflat[a:b], self.flat_m[a:b], self.lr * mult, self.momentum, self.weight_decay, scale)
+        cur.wait_stream(comm)
 
     def step(self, x, class_map, regression_map):
         """x (B,3,H,W) f32, class_map (B,nt,h,w) f32 (mined in place), regression_map (B,4nt,h,w) f32: all on the device.
@@ -199,13 +281,18 @@ class TrainEngine:
                                                c.max_neg, c._pos_keep, c._neg_keep, c._next_seed())
         gflat = m._run_backward(x, grad, persistent=True)
         scale = 1.0
-        if parallel.is_distributed() and not self.skip_allreduce:
-            self._allreduce(gflat)
+        reduce = parallel.is_distributed() and not self.skip_allreduce
+        if reduce:
             scale = 1.0 / parallel.world_size()          # average over ranks, folded into the SGD kernel
-        for s, e, mult in self.groups:
-            if mult == 0.0:
-                continue                                  # score4_upsample: lr 0 (model.py:84) -> nothing to do
-            ops.sgd_step(self.flat_p[s:e], gflat[s:e], self.flat_m[s:e], self.lr * mult, self.momentum, self.weight_decay, scale)
+        if self.sgd_per_bucket and self._overlap is not None:
+            self._bucket_updates(gflat, scale, reduce)
+        else:
+            if reduce:
+                self._allreduce(gflat)
+            for s, e, mult in self.groups:
+                if mult == 0.0:
+                    continue                              # score4_upsample: lr 0 (model.py:84) -> nothing to do
+                ops.sgd_step(self.flat_p[s:e], gflat[s:e], self.flat_m[s:e], self.lr * mult, self.momentum, self.weight_decay, scale)
         self.steps += 1
         if hasattr(c, "_pending") and (parallel.rank() == 0 or not parallel.is_distributed()):
             c._pending.append((loss2, x.shape[0]))       # only the logging rank ever flushes the meters

@@ -400,13 +400,18 @@ class DetectionModel(nn.Module):
         # they are handed to the executor for the duration of this model's backward call only, so several models / engines in one
         # process never see each other's events (the executor's registration is a per-call argument in all but the C signature)
         ev = getattr(self, "_grad_events", None)
+        cb = getattr(self, "_grad_callback", None) if ev is not None else None      # ctypes function (block, stream, user), owned by the engine
         with torch.cuda.device(x.device):
             if ev is not None:
                 check(lib().tf_detnet_set_grad_events(ev[0], ev[1], ev[2]), "tf_detnet_set_grad_events")
+            if cb is not None:
+                check(lib().tf_detnet_set_grad_callback(cb, None), "tf_detnet_set_grad_callback")
             try:
                 check(lib().tf_detnet_backward(self.compute_dtype, ptr(x), N, H, W, self.num_out, self._param_ptrs, table, ptr(gout),
                                                ptr(gflat), gflat.numel() * 4, ptr(self._ws), self._ws.numel(), stream()), "tf_detnet_backward")
             finally:
+                if cb is not None:
+                    lib().tf_detnet_set_grad_callback(None, None)
                 if ev is not None:
                     lib().tf_detnet_set_grad_events(None, None, 0)
         self._last_grad_flat = gflat
