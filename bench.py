@@ -506,18 +506,18 @@ def main():
 
     # diagnostic: N more streams with a token amount of work per step, forked from / joined to the training stream --
     # how many HIP streams one process can keep busy before they start sharing hardware queues
-    extra = [torch.cuda.Stream(device=device) for _ in range(int(os.environ.get("TINYFACES_BENCH_EXTRA_STREAMS", "0")))]
+    extra_streams = [torch.cuda.Stream(device=device) for _ in range(int(os.environ.get("TINYFACES_BENCH_EXTRA_STREAMS", "0")))]
     token = torch.zeros(64, device=device)
 
     def step(i):
-        if extra:
+        if extra_streams:
             cur = torch.cuda.current_stream()
-            for s in extra:
+            for s in extra_streams:
                 s.wait_stream(cur)
                 with torch.cuda.stream(s):
                     token.add_(1.0)
             out = step_(i)
-            for s in extra:
+            for s in extra_streams:
                 cur.wait_stream(s)
             return out
         return step_(i)

@@ -13,6 +13,21 @@
     else hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                             \
   } while (0)
 
+// A launch under a kernel-mode tf::ProfScope (profile.h): the dispatch carries the scope's two events when it is sampled; a fork's
+// completion event (TF_LAUNCH_WITH_STOP_EVENT semantics) takes precedence and the scope falls back to a bracket.
+#define TF_LAUNCH_TIMED(kernel, grid, block, lds, stream, ...)                                                            \
+  do {                                                                                                                  \
+    hipEvent_t f__ = tf::take_next_stop_event(), a__ = nullptr, b__ = nullptr;                                          \
+    if (f__) {                                                                                                          \
+      tf::ProfScope::fall_back_to_bracket();                                                                            \
+      hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, nullptr, f__, 0, __VA_ARGS__);                            \
+    } else if (tf::ProfScope::take_launch_events(&a__, &b__)) {                                                         \
+      hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, a__, b__, 0, __VA_ARGS__);                                \
+    } else {                                                                                                            \
+      hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                                \
+    }                                                                                                                   \
+  } while (0)
+
 #define TF_CHECK_LAUNCH()                                  \
   do {                                                     \
     hipError_t e__ = hipGetLastError();                    \

@@ -417,7 +417,7 @@ void launch_var(const HK& k, hipStream_t stream) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3h_kernel<T, TRACE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv3x3h_kernel<T, TRACE>), dim3(k.mtiles * k.ntiles), dim3(NT), TRACE && RING_BYTES + TRACE_BYTES > LDS_BYTES ? RING_BYTES + TRACE_BYTES : LDS_BYTES, stream, k);
+  TF_LAUNCH_TIMED((conv3x3h_kernel<T, TRACE>), dim3(k.mtiles * k.ntiles), dim3(NT), TRACE && RING_BYTES + TRACE_BYTES > LDS_BYTES ? RING_BYTES + TRACE_BYTES : LDS_BYTES, stream, k);
 }
 
 template <typename T>
@@ -439,7 +439,7 @@ int launch(const tf_conv_args* A, hipStream_t stream) {
   if (A->epi & TF_EPI_JOIN) bytes += 2 * M * A->Cout * es;
   if (A->epi & TF_EPI_MASK2) bytes += M * A->Cout * es;
   if (A->epi & TF_EPI_STATS3) bytes += M * A->Cout * es;
-  tf::ProfScope prof(A->dtype == TF_BF16 ? 6 : 7, 2.0 * M * A->Cout * Kt, bytes, stream, (int)M, A->Cout, k.Ktot, 9, A->mode, A->epi);   // 6 = conv3x3h bf16, 7 = f16
+  tf::ProfScope prof(A->dtype == TF_BF16 ? 6 : 7, 2.0 * M * A->Cout * Kt, bytes, stream, (int)M, A->Cout, k.Ktot, 9, A->mode, A->epi, -1.0, true);   // 6 = conv3x3h bf16, 7 = f16
   if (g_trace) launch_var<T, true>(k, stream); else launch_var<T, false>(k, stream);
   return hipGetLastError() == hipSuccess ? TF_OK : TF_ERR_LAUNCH;
 }

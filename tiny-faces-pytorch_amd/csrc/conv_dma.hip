@@ -612,14 +612,15 @@ int launch_kind(const tf_conv_args* A, hipStream_t stream, int pcls = -1) {
     const double alg_fl = pcls >= 0 ? exec_fl : 2.0 * alg_m * alg_n * alg_k;
     if (pcls >= 0) bytes = ((double)A->N * A->H * A->W * A->Cin + (double)A->Cout * Kt) * es / 4 + M * A->Cout * es * (1 + ((A->epi & (TF_EPI_RES | TF_EPI_MASK | TF_EPI_STATS2)) ? 1 : 0));
     tf::ProfScope prof(A->dtype == TF_F32 ? 12 : (A->dtype == TF_BF16 ? 13 : 15), alg_fl, bytes, stream, k.M, A->Cout, k.Ktot,
-                       A->KH * A->KW, A->mode, A->epi, exec_fl);   // 12 = conv_dma f32, 13 = conv_dma bf16, 15 = conv_dma f16
+                       A->KH * A->KW, A->mode, A->epi, exec_fl, true);   // 12 = conv_dma f32, 13 = conv_dma bf16, 15 = conv_dma f16
     if (k.scat == 1) {
+      prof.begin_bracket();                          // the initialisation of the raster is part of this launch's cost
       // the three other parities of the output raster: zero, or the residual operand itself (y = 0 + aux there)
       const size_t ybytes = (size_t)A->N * A->OH * A->OW * A->ldy * sizeof(T);
       const hipError_t e = (A->epi & TF_EPI_RES) ? hipMemcpyAsync(A->y, A->aux, ybytes, hipMemcpyDeviceToDevice, stream) : hipMemsetAsync(A->y, 0, ybytes, stream);
       if (e != hipSuccess) return TF_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL((conv_dma_kernel<T, BM, BN, NS, KIND, MMA>), dim3(mtiles * k.ntiles), dim3(256), lds, stream, k);
+    TF_LAUNCH_TIMED((conv_dma_kernel<T, BM, BN, NS, KIND, MMA>), dim3(mtiles * k.ntiles), dim3(256), lds, stream, k);
   }
   return hipGetLastError() == hipSuccess ? TF_OK : TF_ERR_LAUNCH;
 }

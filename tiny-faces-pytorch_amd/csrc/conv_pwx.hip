@@ -375,8 +375,8 @@ int launch(const tf_conv_args* A, const PK& k, hipStream_t stream) {
   if (A->epi & TF_EPI_MASK2) bytes += M * A->Cout * 2;
   if (A->epi & TF_EPI_STATS3) bytes += M * A->Cout * 2;
   const double alg_k = A->alg_k > 0 ? A->alg_k : Kt, alg_n = A->alg_n > 0 ? A->alg_n : A->Cout;
-  tf::ProfScope prof(17, 2.0 * M * alg_n * alg_k, bytes, stream, k.M, A->Cout, k.K, 1, A->mode, A->epi, 2.0 * M * A->Cout * Kt);   // 17 = conv_pwx bf16
-  TF_LAUNCH_WITH_STOP_EVENT((conv_pwx_kernel<BN, PRO>), dim3(k.mtiles * k.ntiles), dim3(NT), lds, stream, k);     // (a fork of the executor may ride on this launch)
+  tf::ProfScope prof(17, 2.0 * M * alg_n * alg_k, bytes, stream, k.M, A->Cout, k.K, 1, A->mode, A->epi, 2.0 * M * A->Cout * Kt, true);   // 17 = conv_pwx bf16
+  TF_LAUNCH_TIMED((conv_pwx_kernel<BN, PRO>), dim3(k.mtiles * k.ntiles), dim3(NT), lds, stream, k);     // (a fork of the executor may ride on this launch)
   return hipGetLastError() == hipSuccess ? TF_OK : TF_ERR_LAUNCH;
 }
 

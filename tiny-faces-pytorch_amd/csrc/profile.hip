@@ -22,20 +22,42 @@ hipEvent_t get_event() {
 }
 }  // namespace
 
-tf::ProfScope::ProfScope(int kind, double flops, double bytes, hipStream_t s, int M, int N, int K, int taps, int mode, int epi, double exec_flops)
-    : slot(-1), stream(s) {
+namespace { thread_local tf::ProfScope* g_active = nullptr; }
+tf::ProfScope::ProfScope(int kind, double flops, double bytes, hipStream_t s, int M, int N, int K, int taps, int mode, int epi, double exec_flops,
+                         bool kernel_mode)
+    : slot(-1), stream(s), state(0) {
   if (!g_every) return;
+  static const bool force_bracket = getenv("TINYFACES_PROFILE_BRACKET") != nullptr;
   std::lock_guard<std::mutex> lk(g_mu);
   if (g_seq++ % (unsigned long long)g_every) return;
   Rec r{kind, flops, bytes, exec_flops < 0 ? flops : exec_flops, get_event(), get_event(), M, N, K, taps, mode, epi};
-  (void)hipEventRecord(r.a, s);
   g_recs.push_back(r);
   slot = (int)g_recs.size() - 1;
+  if (kernel_mode && !force_bracket && !g_active) { state = 2; g_active = this; }
+  else { (void)hipEventRecord(r.a, s); state = 1; }
 }
+void tf::ProfScope::begin_bracket() {
+  if (state != 2) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  (void)hipEventRecord(g_recs[slot].a, stream);
+  state = 1;
+  if (g_active == this) g_active = nullptr;
+}
+bool tf::ProfScope::take_launch_events(hipEvent_t* a, hipEvent_t* b) {
+  ProfScope* p = g_active;
+  if (!p || p->state != 2) return false;
+  std::lock_guard<std::mutex> lk(g_mu);
+  *a = g_recs[p->slot].a; *b = g_recs[p->slot].b;
+  p->state = 3;
+  g_active = nullptr;
+  return true;
+}
+void tf::ProfScope::fall_back_to_bracket() { if (g_active) g_active->begin_bracket(); }
 tf::ProfScope::~ProfScope() {
   if (slot < 0) return;
   std::lock_guard<std::mutex> lk(g_mu);
-  (void)hipEventRecord(g_recs[slot].b, stream);
+  if (state == 1) (void)hipEventRecord(g_recs[slot].b, stream);
+  else if (state == 2) { g_recs[slot].kind = -1; if (g_active == this) g_active = nullptr; }      // nothing was launched under this scope: dropped at collect
 }
 
 extern "C" int tf_profile_enable(int on) {
@@ -52,9 +74,8 @@ extern "C" int tf_profile_collect(double* host_out, int max_rows) {
   double acc[NK][5] = {};
   g_shapes.clear();
   for (const Rec& r : g_recs) {
-    (void)hipEventSynchronize(r.b);
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess && r.kind >= 0 && r.kind < NK) {
+    if (r.kind >= 0 && r.kind < NK && hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
       acc[r.kind][0] += 1; acc[r.kind][1] += ms; acc[r.kind][2] += r.flops; acc[r.kind][3] += r.bytes; acc[r.kind][4] += r.xflops;
       ShapeAgg* hit = nullptr;
       for (ShapeAgg& q : g_shapes)

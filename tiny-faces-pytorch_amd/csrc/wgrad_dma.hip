@@ -190,10 +190,10 @@ int tf_wgrad_dma_launch(const tf_wgrad_args* A, hipStream_t stream) {
   const double Md = k.M;
   tf::ProfScope prof(14, 2.0 * Md * A->Cout * A->Cin * ntaps,
                      (Md * A->Cout + (double)A->N * A->H * A->W * A->Cin) * 2 + (double)A->Cout * A->Cin * ntaps * 4, stream, k.M, A->Cout,
-                     A->Cin * ntaps, ntaps, 2, 0);
-  if (pointwise) { if (ns == 2) hipLaunchKernelGGL((wgrad_dma_kernel<1, 2>), dim3(tiles * k.splitk), dim3(256), lds, stream, k);
-                   else hipLaunchKernelGGL((wgrad_dma_kernel<1, 3>), dim3(tiles * k.splitk), dim3(256), lds, stream, k); }
-  else           { if (ns == 2) hipLaunchKernelGGL((wgrad_dma_kernel<0, 2>), dim3(tiles * k.splitk), dim3(256), lds, stream, k);
-                   else hipLaunchKernelGGL((wgrad_dma_kernel<0, 3>), dim3(tiles * k.splitk), dim3(256), lds, stream, k); }
+                     A->Cin * ntaps, ntaps, 2, 0, -1.0, true);
+  if (pointwise) { if (ns == 2) TF_LAUNCH_TIMED((wgrad_dma_kernel<1, 2>), dim3(tiles * k.splitk), dim3(256), lds, stream, k);
+                   else TF_LAUNCH_TIMED((wgrad_dma_kernel<1, 3>), dim3(tiles * k.splitk), dim3(256), lds, stream, k); }
+  else           { if (ns == 2) TF_LAUNCH_TIMED((wgrad_dma_kernel<0, 2>), dim3(tiles * k.splitk), dim3(256), lds, stream, k);
+                   else TF_LAUNCH_TIMED((wgrad_dma_kernel<0, 3>), dim3(tiles * k.splitk), dim3(256), lds, stream, k); }
   return hipGetLastError() == hipSuccess ? TF_OK : TF_ERR_LAUNCH;
 }
