@@ -454,3 +454,54 @@ def test_grad_ready_events_are_recorded_in_backward_order():
     worst = max(float((got[k] - p.grad).abs().max() / (p.grad.abs().max() + 1e-30)) for k, p in m.named_parameters() if p.grad is not None)
     report("grad_events", times_ms=[round(t, 3) for t in times], worst_rel=worst)
     assert worst < 1e-3
+
+
+def test_grad_ready_callback_is_called_per_bucket_with_the_carrying_stream():
+    """r3, tf_detnet_set_grad_callback: while it enqueues the backward pass the executor calls the registered function once per registered
+    block, in backward order, with the stream that carries that bucket's gradients -- its second stream for the bottleneck buckets, the
+    caller's stream for the final one (-1) -- and with NULL events (callback-only registration).  Work enqueued by the callee on that stream
+    (here: a snapshot copy of a bucket's gradient slice) sees the bucket final; an exception inside the callback does not unwind through
+    the C frames (the engine stores it: tinyfaces/engine.py:_on_bucket); without registered blocks the callback is never called."""
+    import ctypes as C
+    from tinyfaces import _hip
+    from tinyfaces.models.model import DetectionModel
+    m = DetectionModel(num_templates=25)
+    _load_oracle_weights(m)
+    m = m.cuda().set_compute_dtype(torch.bfloat16).train()
+    x = torch.randn(2, 3, 160, 192, generator=torch.Generator().manual_seed(12)).cuda()
+    m.flatten_parameters()
+    m._sync_tables(x.device)
+    out = m._run_forward(x, training=True)
+    blocks_py = [22, 14, 7, -1]
+    blocks = (C.c_int * 4)(*blocks_py)
+    nulls = (C.c_void_p * 4)(None, None, None, None)
+    calls, snaps = [], {}
+    main = torch.cuda.current_stream().cuda_stream
+    seg = m._segments
+    o22 = min(o for k, (o, _) in seg.items() if k.startswith("model.layer3.22."))
+
+    def cb(block, stream, _user):
+        calls.append((block, stream or 0))
+        if block == 22:                                                   # everything from layer3.22 on (incl. the heads) is final on `stream`
+            with torch.cuda.stream(torch.cuda.ExternalStream(stream)):
+                snaps[22] = m._grad_flat_persistent[o22:].clone()
+
+    fn = C.CFUNCTYPE(None, C.c_int, C.c_void_p, C.c_void_p)(cb)
+    m._grad_events = (blocks, nulls, 4)
+    m._grad_callback = fn
+    try:
+        g = m._run_backward(x, torch.ones_like(out), persistent=True)
+        torch.cuda.synchronize()
+    finally:
+        m._grad_events = None
+        m._grad_callback = None
+    assert [b for b, _ in calls] == blocks_py, calls
+    assert calls[-1][1] == main and all(s != main for _, s in calls[:-1]), (calls, main)
+    assert len({s for _, s in calls[:-1]}) == 1                           # one second stream
+    assert torch.equal(snaps[22], g[o22:])                                # the bucket was final where the callback was told it is
+    # no registration -> no call
+    calls.clear()
+    m._run_forward(x, training=True)
+    m._run_backward(x, torch.ones_like(out), persistent=True)
+    torch.cuda.synchronize()
+    assert calls == []

@@ -6,9 +6,9 @@ no per-parameter Python loop and no host sync:
 
 Data-parallel overlap: the flat gradient is cut along the backward order into buckets of ~`bucket_mb` MB (default 10: heads +
 layer3.21-22 first, then THREE layer-3 bottlenecks of 4.46 MB each per bucket (two stay under 10 MB), ..., finally layer1/2 + stem: SURVEY.md 8e asks for
-8-12 buckets of ~10 MB in layer 3).  The executor records an event when a bucket's gradients are enqueued
-(tf_detnet_set_grad_events); a communication stream waits on it and starts that bucket's all-reduce while the
-remaining bottlenecks are still being differentiated, so only the last, small bucket is exposed.
+8-12 buckets of ~10 MB in layer 3).  When a bucket's gradients are enqueued the executor calls back with the stream that carries
+them (tf_detnet_set_grad_callback, r3; rounds 1-2: an event + a communication stream waiting on it, still available) and that bucket's
+all-reduce is issued there, while the remaining bottlenecks are still being differentiated: only the last, small bucket is exposed.
 
 Semantics are those of main.py:67-70 (SGD momentum 0.9, weight decay 5e-4, the 4 learning-rate groups of
 model.py:67-87) and of DetectionCriterion (loss.py).  `trainer.train` (autograd + torch.optim) remains the
