@@ -98,6 +98,52 @@ def test_engine_bucket_ranges_partition_the_flat_gradient():
     assert all(10 <= x < 16 for x in mb[:-1]) and mb[-1] < 10, mb
 
 
+def test_group_slices_of_the_buckets_tile_every_trained_parameter_once():
+    """TrainEngine.group_slices (r3, per-bucket SGD): cutting every gradient bucket at the parameter-group boundaries (model.py:67-87) gives
+    slices that carry the group's lr multiplier, never overlap, skip the lr-0 upsample group, and together cover exactly the three trained
+    groups -- i.e. the per-bucket update touches every trained element once with the factor the at-the-end update uses."""
+    from tinyfaces.engine import TrainEngine
+    from tinyfaces.models.model import DetectionModel
+    m = DetectionModel(num_templates=25)
+    flat = m.flatten_parameters()
+    groups = m.group_ranges()
+    assert [g[2] for g in groups] == [1.0, 0.1, 1.0, 0.0]
+    ranges = TrainEngine.bucket_ranges(m._segments, flat.numel(), TrainEngine.auto_first_blocks(m._segments, flat.numel(), 10))
+    cover = np.zeros(flat.numel(), dtype=np.int8)
+    mult_of = np.zeros(flat.numel(), dtype=np.float32)
+    for _, start, end in ranges:
+        for a, b, mult in TrainEngine.group_slices(groups, start, end):
+            assert start <= a < b <= end and mult != 0.0
+            cover[a:b] += 1
+            mult_of[a:b] = mult
+    want = np.zeros_like(cover)
+    for s, e, mult in groups:
+        if mult != 0.0:
+            want[s:e] = 1
+            assert np.all(mult_of[s:e] == np.float32(mult))
+    assert np.array_equal(cover, want)
+    assert TrainEngine.group_slices(groups, 0, 0) == [] and TrainEngine.group_slices([(0, 8, 0.0)], 0, 8) == []
+
+
+def test_forward_levels_lane_assignment():
+    """DetectionModel.assign_lanes (r3, evaluation pyramid on several HIP streams): the largest level owns lane 0 (the caller's stream and
+    the model's workspace), the others go, by decreasing size, to the least loaded lane; every level gets exactly one lane; one lane or
+    one level degenerate to the sequential loop."""
+    from tinyfaces.models.model import DetectionModel
+    f = DetectionModel.assign_lanes
+    px = [480 * 640, 960 * 1280, 1920 * 2560]                       # configs[1], in pyramid order (small -> large)
+    order, lane = f(px, 3)
+    assert order == [2, 1, 0] and lane == {2: 0, 1: 1, 0: 2}
+    order, lane = f(px, 2)
+    assert lane == {2: 0, 1: 1, 0: 1}                                # both small levels beside the large one
+    px4 = [120 * 160, 240 * 320, 480 * 640, 960 * 1280]              # the reference's default scales (-2, -1, 0, 1)
+    order, lane = f(px4, 3)
+    assert order == [3, 2, 1, 0] and lane[3] == 0 and lane[2] == 1 and lane[1] == 2 and lane[0] == 2
+    assert sorted(lane) == [0, 1, 2, 3]
+    assert f([5, 5, 5], 3)[0] == [0, 1, 2]                           # ties keep the list order
+    assert f([7], 3) == ([0], {0: 0}) and set(f(px, 1)[1].values()) == {0}
+
+
 def test_wider_annotation_parser_vs_reference_golden(golden, tmp_path):
     """tinyfaces.datasets.wider_face.parse_annotations == the reference's WIDERFace.load (wider_face.py:65-121) on an annotation
     file with an empty image (placeholder line), zero-size boxes, negative numbers and attributes."""

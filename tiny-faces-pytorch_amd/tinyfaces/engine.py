@@ -249,6 +249,17 @@ class TrainEngine:
         for w in works:
             w.wait()
 
+    @staticmethod
+    def group_slices(groups, start, end):
+        """[(a, b, lr multiplier)]: the parts of the flat range [start, end) that belong to a parameter group with a non-zero learning
+        rate (model.py:67-87) -- a gradient bucket may straddle group boundaries (layer 3 | score_res3 | score_res4 | upsample)."""
+        out = []
+        for s, e, mult in groups:
+            a, b = max(s, start), min(e, end)
+            if mult != 0.0 and b > a:
+                out.append((a, b, mult))
+        return out
+
     def _bucket_updates(self, gflat, scale, reduce):
         """Per bucket, on the second stream: wait for the executor's gradient-ready event, all-reduce the bucket (data-parallel), then
         the SGD update of the bucket's parameters -- every (group ∩ bucket) range with the group's lr multiplier (model.py:67-87); the
@@ -265,10 +276,8 @@ class TrainEngine:
             with torch.cuda.stream(comm):
                 if w is not None:
                     w.wait()                              # the second stream (not the host, with RCCL) waits for this bucket's sum
-                for s, e, mult in self.groups:
-                    a, b = max(s, start), min(e, end)
-                    if mult != 0.0 and b > a:
-                        ops.sgd_step(self.flat_p[a:b], gflat[a:b], self.flat_m[a:b], self.lr * mult, self.momentum, self.weight_decay, scale)
+                for a, b, mult in self.group_slices(self.groups, start, end):
+                    ops.sgd_step(self.flat_p[a:b], gflat[a:b], self.flat_m[a:b], self.lr * mult, self.momentum, self.weight_decay, scale)
         cur.wait_stream(comm)
 
     def step(self, x, class_map, regression_map):

@@ -191,13 +191,7 @@ class DetectionModel(nn.Module):
         xs = [x.contiguous().float() for x in xs]
         dev = xs[0].device
         self._sync_tables(dev)
-        order = sorted(range(len(xs)), key=lambda i: -xs[i].shape[0] * xs[i].shape[2] * xs[i].shape[3])
-        load = [0] * n_lanes
-        lane_of = {}
-        for i in order:                                                   # largest -> lane 0, then always the least loaded lane
-            ln = 0 if not lane_of else min(range(n_lanes), key=lambda k: (load[k], k))
-            lane_of[i] = ln
-            load[ln] += xs[i].shape[0] * xs[i].shape[2] * xs[i].shape[3]
+        order, lane_of = self.assign_lanes([x.shape[0] * x.shape[2] * x.shape[3] for x in xs], n_lanes)
         while len(self._lanes) < n_lanes - 1:
             self._lanes.append({"ws": None, "stream": torch.cuda.Stream(device=dev), "ready": None})
         cur = torch.cuda.current_stream(dev)
@@ -218,6 +212,19 @@ class DetectionModel(nn.Module):
         for ln in used:
             cur.wait_stream(self._lanes[ln - 1]["stream"])
         return outs
+
+    @staticmethod
+    def assign_lanes(sizes, n_lanes):
+        """(order, lane_of) for forward_levels: levels by decreasing size (ties: list order); the largest goes to lane 0 -- the caller's
+        stream and the model's own workspace --, every further one to the lane with the least pixels so far (ties: lowest lane)."""
+        order = sorted(range(len(sizes)), key=lambda i: (-sizes[i], i))
+        load = [0] * n_lanes
+        lane_of = {}
+        for i in order:
+            ln = 0 if not lane_of else min(range(n_lanes), key=lambda k: (load[k], k))
+            lane_of[i] = ln
+            load[ln] += sizes[i]
+        return order, lane_of
 
     def _run_eval_lane(self, x, lane):
         """Eval-mode tf_detnet_forward of one level on a lane's own stream and workspace (forward_levels)."""
