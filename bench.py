@@ -185,7 +185,7 @@ ROCPROF_STATS_FILE = os.path.join(ROOT, "profiles", "r03_train_bs12_bf16_kernel_
 
 def rocprof_avg_us(kind):
     """Average TRUE kernel duration (microseconds) of the dominant kernel in the committed `rocprofv3 --kernel-trace --stats` summary of
-    this same command (scripts/gpu_prof.sh, regenerated with the final binary of the round): the cross-check of `avg_launch_us`.  The
+    this same command (`scripts/gpu_job.sh prof train`, regenerated with the final binary of the round): the cross-check of `avg_launch_us`.  The
     HIP-event bracket of bench.py is systematically longer: it spans record -> dispatch -> kernel -> record, i.e. the ~5-6 us
     inter-packet latency of the queue on top of the kernel.  None without a pattern / file; RuntimeError when the file no longer holds
     the kernel (a stale summary must not pass silently)."""
@@ -200,7 +200,7 @@ def rocprof_avg_us(kind):
             if name.startswith(pats):
                 calls += int(r["Calls"]); total += float(r["TotalDurationNs"])
     if not calls:
-        raise RuntimeError(f"{ROCPROF_STATS_FILE} holds no kernel named {pats}: regenerate it (scripts/gpu_prof.sh) with the current binary")
+        raise RuntimeError(f"{ROCPROF_STATS_FILE} holds no kernel named {pats}: regenerate it (scripts/gpu_job.sh prof train) with the current binary")
     return round(total / calls / 1e3, 2)
 
 

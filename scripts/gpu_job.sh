@@ -10,6 +10,9 @@
 #   timeline [ENV=..]          kernel trace of 3 steps -> per-queue timeline       -> gpurun_out/timeline[_tag].txt
 #   pmc-traffic                FETCH_SIZE / WRITE_SIZE passes over the bench cmd   -> gpurun_out/pmc_bench/traffic.json (scripts/gpu_pmc_bench.sh)
 #   pmc-sq SCRIPT              one SQ counter pass over `python SCRIPT`            -> gpurun_out/pmc/sq_summary.txt
+#   pmc-all SCRIPT             SQ + FETCH_SIZE + WRITE_SIZE passes over `python SCRIPT` (TAG names the files) -> gpurun_out/pmc/<TAG>_{sq,fetch,write}.csv
+#   ubench SCRIPT [args]       a micro-benchmark under the kernel tracer: TRUE kernel durations (TAG, PAT=kernel-name regex) -> gpurun_out/ub/<TAG>.txt
+#   eval-lanes                 A/B of the evaluation pyramid over lane count / enqueue order -> gpurun_out/eval_lanes.txt
 #   layer-table                bench.py --layer-table (every MFMA launch bracketed)-> gpurun_out/layer_table.{json,md}
 #   eval-table                 the same table for the configs[1] pyramid (per image)-> gpurun_out/eval_layer_table.{json,md}
 #   contention | floor | nms   the round-3 micro-benchmarks (scripts/contention.py, floor.py, nms_bench.py under the tracer)
@@ -54,6 +57,24 @@ print(d['value'], d['ms_per_step'], 'frac', r.get('frac'), 'fwd', r.get('forward
     mkdir -p "$R/gpurun_out/pmc"
     ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/pmc_sq && timeout 200 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d /tmp/pmc_sq -o p -- python $R/$1 > /tmp/pmc_sq.log 2>&1 ); echo "pmc exit $?"
     f=$(find /tmp/pmc_sq -name "*counter_collection.csv" | head -1); python scripts/pmc_summary.py "$f" "${2:-conv|wgrad}" | tee "$R/gpurun_out/pmc/sq_summary.txt" ;;
+  pmc-all)
+    mkdir -p "$R/gpurun_out/pmc"; tag=${TAG:-pmc}
+    for pass in "sq SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "fetch FETCH_SIZE" "write WRITE_SIZE"; do
+      set -- $pass; n=$1; shift       # separate passes, --kernel-trace only (MI355X_MICROARCH.md; gpurun refuses --pmc beside the sys / hip traces)
+      ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/pmc_$n && timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d /tmp/pmc_$n -o p -- python $R/${SCRIPT:?SCRIPT=scripts/...} > /tmp/pmc_$n.log 2>&1 ); echo "pmc $n exit $?"
+      f=$(find /tmp/pmc_$n -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp "$f" "$R/gpurun_out/pmc/${tag}_$n.csv"
+    done ;;
+  ubench)
+    mkdir -p "$R/gpurun_out/ub"; tag=${TAG:-ub}
+    ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/ub_$tag && timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/ub_$tag -o ub -- python $R/"$@" > "$R/gpurun_out/ub/$tag.log" 2>&1 )
+    f=$(find /tmp/ub_$tag -name "*kernel_trace.csv" | head -1); python scripts/trace_summary.py "$f" "${PAT:-conv_dma|wgrad}" | tee "$R/gpurun_out/ub/$tag.txt" ;;
+  eval-lanes)
+    out="$R/gpurun_out/eval_lanes.txt"; : > "$out"
+    for rep in 1 2 3; do for cfg in "1 big" "2 big" "3 big" "2 small" "3 small"; do
+      set -- $cfg
+      ms=$(TINYFACES_EVAL_LANES=$1 TINYFACES_EVAL_LANES_ORDER=$2 python bench.py --eval-only 2>/dev/null | python -c "import json,sys; print(json.loads(sys.stdin.readline())['eval']['ms_per_image'])")
+      echo "[$rep] lanes=$1 order=$2 -> $ms ms/image" | tee -a "$out"
+    done; done ;;
   layer-table)
     timeout 300 python bench.py --steps 10 --warmup 4 --no-cpu-baseline --no-eval --no-fp32-path --layer-table "$R/gpurun_out/layer_table.json" > "$R/gpurun_out/bench_layer.json" 2> "$R/gpurun_out/bench_layer.err"; echo "layer-table exit $?"; head -12 "$R/gpurun_out/layer_table.md" ;;
   eval-table)

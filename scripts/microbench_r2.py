@@ -1,5 +1,5 @@
 """Round-2 micro-benchmark of the conv tiles on the real layer shapes (bs=12, 500x500), meant to run under
-`rocprofv3 --kernel-trace` (scripts/gpu_ubench_trace.sh): TRUE kernel durations come from the trace, the printed event
+`rocprofv3 --kernel-trace` (`scripts/gpu_job.sh ubench scripts/microbench_r2.py`): TRUE kernel durations come from the trace, the printed event
 timings include the Python launch path.  Every variant is also checked against the 64x64 reference tile (max abs difference)."""
 import os, sys
 import torch

@@ -1,5 +1,5 @@
 """3x3 weight gradients on the real layer shapes: the per-tap LDS-DMA kernel (tile 1) vs the all-taps kernel (tile 3), several
-split-K factors.  Run under rocprofv3 --kernel-trace for true durations (scripts/gpu_ubench_trace.sh)."""
+split-K factors.  Run under rocprofv3 --kernel-trace for true durations (`scripts/gpu_job.sh ubench scripts/microbench_wgrad3.py`)."""
 import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,5 +1,5 @@
 """A handful of launches of the conv tile candidates and the 3x3 weight-gradient kernels on the layer-3 / layer-2 shapes (bs=12,
-500x500) for rocprofv3 --pmc passes (scripts/gpu_pmc.sh, SCRIPT=scripts/pmc_kernels_r2.py)."""
+500x500) for rocprofv3 --pmc passes (`SCRIPT=scripts/pmc_kernels_r2.py scripts/gpu_job.sh pmc-all`)."""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tiny-faces-pytorch_amd")]

@@ -1,4 +1,4 @@
-"""Critical-path view of ONE training step from a rocprofv3 kernel trace (scripts/gpu_trace.sh): per queue busy time, idle gaps,
+"""Critical-path view of ONE training step from a rocprofv3 kernel trace (`scripts/gpu_job.sh timeline`): per queue busy time, idle gaps,
 overlap between the two streams, and the phases of the step (forward / backward chain / tail)."""
 import csv, re, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
