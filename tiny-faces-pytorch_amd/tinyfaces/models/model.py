@@ -407,7 +407,9 @@ class DetectionModel(nn.Module):
         # they are handed to the executor for the duration of this model's backward call only, so several models / engines in one
         # process never see each other's events (the executor's registration is a per-call argument in all but the C signature)
         ev = getattr(self, "_grad_events", None)
-        cb = getattr(self, "_grad_callback", None) if ev is not None else None      # ctypes function (block, stream, user), owned by the engine
+        # ctypes function (block, stream, user), owned by the engine; it reduces slices of the PERSISTENT flat buffer, so the autograd path
+        # (fresh buffer per call; trainer.train reduces behind the backward pass, parallel.GradientReducer) never installs it
+        cb = getattr(self, "_grad_callback", None) if (ev is not None and persistent) else None
         with torch.cuda.device(x.device):
             if ev is not None:
                 check(lib().tf_detnet_set_grad_events(ev[0], ev[1], ev[2]), "tf_detnet_set_grad_events")
