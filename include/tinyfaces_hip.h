@@ -235,6 +235,14 @@ typedef struct tf_wgrad_args {
 } tf_wgrad_args;
 int tf_conv2d_wgrad(const tf_wgrad_args* a, void* stream);
 size_t tf_wgrad_workspace_bytes(const tf_wgrad_args* a);   /* 0 when the all-taps kernel does not apply to `a` */
+/* r4: the weight gradients of a GROUP of convolutions in ONE launch, every output tile reduced over ALL pixels inside its block: no
+ * split-K, no atomics, no partial-tile workspace -- dw_oihw of every problem is OVERWRITTEN (plain stores), the caller need not zero it.
+ * Replaces the autograd weight gradients (tinyfaces/trainer.py:86) of the 22 identity Bottlenecks of layer 3, whose shapes are identical:
+ * one such gradient alone has 16 output tiles for 256 CUs; a group of eight bottlenecks has 256.
+ *   all problems 1x1 / stride 1 / pad 0 (any channel counts, ONE pixel count N*OH*OW), n <= 48: 128 x 128 tiles (csrc/wgrad_group.hip);
+ *   all problems the SAME 3x3 / stride 1 / pad 1 shape, n <= 24: the all-taps kernel with splitk = 1 (csrc/wgrad3x3.hip).
+ * bf16, no prologue.  TF_ERR_UNSUPPORTED: nothing was launched, call tf_conv2d_wgrad per problem (into zeroed gradients). */
+int tf_conv2d_wgrad_group(const tf_wgrad_args* problems, int n, void* stream);
 /* [Cout][taps][Cin] fp32 -> OIHW fp32 (overwrites) */
 int tf_unpack_dw(const float* packed, int Cout, int Cin, int taps, float* dw_oihw, void* stream);
 
@@ -384,7 +392,8 @@ int tf_image_prepare(const tf_image_prepare_args* a, void* stream);
  * forward convolution the launch belongs to, unpadded channels: a stride-2 data gradient counts the
  * forward conv's MACs, not the zero-inserted gather it executes), algorithmic bytes, EXECUTED flops
  * (2*M*N*K of the GEMM the kernel ran, padding and zero taps included).  kind 0..5 = conv_igemm (dtype*3 + tile-1), 8..11 = wgrad (8 + dtype*2 + (tile==128)),
- * 12/13/15 = conv_dma f32/bf16/f16, 14 = wgrad_dma bf16, 6/7 = conv3x3h bf16/f16, 16 = wgrad3x3 bf16 (both launches of its two-phase form). */
+ * 12/13/15 = conv_dma f32/bf16/f16, 14 = wgrad_dma bf16, 6/7 = conv3x3h bf16/f16, 16 = wgrad3x3 bf16 (both launches of its two-phase form), 17 = conv_pwx,
+ * 18 / 19 = the grouped pointwise / 3x3 weight gradients (tf_conv2d_wgrad_group: flops and bytes of the whole group). */
 int tf_profile_enable(int every);   /* 0 = off, 1 = bracket every launch, n = every n-th launch (sampling keeps the timed region undisturbed) */
 int tf_profile_collect(double* host_out, int max_rows);
 /* per layer shape, for the records consumed by the LAST tf_profile_collect: rows of 12 doubles

@@ -771,6 +771,98 @@ def test_wgrad3x3_all_taps(case, splitk):
     assert d[2] < 2e-3 and dp[2] < 2e-3 and do[2] < 1e-4 and d2[2] < 2e-3
 
 
+PWG_CASES = [
+    # N, H, W, [(Cin, Cout, ldx, lddy)]
+    (2, 9, 7, [(128, 128, 128, 128), (256, 128, 256, 128)]),                          # M = 126: a ragged last stage, several k-steps
+    (1, 5, 5, [(64, 192, 64, 192), (320, 64, 320, 64), (40, 24, 40, 24)]),           # channel counts that are no multiple of the 128 tile
+    (3, 11, 13, [(125, 512, 128, 512), (512, 125, 512, 128)]),                        # padded leading dimensions (the head shape)
+    (1, 32, 33, [(1024, 256, 1024, 256), (256, 1024, 256, 1024)] * 2),               # the layer-3 pair, M = 1056
+]
+
+
+@pytest.mark.parametrize("case", PWG_CASES)
+def test_wgrad_group_pointwise(case):
+    """tf_conv2d_wgrad_group, pointwise form (csrc/wgrad_group.hip): every 128 x 128 tile reduced over all pixels in-block, dW OVERWRITTEN
+    (the outputs start as NaN), vs an fp32 matmul of the same bf16-rounded operands."""
+    from tinyfaces import ops
+    dtype = torch.bfloat16
+    N, H, W, probs = case
+    g = _g(len(probs) * 131 + H)
+    M = N * H * W
+    ins, refs = [], []
+    for Cin, Cout, ldx, lddy in probs:
+        x = torch.zeros(M, ldx); dy = torch.zeros(M, lddy)
+        x[:, :Cin] = torch.randn(M, Cin, generator=g); dy[:, :Cout] = torch.randn(M, Cout, generator=g)
+        if ldx > Cin: x[:, Cin:] = 7.0                       # pad columns hold garbage: must not leak into dW
+        if lddy > Cout: dy[:, Cout:] = -3.0
+        refs.append(q(dy[:, :Cout], dtype).double().t() @ q(x[:, :Cin], dtype).double())
+        ins.append((x.view(N, H, W, ldx).to("cuda", dtype), dy.view(N, H, W, lddy).to("cuda", dtype), Cin, Cout))
+    outs = ops.conv2d_wgrad_group(ins, 1, 0)
+    worst = 0.0
+    for dw, ref in zip(outs, refs):
+        assert torch.isfinite(dw).all()
+        worst = max(worst, err(dw.cpu().reshape(ref.shape), ref)[2])
+    report(f"wgrad_group_pw[{N}x{H}x{W},{len(probs)}]", rel=worst)
+    assert worst < 1e-4                                      # fp32 accumulation of exact bf16 products: order only
+
+
+def test_wgrad_group_pointwise_layer3_full_k():
+    """The real shape: M = 12 288 pixels (384 stages per tile), three problems of each kind -- and the same gradients from the split-K
+    kernel it replaces."""
+    from tinyfaces import ops
+    dtype = torch.bfloat16
+    g = _g(77)
+    N, H, W = 12, 32, 32
+    ins, refs = [], []
+    for Cin, Cout in [(1024, 256), (256, 1024)] * 3:
+        x = torch.randn(N * H * W, Cin, generator=g); dy = torch.randn(N * H * W, Cout, generator=g) * 0.1
+        refs.append(q(dy, dtype).double().t() @ q(x, dtype).double())
+        ins.append((x.view(N, H, W, Cin).to("cuda", dtype), dy.view(N, H, W, Cout).to("cuda", dtype), Cin, Cout))
+    outs = ops.conv2d_wgrad_group(ins, 1, 0)
+    worst = max(err(dw.cpu().reshape(ref.shape), ref)[2] for dw, ref in zip(outs, refs))
+    old = ops.conv2d_wgrad(ins[0][0], ins[0][1], 1024, 256, 1, 1, 1, 0)
+    vs_old = err(outs[0].cpu(), old.cpu())[2]
+    report("wgrad_group_pw[layer3]", rel=worst, vs_splitk=vs_old)
+    assert worst < 1e-4 and vs_old < 1e-4
+
+
+@pytest.mark.parametrize("case", [(2, 9, 11, 64, 64, 3), (12, 32, 32, 256, 256, 2), (1, 30, 17, 128, 192, 4)])
+def test_wgrad_group_3x3(case):
+    """tf_conv2d_wgrad_group, 3x3 form: n problems of one shape through the all-taps kernel with splitk = 1 and plain stores, vs torch
+    autograd and vs the single-problem kernel."""
+    from tinyfaces import ops
+    dtype = torch.bfloat16
+    N, H, W, Cin, Cout, n = case
+    g = _g(sum(case))
+    ins, refs = [], []
+    for _ in range(n):
+        x = torch.randn(N, Cin, H, W, generator=g)
+        w = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05).requires_grad_(True)
+        y = F.conv2d(q(x, dtype), w, padding=1)
+        gy = torch.randn(y.shape, generator=g)
+        y.backward(q(gy, dtype))
+        refs.append(w.grad)
+        ins.append((to_nhwc(x, dtype), to_nhwc(gy, dtype), Cin, Cout))
+    outs = ops.conv2d_wgrad_group(ins, 3, 1)
+    worst = max(err(dw.cpu(), ref)[2] for dw, ref in zip(outs, refs))
+    single = ops.conv2d_wgrad(ins[-1][0], ins[-1][1], Cin, Cout, 3, 3, 1, 1, tile=3, splitk=1)
+    vs_single = err(outs[-1].cpu(), single.cpu())[2]
+    report(f"wgrad_group_3x3[{case}]", rel=worst, vs_single=vs_single)
+    assert worst < 2e-3 and vs_single < 1e-6
+
+
+def test_wgrad_group_refuses_mixed_or_foreign_problems():
+    from tinyfaces import ops
+    x = torch.randn(1, 8, 8, 64, device="cuda").to(torch.bfloat16)
+    with pytest.raises(RuntimeError):                       # fp32 operands: the grouped kernels are bf16 only
+        ops.conv2d_wgrad_group([(x.float(), x.float(), 64, 64)], 1, 0)
+    x2 = torch.randn(1, 9, 8, 64, device="cuda").to(torch.bfloat16)
+    with pytest.raises(RuntimeError):                       # two pixel counts in one pointwise group
+        ops.conv2d_wgrad_group([(x, x, 64, 64), (x2, x2, 64, 64)], 1, 0)
+    with pytest.raises(RuntimeError):                       # two shapes in one 3x3 group
+        ops.conv2d_wgrad_group([(x, x, 64, 64), (x2, x2, 64, 64)], 3, 1)
+
+
 def test_wgrad3x3_refuses_what_it_cannot_do():
     from tinyfaces import ops
     x = torch.randn(1, 9, 9, 64, device="cuda").to(torch.bfloat16)

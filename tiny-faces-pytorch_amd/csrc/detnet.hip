@@ -50,6 +50,7 @@ int tf_upsample_add_crop(int, const void*, const void*, const float*, int, int, 
 int tf_upsample_add_crop_bwd(int, const float*, const float*, int, int, int, int, int, int, int, void*, void*, void*);
 int tf_reduce_partials(const float*, int, int, int, int, int, float*, int, void*);
 int tf_conv2d_bnbwd(const tf_conv_args*, const tf_bn_bwd_desc*, const void*, void*, int, float, void*);
+int tf_conv2d_wgrad_group(const tf_wgrad_args*, int, void*);
 }
 
 namespace {
@@ -119,6 +120,15 @@ const Arch& arch() {
   return a;
 }
 
+// r4: the weight gradients of the identity bottlenecks of layer 3 (22 blocks of identical shape) are differentiated in GROUPS of up to
+// this many bottlenecks per launch (tf_conv2d_wgrad_group: full-K tiles, no split-K / atomics / partial tiles); their dY operands then
+// live in per-block buffers instead of the two parity sets.  TINYFACES_WGRAD_GROUP=0: the per-block launches of rounds 1-3.
+inline int wgrad_group_size() {
+  static const int g = [] { const char* e = getenv("TINYFACES_WGRAD_GROUP"); const int v = e ? atoi(e) : 8; return v < 0 ? 0 : (v > 22 ? 22 : v); }();
+  return g;
+}
+inline bool wgrad_group_mode(int dtype, int training) { return training && dtype == TF_BF16 && wgrad_group_size() > 0; }
+
 inline int down2(int n) { return (n - 1) / 2 + 1; }   // every stride-2 stage of the trunk: ceil(n/2)
 inline size_t esize(int dtype) { return dtype == TF_F32 ? 4 : 2; }
 inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -156,6 +166,7 @@ struct Plan {                    // everything a forward carves; backward re-der
     void *a1, *a2;                   // relu(bn1(c1)), relu(bn2(c2)) materialised in training (operands of conv2/conv3 and of their weight gradients)
     void *w1, *w2, *w3, *wd;         // packed forward weights
     void *w1t, *w2t, *w3t, *wdt;     // packed data-gradient (transposed) weights, training only
+    void *gT1, *gT2, *gU1;           // r4, grouped weight gradients: this block's own g_c3 / g_c2 / g_c1 (alive until its group's launch)
     BnBuf b1, b2, b3, bd;
   };
   std::vector<Blk> blk;
@@ -246,6 +257,10 @@ void build_plan(Plan& P, Arena& ar, int dtype, int N, int H, int W, int nout, in
     b.c3 = training ? ar.get(Mout * c4 * es) : nullptr;
     b.d = B.has_ds ? ar.get(Mout * c4 * es) : nullptr;
     b.y = ar.get(Mout * c4 * es);
+    b.gT1 = b.gT2 = b.gU1 = nullptr;
+    if (wgrad_group_mode(dtype, training) && (int)i > A.layer_end[1] && !B.has_ds) {
+      b.gT1 = ar.get(Mout * c4 * es); b.gT2 = ar.get(Mout * pl * es); b.gU1 = ar.get(Min * pl * es);
+    }
     part(Min, pl); part(Mout, c4);
     if (Min * (size_t)B.cin * es > max_act) max_act = Min * B.cin * es;
     if (Mout * c4 * es > max_act) max_act = Mout * c4 * es;
@@ -649,17 +664,24 @@ void bn_backward_coefs(Ctx& c, const ConvUnit& u, int C, BnBuf& b, const float* 
                            b.cD, clear, c.stream));
 }
 
-void wgrad(Ctx& c, const ConvUnit& u, int cout, int N, int H, int W, int OH, int OW, const void* x, int ldx, const void* dy, int lddy,
-           const BnBuf* pro, int cin_override = 0, int k_override = 0, int dw_ld = 0, float* packed_scratch = nullptr, size_t scratch_floats = 0) {
-  // timing-ablation knob (RESULTS INVALID): the step without any weight gradient = what the data-gradient chain costs when it owns the GPU
-  static const bool skip = [] { const bool s = getenv("TINYFACES_DBG_SKIP_WGRAD") != nullptr; if (s) fprintf(stderr, "tinyfaces: TINYFACES_DBG_SKIP_WGRAD -- weight gradients NOT computed, timing only\n"); return s; }();
-  if (skip) return;
+tf_wgrad_args wgrad_args(const Ctx& c, const ConvUnit& u, int cout, int N, int H, int W, int OH, int OW, const void* x, int ldx, const void* dy,
+                         int lddy, int cin_override = 0, int k_override = 0, int dw_ld = 0) {
   tf_wgrad_args w;
   memset(&w, 0, sizeof(w));
   const int cin = cin_override ? cin_override : u.cin, k = k_override ? k_override : u.k;
   w.dtype = c.dtype; w.N = N; w.H = H; w.W = W; w.Cin = cin; w.OH = OH; w.OW = OW; w.Cout = cout; w.KH = k; w.KW = k;
   w.stride = u.stride; w.pad = u.pad; w.ldx = ldx; w.lddy = lddy; w.x = x; w.dy = dy; w.dw_oihw = c.G(u.w);
   w.dw_ld = dw_ld ? dw_ld : cin * k * k;
+  return w;
+}
+
+void wgrad(Ctx& c, const ConvUnit& u, int cout, int N, int H, int W, int OH, int OW, const void* x, int ldx, const void* dy, int lddy,
+           const BnBuf* pro, int cin_override = 0, int k_override = 0, int dw_ld = 0, float* packed_scratch = nullptr, size_t scratch_floats = 0) {
+  // timing-ablation knob (RESULTS INVALID): the step without any weight gradient = what the data-gradient chain costs when it owns the GPU
+  static const bool skip = [] { const bool s = getenv("TINYFACES_DBG_SKIP_WGRAD") != nullptr; if (s) fprintf(stderr, "tinyfaces: TINYFACES_DBG_SKIP_WGRAD -- weight gradients NOT computed, timing only\n"); return s; }();
+  if (skip) return;
+  const int cin = cin_override ? cin_override : u.cin, k = k_override ? k_override : u.k;
+  tf_wgrad_args w = wgrad_args(c, u, cout, N, H, W, OH, OW, x, ldx, dy, lddy, cin_override, k_override, dw_ld);
   if (pro) { w.pro_scale = pro->scale; w.pro_shift = pro->shift; w.pro_relu = 1; }
   if (k > 1 && packed_scratch && c.grads_zeroed) {
     // 3x3 / stride 1: the all-taps kernel sums its split-K slices through the scratch straight into the (already zeroed) OIHW
@@ -787,6 +809,37 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
   // later and overlap the next bottleneck instead, far from the end of the pass (layer 1 / 2 and the stem keep one fork per
   // gradient so that the tail of the weight-gradient stream stays short).  TINYFACES_L3_FORK_PER_WGRAD=1: the old schedule.
   static const bool l3_single_fork = getenv("TINYFACES_L3_FORK_PER_WGRAD") == nullptr;
+  // r4: GROUPED weight gradients of the identity bottlenecks of layer 3.  Their three gradients are not launched
+  // per block any more: the block's dY operands go to buffers of its own (Plan::Blk::gT1 / gT2 / gU1), the problems are queued, and when
+  // a group is complete -- behind the BN1-backward apply of its LAST (lowest) block, the kernel that produces the group's last operand --
+  // ONE fork hands the second stream two launches (tf_conv2d_wgrad_group): the 2 x n pointwise problems (128 x 128 tiles, each reduced
+  // over all 12 288 pixels in-block) and the n 3x3 problems (all-taps kernel, splitk = 1).  No split-K, no atomics, no partial tiles, no
+  // reduce kernel, 3 forks instead of 22 for these blocks; the gradient-ready events of the group's blocks fire behind the group.
+  const bool group_on = wgrad_group_mode(dtype, 1) && fused;
+  const int first_id = A.layer_end[1] + 2, last_id = A.layer_end[2];           // the identity bottlenecks of layer 3: blocks 8 .. 29
+  std::vector<int> group_close;                                                 // block index that closes each group (descending)
+  if (group_on) {
+    const int nid = last_id - first_id + 1, gs = wgrad_group_size(), ng = (nid + gs - 1) / gs;
+    for (int g = 1; g <= ng; ++g) group_close.push_back(last_id + 1 - (int)(((long long)nid * g + ng - 1) / ng));      // balanced: 8 + 7 + 7
+  }
+  std::vector<tf_wgrad_args> pend_pw, pend_c3;
+  std::vector<int> pend_blocks;
+  auto flush_group = [&]() {
+    if (pend_blocks.empty()) return;
+    static const bool skip = getenv("TINYFACES_DBG_SKIP_WGRAD") != nullptr;
+    if (!skip) {
+      // the 3x3 group first: 16 tiles per problem = half a machine for a group of eight; the pointwise launch behind it fills the CUs its
+      // tail leaves (both are enqueued behind the same fork)
+      int rc = tf_conv2d_wgrad_group(pend_c3.data(), (int)pend_c3.size(), c.wstream());
+      if (rc == TF_ERR_UNSUPPORTED) for (const tf_wgrad_args& w : pend_c3) c.chk(tf_conv2d_wgrad(&w, c.wstream()));      // (atomics into the zeroed gradient)
+      else c.chk(rc);
+      rc = tf_conv2d_wgrad_group(pend_pw.data(), (int)pend_pw.size(), c.wstream());
+      if (rc == TF_ERR_UNSUPPORTED) for (const tf_wgrad_args& w : pend_pw) c.chk(tf_conv2d_wgrad(&w, c.wstream()));
+      else c.chk(rc);
+    }
+    for (int blk : pend_blocks) record_grad_events(blk, c.wstream(), c.rc);
+    pend_pw.clear(); pend_c3.clear(); pend_blocks.clear();
+  };
   // ---- bottlenecks in reverse
   std::vector<hipEvent_t> block_done(A.blocks.size(), nullptr);
   for (int i = (int)A.blocks.size() - 1; i >= 0; --i) {
@@ -797,8 +850,12 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
     const void* yin = i == 0 ? P.pool : P.blk[i - 1].y;
     const void* extra = (i == A.layer_end[1] + 1) ? P.R3 : nullptr;     // the block whose INPUT is res3
     const int par = i & 1;
-    const bool late = fused && fork_each && l3_single_fork && i > A.layer_end[1] && !B.has_ds;    // the three gradients behind ONE fork
+    const bool grouped = group_on && i >= first_id && i <= last_id && b.gT1 != nullptr;
+    bool closes_group = false;
+    if (grouped) for (int gc : group_close) closes_group |= gc == i;
+    const bool late = !grouped && fused && fork_each && l3_single_fork && i > A.layer_end[1] && !B.has_ds;    // the three gradients behind ONE fork
     void *T1 = P.S1[par], *T2 = P.S2[par], *U1 = P.S3[par], *T3 = P.SD[par];
+    if (grouped) { T1 = b.gT1; T2 = b.gT2; U1 = b.gU1; }
     // this parity's buffers were last read by the weight gradients of block i+2: wait for them
     if (i + 2 < (int)A.blocks.size()) c.wait_on_main(block_done[i + 2]);
     // (1) per-channel sums for bn3 (and the downsample BN) with gz = g_y * (y > 0)
@@ -818,7 +875,7 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
       const tf_bn_bwd_desc d = bwd_desc(c, B.c3, b.b3, b.b3.bst, nk, 1);
       conv_fill(a, dtype, 1, N, b.Hout, b.Wout, c4, b.Hout, b.Wout, pl, 1, 1, 0, pl, Gcur, b.w3t, T2);
       a.epi = TF_EPI_MASK | TF_EPI_STATS2; a.aux = b.c2; a.mask_scale = b.b2.scale; a.mask_shift = b.b2.shift; a.stat_out = b.b2.bst;
-      if (fork_each && !late) c.arm_fork();
+      if (fork_each && !late && !grouped) c.arm_fork();
       const int rc = tf_conv2d_bnbwd(&a, &d, b.c3, T1, srows, (float)Mout, c.stream);
       if (rc == TF_OK) fused24 = true;
       else if (rc != TF_ERR_UNSUPPORTED) c.chk(rc);
@@ -828,7 +885,7 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
       // nothing: T1 and T2 are on their way
     } else if (fused) {
       const tf_bn_bwd_desc d = bwd_desc(c, B.c3, b.b3, b.b3.bst, nk, 1);
-      if (fork_each && !late) c.arm_fork();
+      if (fork_each && !late && !grouped) c.arm_fork();
       c.chk(tf_bn_bwd_apply_fused(dtype, Gcur, nullptr, b.c3, &d, srows, Mout, c4, (float)Mout, T1, c.stream));
     } else {
       bn_backward_coefs(c, B.c3, c4, b.b3, P.partial, nb, nk, 1, c4, (float)Mout, B.has_ds ? 0 : 1);   // the last reader clears the partial rows
@@ -837,7 +894,8 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
     }
     // (3) wgrad conv3 (its input is relu(bn2(c2)), materialised in the forward)
     auto wg3 = [&]() { wgrad(c, B.c3, c4, N, b.Hout, b.Wout, b.Hout, b.Wout, b.a2, pl, T1, c4, nullptr); };
-    if (fork_each && !late) { c.fork_armed(); wg3(); }
+    if (grouped) pend_pw.push_back(wgrad_args(c, B.c3, c4, N, b.Hout, b.Wout, b.Hout, b.Wout, b.a2, pl, T1, c4));
+    else if (fork_each && !late) { c.fork_armed(); wg3(); }
     // (4) dgrad conv3 -> gz2 in T2 (masked by relu(bn2(c2))) + BN-backward sums
     if (!fused24) {
       conv_fill(a, dtype, 1, N, b.Hout, b.Wout, c4, b.Hout, b.Wout, pl, 1, 1, 0, pl, T1, b.w3t, T2);
@@ -848,7 +906,7 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
     // (5) g_c2 in place
     if (fused) {
       const tf_bn_bwd_desc d = bwd_desc(c, B.c2, b.b2, b.b2.bst, 2, 1);
-      if (fork_each && !late) c.arm_fork();
+      if (fork_each && !late && !grouped) c.arm_fork();
       c.chk(tf_bn_bwd_apply_fused(dtype, T2, nullptr, b.c2, &d, srows, Mout, pl, (float)Mout, T2, c.stream));
     } else {
       bn_backward_coefs(c, B.c2, pl, b.b2, P.partial, tf_conv_mtiles(&a), 2, 1, pl, (float)Mout);
@@ -856,7 +914,8 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
     }
     // (6) wgrad conv2 (input relu(bn1(c1)))
     auto wg2 = [&]() { wgrad(c, B.c2, pl, N, b.Hin, b.Win, b.Hout, b.Wout, b.a1, pl, T2, pl, nullptr, 0, 0, 0, P.dwp, P.dwp_floats); };
-    if (fork_each && !late) { c.fork_armed(); wg2(); }
+    if (grouped) pend_c3.push_back(wgrad_args(c, B.c2, pl, N, b.Hin, b.Win, b.Hout, b.Wout, b.a1, pl, T2, pl));
+    else if (fork_each && !late) { c.fork_armed(); wg2(); }
     // (7) dgrad conv2 -> gz1 in U1 (+ sums); output spatial = conv2's input
     conv_fill(a, dtype, 1, N, b.Hout, b.Wout, pl, b.Hin, b.Win, pl, 3, B.stride, 1, pl, T2, b.w2t, U1);
     a.epi = TF_EPI_MASK | TF_EPI_STATS2; a.aux = b.c1; a.mask_scale = b.b1.scale; a.mask_shift = b.b1.shift;
@@ -865,7 +924,7 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
     // (8) g_c1 in place
     if (fused) {
       const tf_bn_bwd_desc d = bwd_desc(c, B.c1, b.b1, b.b1.bst, 2, 1);
-      if (fork_each) c.arm_fork();
+      if (grouped ? closes_group : fork_each) c.arm_fork();       // grouped: only the kernel that completes a GROUP's operands carries a fork
       c.chk(tf_bn_bwd_apply_fused(dtype, U1, nullptr, b.c1, &d, srows, Min, pl, (float)Min, U1, c.stream));
     } else {
       bn_backward_coefs(c, B.c1, pl, b.b1, P.partial, tf_conv_mtiles(&a), 2, 1, pl, (float)Min);
@@ -873,7 +932,11 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
     }
     // (9) wgrad conv1 (input = block input, already activated)
     auto wg1 = [&]() { wgrad(c, B.c1, pl, N, b.Hin, b.Win, b.Hin, b.Win, yin, B.cin, U1, pl, nullptr); };
-    if (fork_each) { c.fork_armed(); if (late) { wg3(); wg2(); } wg1(); }
+    if (grouped) {
+      pend_pw.push_back(wgrad_args(c, B.c1, pl, N, b.Hin, b.Win, b.Hin, b.Win, yin, B.cin, U1, pl));
+      pend_blocks.push_back(i);
+      if (closes_group) { c.fork_armed(); flush_group(); }
+    } else if (fork_each) { c.fork_armed(); if (late) { wg3(); wg2(); } wg1(); }
     // (10) gradient w.r.t. the block input -> Gnext.  Fused flow: the conv that completes it also applies the ReLU mask of
     //      the previous block's output (MASK2 with aux2 = yin) and, unless that block has a downsample branch, accumulates
     //      its BN3-backward sums (STATS3 with aux3 = its c3), so the next iteration starts at step (2).
@@ -904,15 +967,17 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
       else { a.epi = TF_EPI_JOIN; a.aux2 = b.y; a.aux3 = Gcur; }            // identity branch: + g_y * (y > 0)
       c.chk(tf_conv2d(&a, c.stream));
     }
-    if (!fork_each) {
+    if (!fork_each && !grouped) {
       // alternative schedule: the block's four weight gradients start together once its data-gradient chain is enqueued
       // and overlap the NEXT block's chain (their operands live in this parity's buffers until block i-2 reuses them)
       c.fork();
       wg3(); wg2(); wg1();
       if (B.has_ds) wgrad(c, B.ds, c4, N, b.Hin, b.Win, b.Hout, b.Wout, yin, B.cin, T3, c4, nullptr);
     }
-    block_done[i] = c.mark_side();
-    record_grad_events(i, c.wstream(), c.rc);      // everything up to here on that stream: the weight/BN gradients of blocks >= i and of the heads
+    if (!grouped) {
+      block_done[i] = c.mark_side();
+      record_grad_events(i, c.wstream(), c.rc);      // everything up to here on that stream: the weight/BN gradients of blocks >= i and of the heads
+    }                                                // (grouped blocks: no parity buffer to protect; their events fire in flush_group)
     void* t = Gcur; Gcur = Gnext; Gnext = t;
   }
 

@@ -18,6 +18,8 @@
 
 int tf_wgrad_dma_launch(const tf_wgrad_args* a, hipStream_t stream);
 int tf_wgrad3x3_launch(const tf_wgrad_args* a, hipStream_t stream);       // wgrad3x3.hip   // wgrad_dma.hip
+int tf_wgrad3x3_group_launch(const tf_wgrad_args* a, int n, hipStream_t stream);       // wgrad3x3.hip
+int tf_wgrad_pw_group_launch(const tf_wgrad_args* a, int n, hipStream_t stream);        // wgrad_group.hip
 
 namespace {
 
@@ -238,6 +240,23 @@ extern "C" int tf_conv2d_wgrad(const tf_wgrad_args* a, void* stream_) {
   const bool small = a->tile ? a->tile == 64 : true;   // 64x64 tiles: 4x fewer split-K partials per MFMA flop than 128x128
   if (a->dtype == TF_BF16) return small ? launch_wgrad<tf::bf16_t, 64>(a, stream) : launch_wgrad<tf::bf16_t, 128>(a, stream);
   return small ? launch_wgrad<float, 64>(a, stream) : launch_wgrad<float, 128>(a, stream);
+}
+
+// r4: a GROUP of weight gradients in one launch, every output tile reduced over all pixels in-block (no split-K, no atomics: dw is
+// OVERWRITTEN).  All problems pointwise (any channel counts, one pixel count), or all the same 3x3 / stride 1 / pad 1 shape.
+extern "C" int tf_conv2d_wgrad_group(const tf_wgrad_args* probs, int n, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!probs || n <= 0) return TF_ERR_ARG;
+  for (int i = 0; i < n; ++i) {
+    const tf_wgrad_args& a = probs[i];
+    if (!a.x || !a.dy || !a.dw_oihw) return TF_ERR_ARG;
+    if (a.dtype != TF_BF16 || a.pro_scale) return TF_ERR_UNSUPPORTED;
+    if (a.ldx % 8 || a.lddy % 8 || a.ldx < a.Cin || a.lddy < a.Cout) return TF_ERR_ARG;
+    if (a.KH != probs[0].KH || a.KW != probs[0].KW) return TF_ERR_UNSUPPORTED;
+  }
+  if (probs[0].KH == 1 && probs[0].KW == 1) return tf_wgrad_pw_group_launch(probs, n, stream);
+  if (probs[0].KH == 3 && probs[0].KW == 3) return tf_wgrad3x3_group_launch(probs, n, stream);
+  return TF_ERR_UNSUPPORTED;
 }
 
 namespace {

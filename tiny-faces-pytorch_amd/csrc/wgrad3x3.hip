@@ -25,6 +25,7 @@
 #include <cstdlib>
 #include "common.h"
 #include "profile.h"
+#include "lds_dma.h"
 
 namespace {
 
@@ -40,16 +41,24 @@ struct W3K {
   int Hp, Wp, HWp, Mp;              // padded frame: H+2, W+2, their product, N * HWp
   int nco, nci, splitk, chunk, hb;  // hb = halo in 64-row chunks on either side: ceil((Wp + 1) / 64)
   int q64, r64, small_frame, dbg;   // 64 = q64 * Wp + r64; small_frame: a frame of <= q64 + 1 rows (loop in PadPos::advance)
+  int direct;                       // 1: single writer per output element (splitk == 1): plain stores instead of fp32 atomics
 };
+// r4: a GROUP of problems of identical shape in one launch (the conv2 weight gradients of the identity bottlenecks of layer 3): block ->
+// (problem, tile); x / dy / dw per problem.  With splitk = 1 every tile reduces over the WHOLE padded raster in-block: no slices, no
+// partial tiles, no summing kernel, no atomics (tf_conv2d_wgrad_group, csrc/wgrad.hip).
+constexpr int W3_MAXG = 24;
+struct W3G { const char* x[W3_MAXG]; const char* dy[W3_MAXG]; float* dw[W3_MAXG]; };
 
 constexpr int PK = 64, NS = 3, YT = PK * 128, XROWS = 512, XBYTES = XROWS * 128, L = 2, NT = 512;
 constexpr int TILE_FLOATS = 9 * 64 * 64;
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// r4: issued from inline asm (lds_dma.h).  Through __builtin_amdgcn_global_load_lds hipcc saw a pending LDS write and put an
+// `s_waitcnt vmcnt(0)` in front of the first ds_read_b64_tr_b16 of EVERY stage (the transposing read carries no memory operand the
+// wait-count pass could disambiguate): the ring was drained once per stage, each stage paid the full latency of the DMA issued just
+// before it.  The counted vmcnt + barrier of the loop is what orders the fragment reads behind the DMA.
 __device__ __forceinline__ void dma16(const void* gsrc, void* lds_wave_base) {
-  typedef __attribute__((address_space(3))) void lds_void;
-  typedef __attribute__((address_space(1))) const void glb_void;
-  __builtin_amdgcn_global_load_lds((glb_void*)gsrc, (lds_void*)lds_wave_base, 16, 0, 0);
+  tf::dma16_hidden(gsrc, tf::lds_addr_uniform(lds_wave_base));
 }
 // same source-side swizzle as wgrad_dma.hip: conflict-free ds_read_b64_tr_b16 for ANY eight consecutive rows (the shifted reads of
 // the taps start at arbitrary rows; 512 is a multiple of 8, so the ring wrap keeps the pattern)
@@ -100,12 +109,11 @@ __device__ __forceinline__ bf16x8 read_tr_pair(const char* base, int off_lo, int
 //     modulo the 64 KiB ring; the swizzle term is stage-invariant (64 and the 512-row wrap are multiples of 8 rows);
 //   * the 4 dY-fragment offsets are fixed; the ring slot is a scalar add;
 //   * the DMA source walk is branch-free (PadPos::advance).
-template <bool SMALL>
-__global__ void __launch_bounds__(NT, 2) wgrad3x3_kernel(const W3K a) {
+template <bool SMALL, bool GROUPED>
+__device__ __forceinline__ void wgrad3x3_body(const W3K& a, const char* const gx, const char* const gdy, float* const gdw, int b) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const yring = smem;
   char* const xring = smem + NS * YT;
-  int b = blockIdx.x;
   const int ks = b % a.splitk; b /= a.splitk;
   const int tci = b % a.nci; b /= a.nci;
   const int tco = b;
@@ -126,8 +134,8 @@ __global__ void __launch_bounds__(NT, 2) wgrad3x3_kernel(const W3K a) {
   int yrow = pb + r;                                     // padded index of this thread's dY row in the NEXT stage to issue
   const int ycol = co0 + ls * 8, xcol = ci0 + ls * 8;
   const bool ycok = ycol + 8 <= a.lddy, xcok = xcol + 8 <= a.ldx;
-  const char* const ybase = a.dy + (size_t)ycol * 2;
-  const char* const xbase = a.x + (size_t)xcol * 2;
+  const char* const ybase = gdy + (size_t)ycol * 2;
+  const char* const xbase = gx + (size_t)xcol * 2;
   int ys_slot = 0, xc = 0;                               // dY ring slot / X chunk index of the next issue (scalar)
   auto issue_y = [&]() {
     const bool ok = (yrow < pe) & ycok & ypos.interior(a);
@@ -241,9 +249,27 @@ __global__ void __launch_bounds__(NT, 2) wgrad3x3_kernel(const W3K a) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int co = co0 + wco * 32 + n * 16 + lg * 4 + q;
-        if (co < a.Cout && ci < a.Cin) atomicAdd(a.dw + (size_t)co * a.dw_ld + (size_t)ci * a.ci_stride + (size_t)t * a.tap_stride, acc[t][n][q]);
+        if (co < a.Cout && ci < a.Cin) {
+          float* d = gdw + (size_t)co * a.dw_ld + (size_t)ci * a.ci_stride + (size_t)t * a.tap_stride;
+          if (GROUPED || a.direct) *d = acc[t][n][q]; else atomicAdd(d, acc[t][n][q]);
+        }
       }
     }
+}
+
+template <bool SMALL>
+__global__ void __launch_bounds__(NT, 2) wgrad3x3_kernel(const W3K a) {
+  wgrad3x3_body<SMALL, false>(a, a.x, a.dy, a.dw, blockIdx.x);
+}
+// grouped form: splitk == 1, no partial workspace; the tiles of one problem are consecutive in the XCD-remapped block order (they
+// stream the same dY / X rows: one XCD's L2 serves all 16 of them)
+template <bool SMALL>
+__global__ void __launch_bounds__(NT, 2) wgrad3x3_group_kernel(const W3K a, const W3G g) {
+  const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  const int per = a.nco * a.nci;
+  const int grp = logical / per;
+  wgrad3x3_body<SMALL, true>(a, g.x[grp], g.dy[grp], g.dw[grp], logical - grp * per);
 }
 
 // dW += sum over the slices of the partial tiles.  256 threads = (256 / SG) float4 columns x SG slice groups; SG is chosen so that a
@@ -300,7 +326,7 @@ bool w3_plan(const tf_wgrad_args* A, W3K& k) {
   if ((long long)A->N * A->H * A->W * 2 * (A->ldx > A->lddy ? A->ldx : A->lddy) >= (1ll << 32)) return false;       // 32-bit byte offsets in the DMA walk
   k.Mp = (int)mp;
   k.hb = (k.Wp + 1 + PK - 1) / PK;
-  k.q64 = PK / k.Wp; k.r64 = PK % k.Wp; k.small_frame = k.Hp <= k.q64 + 1; k.dbg = 0;
+  k.q64 = PK / k.Wp; k.r64 = PK % k.Wp; k.small_frame = k.Hp <= k.q64 + 1; k.dbg = 0; k.direct = 0;
   k.nco = (A->Cout + 63) / 64; k.nci = (A->Cin + 63) / 64;
   const int tiles = k.nco * k.nci;
   int sk = A->splitk;
@@ -357,5 +383,40 @@ int tf_wgrad3x3_launch(const tf_wgrad_args* A, hipStream_t stream) {
     else if (k.splitk >= 16) hipLaunchKernelGGL(wgrad3x3_reduce_kernel<2>, dim3((unsigned)(total4 / 128)), dim3(256), 0, stream, k);
     else                     hipLaunchKernelGGL(wgrad3x3_reduce_kernel<1>, dim3((unsigned)(total4 / 256)), dim3(256), 0, stream, k);
   }
+  return hipGetLastError() == hipSuccess ? TF_OK : TF_ERR_LAUNCH;
+}
+
+// n problems of the SAME shape (3x3 / stride 1 / pad 1, bf16) in one launch, every tile reduced over the whole padded raster in-block;
+// dw is OVERWRITTEN (plain stores).  TF_ERR_UNSUPPORTED when the shape does not qualify or the problems differ in shape.
+int tf_wgrad3x3_group_launch(const tf_wgrad_args* A, int n, hipStream_t stream) {
+  if (n <= 0 || n > W3_MAXG) return TF_ERR_UNSUPPORTED;
+  tf_wgrad_args first = A[0];
+  first.splitk = 1; first.partial_ws = nullptr; first.partial_ws_bytes = 0;
+  W3K k;
+  if (!w3_plan(&first, k) || k.splitk != 1) return TF_ERR_UNSUPPORTED;
+  W3G g;
+  for (int i = 0; i < n; ++i) {
+    const tf_wgrad_args& q = A[i];
+    if (q.dtype != first.dtype || q.pro_scale || q.N != first.N || q.H != first.H || q.W != first.W || q.Cin != first.Cin || q.Cout != first.Cout ||
+        q.KH != 3 || q.KW != 3 || q.stride != 1 || q.pad != 1 || q.OH != q.H || q.OW != q.W || q.ldx != first.ldx || q.lddy != first.lddy ||
+        q.dw_ld != first.dw_ld || q.packed != first.packed) return TF_ERR_UNSUPPORTED;
+    g.x[i] = (const char*)q.x; g.dy[i] = (const char*)q.dy; g.dw[i] = q.dw_oihw;
+  }
+  for (int i = n; i < W3_MAXG; ++i) { g.x[i] = nullptr; g.dy[i] = nullptr; g.dw[i] = nullptr; }
+  k.direct = 1;
+  const size_t lds = (size_t)NS * YT + XBYTES;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_group_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_group_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  const double Md = (double)first.N * first.H * first.W;
+  // kind 19 = grouped all-taps 3x3 weight gradient; the GEMM view is the SUM over the group
+  tf::ProfScope prof(19, 2.0 * Md * first.Cout * first.Cin * 9 * n, ((Md * first.Cout + Md * first.Cin) * 2 + (double)first.Cout * first.Cin * 9 * 4) * n, stream,
+                     (int)Md, first.Cout, first.Cin * 9, 9, 2, 0, -1.0, true);
+  const dim3 grid(k.nco * k.nci * n);
+  if (k.small_frame) TF_LAUNCH_TIMED((wgrad3x3_group_kernel<true>), grid, dim3(NT), lds, stream, k, g);
+  else TF_LAUNCH_TIMED((wgrad3x3_group_kernel<false>), grid, dim3(NT), lds, stream, k, g);
   return hipGetLastError() == hipSuccess ? TF_OK : TF_ERR_LAUNCH;
 }

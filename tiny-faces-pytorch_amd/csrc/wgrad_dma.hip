@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include "common.h"
 #include "profile.h"
+#include "lds_dma.h"
 
 namespace {
 
@@ -27,10 +28,19 @@ struct WdK {
 constexpr int PK = 64, TILEB = PK * 128, BUF = 2 * TILEB, L = 4;     // ring depth NS: template parameter (3 default; 2 = 32 KiB of LDS per block)
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-__device__ __forceinline__ void dma16(const void* gsrc, void* lds_wave_base) {
-  typedef __attribute__((address_space(3))) void lds_void;
-  typedef __attribute__((address_space(1))) const void glb_void;
-  __builtin_amdgcn_global_load_lds((glb_void*)gsrc, (lds_void*)lds_wave_base, 16, 0, 0);
+// r4: issued from inline asm (lds_dma.h).  Through __builtin_amdgcn_global_load_lds hipcc saw a pending LDS write and put an
+// `s_waitcnt vmcnt(0)` in front of the first ds_read_b64_tr_b16 of EVERY stage (the transposing read carries no memory operand the
+// wait-count pass could disambiguate): the ring was drained once per stage, each stage paid the full latency of the DMA issued just
+// before it.  The counted vmcnt + barrier of the loop is what orders the fragment reads behind the DMA.
+// HIDDEN = false keeps the builtin form of rounds 1-3 for the A/B (TINYFACES_DMA_BUILTIN=1).
+template <bool HIDDEN> __device__ __forceinline__ void dma16(const void* gsrc, void* lds_wave_base) {
+  if constexpr (HIDDEN) {
+    tf::dma16_hidden(gsrc, tf::lds_addr_uniform(lds_wave_base));
+  } else {
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef __attribute__((address_space(1))) const void glb_void;
+    __builtin_amdgcn_global_load_lds((glb_void*)gsrc, (lds_void*)lds_wave_base, 16, 0, 0);
+  }
 }
 __device__ __forceinline__ int fsw(int row) { return ((row >> 1) & 3) << 1; }
 
@@ -47,7 +57,7 @@ __device__ __forceinline__ bf16x8 frag_tr(const char* tile, int pk0, int c0) {
 }
 
 // KIND 1: pointwise (1x1, stride 1, pad 0): X row of pixel p is row p.  KIND 0: generic tap gather.
-template <int KIND, int NS = 3>
+template <int KIND, int NS = 3, bool HIDDEN = true>
 __global__ void __launch_bounds__(256) wgrad_dma_kernel(const WdK a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int b = blockIdx.x;
@@ -91,7 +101,7 @@ __global__ void __launch_bounds__(256) wgrad_dma_kernel(const WdK a) {
     for (int i = 0; i < 2; ++i) {
       const bool in = prow[i] < pend;
       const uintptr_t ysrc = (in && ycol[i]) ? reinterpret_cast<uintptr_t>(yptr[i]) : reinterpret_cast<uintptr_t>(zero);
-      dma16(reinterpret_cast<const void*>(ysrc), ys + i * 4096 + wave_byte);
+      dma16<HIDDEN>(reinterpret_cast<const void*>(ysrc), ys + i * 4096 + wave_byte);
       uintptr_t xsrc;
       if (KIND == 1) {
         xsrc = (in && xcol[i]) ? reinterpret_cast<uintptr_t>(xptr[i]) : reinterpret_cast<uintptr_t>(zero);
@@ -105,7 +115,7 @@ __global__ void __launch_bounds__(256) wgrad_dma_kernel(const WdK a) {
         row_[i] += PK;
         while (row_[i] >= a.OW) { row_[i] -= a.OW; if (++roh[i] == a.OH) { roh[i] = 0; ++rn[i]; } }
       }
-      dma16(reinterpret_cast<const void*>(xsrc), xs + i * 4096 + wave_byte);
+      dma16<HIDDEN>(reinterpret_cast<const void*>(xsrc), xs + i * 4096 + wave_byte);
       yptr[i] += (size_t)PK * a.lddy * 2;
       prow[i] += PK;
     }
@@ -186,14 +196,23 @@ int tf_wgrad_dma_launch(const tf_wgrad_args* A, hipStream_t stream) {
   // (profiles/r03_contention.txt); TINYFACES_WGRAD_NS=2 trades a shallower ring for a third less LDS per block
   static const int ns = [] { const char* e = getenv("TINYFACES_WGRAD_NS"); const int v = e ? atoi(e) : 3; return v == 2 ? 2 : 3; }();
   const size_t lds = (size_t)ns * BUF;
+  auto lds3 = [] { return (size_t)3 * BUF; };
   const bool pointwise = ntaps == 1 && A->stride == 1 && A->pad == 0 && A->H == A->OH && A->W == A->OW;
   const double Md = k.M;
   tf::ProfScope prof(14, 2.0 * Md * A->Cout * A->Cin * ntaps,
                      (Md * A->Cout + (double)A->N * A->H * A->W * A->Cin) * 2 + (double)A->Cout * A->Cin * ntaps * 4, stream, k.M, A->Cout,
                      A->Cin * ntaps, ntaps, 2, 0, -1.0, true);
-  if (pointwise) { if (ns == 2) TF_LAUNCH_TIMED((wgrad_dma_kernel<1, 2>), dim3(tiles * k.splitk), dim3(256), lds, stream, k);
-                   else TF_LAUNCH_TIMED((wgrad_dma_kernel<1, 3>), dim3(tiles * k.splitk), dim3(256), lds, stream, k); }
-  else           { if (ns == 2) TF_LAUNCH_TIMED((wgrad_dma_kernel<0, 2>), dim3(tiles * k.splitk), dim3(256), lds, stream, k);
-                   else TF_LAUNCH_TIMED((wgrad_dma_kernel<0, 3>), dim3(tiles * k.splitk), dim3(256), lds, stream, k); }
+  static const bool builtin_dma = getenv("TINYFACES_DMA_BUILTIN") != nullptr;       // A/B: the compiler-visible DMA of rounds 1-3 (drained every stage)
+  const dim3 grid(tiles * k.splitk);
+  if (builtin_dma) {
+    if (pointwise) TF_LAUNCH_TIMED((wgrad_dma_kernel<1, 3, false>), grid, dim3(256), lds3(), stream, k);
+    else TF_LAUNCH_TIMED((wgrad_dma_kernel<0, 3, false>), grid, dim3(256), lds3(), stream, k);
+  } else if (pointwise) {
+    if (ns == 2) TF_LAUNCH_TIMED((wgrad_dma_kernel<1, 2>), grid, dim3(256), lds, stream, k);
+    else TF_LAUNCH_TIMED((wgrad_dma_kernel<1, 3>), grid, dim3(256), lds, stream, k);
+  } else {
+    if (ns == 2) TF_LAUNCH_TIMED((wgrad_dma_kernel<0, 2>), grid, dim3(256), lds, stream, k);
+    else TF_LAUNCH_TIMED((wgrad_dma_kernel<0, 3>), grid, dim3(256), lds, stream, k);
+  }
   return hipGetLastError() == hipSuccess ? TF_OK : TF_ERR_LAUNCH;
 }

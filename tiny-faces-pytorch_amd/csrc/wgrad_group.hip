@@ -1,0 +1,221 @@
+// wgrad_group: the weight gradients of a GROUP of pointwise convolutions in ONE launch, every output tile reduced over ALL pixels
+// inside its block (gfx950).
+//
+//   dW_g[co][ci] = sum over all M pixels of dY_g[p][co] * X_g[p][ci]          g = 0 .. nprob-1     (bf16 operands, fp32 accumulate)
+//
+// Why it exists (profiles/r03_layer_table.md): one pointwise weight gradient of layer 3 is a GEMM with a 256 x 1024
+// output and a 12 288-long reduction -- 16 output tiles of 128 x 128 for 256 CUs.  wgrad_dma_kernel therefore splits the reduction 16 ways
+// and adds the slices with fp32 atomics: 12 pixel stages per block, i.e. launch / prologue / epilogue as long as the loop, and 64 x 64
+// tiles whose operands cross the LDS twice per MAC (0.066 of the bf16 MFMA peak in situ).  The 22 identity bottlenecks of layer 3 have
+// IDENTICAL shapes, and nothing but the optimizer reads a weight gradient: the executor keeps their dY / X tensors alive (csrc/detnet.hip,
+// 0.9 GB of 288) and differentiates a whole group of bottlenecks in one launch -- 32 tiles per bottleneck, 256 per group of eight.
+//   * no split-K: a block walks all 384 pixel stages of its tile; no atomics, no memset, no partial-tile round trip, no reduce kernel:
+//     the epilogue is 64 plain stores per lane, once per 0.4 GFLOP;
+//   * 128 x 128 tiles, 4 waves, 64 x 64 per wave on mfma_f32_16x16x32_bf16: 16 MFMAs per 16 transposing fragment reads
+//     (ds_read_b64_tr_b16: the reduction index -- the pixel -- is the strided one of both NHWC operands) instead of 4 per 8;
+//   * operands HBM/L2 -> LDS by global_load_lds_dwordx4 (no register hop), 32-pixel stages of 16 KiB, GP_NS-deep ring (default 4:
+//     64 KiB per block), counted vmcnt + raw s_barrier; the fragments of stage st+1 are read while the MFMAs of stage st run
+//     (two named fragment sets: a one-block-per-CU launch has ONE wave per SIMD and nobody else hides its LDS latency);
+//   * the tiles of one problem are consecutive in the XCD-remapped block order, so the 16 blocks that stream the same dY / X rows
+//     share one XCD's L2 (the operands of a group -- 0.6 GB -- do not fit the 256 MB Infinity Cache: they come from HBM once).
+// LDS image of an operand sub-tile: [32 pixels][8 x 16 B] (64 channels), 16-byte slots XOR-swizzled on the SOURCE address with
+// ((row >> 1) & 3) << 1 -- the layout wgrad_dma.hip found conflict-free for the transposing reads.
+// Replaces the autograd weight gradient of the conv1 / conv3 of every identity Bottleneck of layer 3 (tinyfaces/trainer.py:86 through
+// torchvision's Bottleneck); bf16 only (the fp32 parity path keeps wgrad.hip).
+#include <cstdlib>
+#include "common.h"
+#include "profile.h"
+#include "lds_dma.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+__device__ uint4 g_gzero_page[8];
+
+constexpr int GP_PK = 32;                    // pixels per stage = one MFMA k-step
+constexpr int GP_SUB = GP_PK * 128;          // one 64-channel operand sub-tile of a stage: 4 KiB
+constexpr int GP_STAGE = 4 * GP_SUB;         // dY[co 0-63], dY[co 64-127], X[ci 0-63], X[ci 64-127]: 16 KiB
+constexpr int GP_L = 4;                      // DMA instructions per thread and stage
+constexpr int GP_MAX = 48;                   // problems per launch (the table travels as kernel arguments)
+
+struct GpProb { const char* x; const char* dy; float* dw; int Cin, Cout, ldx, lddy, dw_ld, nci, tile0, pad_; };
+struct GpK { int M, nprob, ntiles, pad_; GpProb p[GP_MAX]; };
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ int fsw(int row) { return ((row >> 1) & 3) << 1; }
+
+struct Frags { bf16x8 y[4], x[4]; };
+// the eight 16-channel x 32-pixel fragments of a wave's 64 x 64 tile from one stage: off[n] = byte offset of fragment n's low half
+// inside a sub-tile (the same for both operands), the +16-pixel half 2 KiB further (fsw(row + 16) == fsw(row))
+__device__ __forceinline__ void read_frags(Frags& f, const char* ysub, const char* xsub, const int (&off)[4]) {
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(ysub + off[n]));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(ysub + off[n] + 16 * 128));
+    f.y[n] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(xsub + off[m]));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(xsub + off[m] + 16 * 128));
+    f.x[m] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+}
+__device__ __forceinline__ void mma_frags(f32x4 (&acc)[4][4], const Frags& f) {
+#pragma unroll
+  for (int n = 0; n < 4; ++n)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.y[n], f.x[m], acc[n][m], 0, 0, 0);
+}
+
+template <int NS>
+__global__ void __launch_bounds__(256, 2) wgrad_group_kernel(const GpK a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // XCD-aware bijective remap: the dispatcher deals consecutive block ids round-robin to the 8 XCDs; give every XCD a contiguous range
+  // of tiles, so that the tiles of one problem (same dY, same X) meet in one L2
+  int logical;
+  {
+    const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  int pi = 0;
+  while (pi + 1 < a.nprob && logical >= a.p[pi + 1].tile0) ++pi;
+  const GpProb P = a.p[pi];
+  const int t = logical - P.tile0;
+  const int tco = t / P.nci, tci = t - tco * P.nci;
+  const int co0 = tco * 128, ci0 = tci * 128;
+  const int tid = threadIdx.x, lrow = tid >> 3, pslot = tid & 7;
+  const int wave_byte = (tid & ~63) * 16;
+  const char* zero = reinterpret_cast<const char*>(g_gzero_page) + pslot * 16;
+
+  // this thread's 16-byte piece of row `lrow` of each of the four sub-tiles of a stage
+  const int ls = pslot ^ fsw(lrow);          // logical slot that must land in physical slot pslot of row lrow
+  const char* src[4];
+  bool colok[4];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int cy = co0 + s * 64 + ls * 8, cx = ci0 + s * 64 + ls * 8;
+    colok[s] = cy + 8 <= P.lddy; colok[2 + s] = cx + 8 <= P.ldx;
+    src[s] = P.dy + ((size_t)lrow * P.lddy + cy) * 2;
+    src[2 + s] = P.x + ((size_t)lrow * P.ldx + cx) * 2;
+  }
+  const size_t ystep = (size_t)GP_PK * P.lddy * 2, xstep = (size_t)GP_PK * P.ldx * 2;
+  int prow = lrow, is_slot = 0;
+  const uint32_t lds0 = tf::lds_addr_uniform(smem + wave_byte);      // this wave's 1 KiB (8 rows) of sub-tile 0 of ring slot 0
+  // the DMA is issued from inline asm (lds_dma.h): hipcc must not see a pending LDS write, or it drains the ring with a
+  // `s_waitcnt vmcnt(0)` in front of the first transposing fragment read of every stage
+  auto issue = [&]() {
+    const uint32_t st = lds0 + (uint32_t)(is_slot * GP_STAGE);
+    const bool in = prow < a.M;
+    const void* g[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      g[s] = reinterpret_cast<const void*>((in && colok[s]) ? reinterpret_cast<uintptr_t>(src[s]) : reinterpret_cast<uintptr_t>(zero));
+      src[s] += s < 2 ? ystep : xstep;
+    }
+    tf::dma16_hidden4(g[0], g[1], g[2], g[3], st, st + GP_SUB, st + 2 * GP_SUB, st + 3 * GP_SUB);
+    prow += GP_PK;
+    if (++is_slot == NS) is_slot = 0;
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int wave = tid >> 6, wco = wave & 1, wci = wave >> 1;
+  const int l = tid & 63, li = l & 15, lg = l >> 4;
+  int off[4];
+  {
+    const int row = lg * 4 + (li >> 2), fs = (li & 3) >> 1, fhalf = (li & 1) << 3;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) off[n] = row * 128 + (((2 * n + fs) ^ fsw(row)) << 4) + fhalf;
+  }
+  const int ybase = wco * GP_SUB, xbase = 2 * GP_SUB + wci * GP_SUB;
+
+  const int nst = (a.M + GP_PK - 1) / GP_PK;
+  // prologue: stages 0 .. NS-2 in flight, stage 0 landed and read
+#pragma unroll
+  for (int j = 0; j < NS - 1; ++j) issue();            // past the end the rows come from the zero page: the DMA count stays uniform
+  wait_vm<GP_L*(NS - 2)>();
+  __builtin_amdgcn_s_barrier();
+  Frags fa, fb;
+  read_frags(fa, smem + ybase, smem + xbase, off);
+  int rs = 1;                                           // ring slot of the NEXT stage to read
+  // iteration st: stage st+1 landed -> barrier -> DMA of stage st+NS-1 into the slot stage st-1 left -> fragments of stage st+1
+  // are read WHILE the MFMAs of stage st (fragments already in registers) run.  Two iterations per trip: named fragment sets.
+  auto step = [&](Frags& cur, Frags& nxt) {
+    wait_vm<GP_L*(NS - 3)>();                           // this wave's pieces of stage st+1 landed (stages st+2 .. may be in flight)
+    __builtin_amdgcn_s_barrier();                       // everyone's pieces landed; everyone finished the MFMAs of stage st-1
+    issue();
+    const char* sb = smem + rs * GP_STAGE;
+    read_frags(nxt, sb + ybase, sb + xbase, off);
+    __builtin_amdgcn_sched_barrier(0);                  // the 16 fragment reads are ISSUED before the first MFMA (hipcc would hoist the
+    mma_frags(acc, cur);                                //  register-only MFMAs above the barrier and expose the LDS latency every stage)
+    if (++rs == NS) rs = 0;
+  };
+  int st = 0;
+  for (; st + 2 <= nst - 1; st += 2) { step(fa, fb); step(fb, fa); }
+  if (st < nst - 1) { step(fa, fb); mma_frags(acc, fb); }
+  else mma_frags(acc, fa);
+  wait_vm<0>();                                         // the zero-page pieces issued past the end, before the LDS is released
+
+  // D[co][ci]: lane holds co = (l >> 4) * 4 + r, ci = l & 15 of every 16 x 16 tile.  Single writer: plain stores.
+#pragma unroll
+  for (int n = 0; n < 4; ++n)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = co0 + wco * 64 + n * 16 + lg * 4 + r;
+      if (co < P.Cout) {
+        float* drow = P.dw + (size_t)co * P.dw_ld;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int ci = ci0 + wci * 64 + m * 16 + li;
+          if (ci < P.Cin) drow[ci] = acc[n][m][r];
+        }
+      }
+    }
+}
+
+}  // namespace
+
+// n pointwise problems (1x1, stride 1, pad 0, bf16, no prologue, all with the same pixel count) in one launch; dw is OVERWRITTEN.
+// TF_ERR_UNSUPPORTED when a problem does not qualify (the caller runs tf_conv2d_wgrad per problem instead).
+int tf_wgrad_pw_group_launch(const tf_wgrad_args* A, int n, hipStream_t stream) {
+  if (n <= 0 || n > GP_MAX) return TF_ERR_UNSUPPORTED;
+  GpK k;
+  k.M = A[0].N * A[0].OH * A[0].OW; k.nprob = n; k.pad_ = 0;
+  int tiles = 0;
+  double flops = 0, bytes = 0;
+  for (int i = 0; i < n; ++i) {
+    const tf_wgrad_args& q = A[i];
+    if (q.dtype != TF_BF16 || q.pro_scale || q.packed) return TF_ERR_UNSUPPORTED;
+    if (q.KH != 1 || q.KW != 1 || q.stride != 1 || q.pad != 0 || q.H != q.OH || q.W != q.OW) return TF_ERR_UNSUPPORTED;
+    if (q.N * q.OH * q.OW != k.M || q.ldx % 8 || q.lddy % 8 || q.ldx < q.Cin || q.lddy < q.Cout) return TF_ERR_UNSUPPORTED;
+    GpProb& p = k.p[i];
+    p.x = (const char*)q.x; p.dy = (const char*)q.dy; p.dw = q.dw_oihw; p.Cin = q.Cin; p.Cout = q.Cout; p.ldx = q.ldx; p.lddy = q.lddy;
+    p.dw_ld = q.dw_ld ? q.dw_ld : q.Cin; p.nci = (q.Cin + 127) / 128; p.tile0 = tiles; p.pad_ = 0;
+    tiles += ((q.Cout + 127) / 128) * p.nci;
+    flops += 2.0 * k.M * q.Cout * q.Cin;
+    bytes += ((double)k.M * q.Cout + (double)k.M * q.Cin) * 2 + (double)q.Cout * q.Cin * 4;
+  }
+  k.ntiles = tiles;
+  // ring depth: 4 (64 KiB per block: two blocks fit a CU beside nothing, one beside the data-gradient chain's kernels) or 5
+  static const int ns = [] { const char* e = getenv("TINYFACES_WGRADG_NS"); const int v = e ? atoi(e) : 4; return v == 5 ? 5 : 4; }();
+  const size_t lds = (size_t)ns * GP_STAGE;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_group_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_group_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  // kind 18 = grouped pointwise weight gradient (bench.py tables); the GEMM view is the SUM over the group
+  tf::ProfScope prof(18, flops, bytes, stream, k.M, A[0].Cout, A[0].Cin, 1, 2, 0, -1.0, true);
+  if (ns == 5) TF_LAUNCH_TIMED((wgrad_group_kernel<5>), dim3(tiles), dim3(256), lds, stream, k);
+  else TF_LAUNCH_TIMED((wgrad_group_kernel<4>), dim3(tiles), dim3(256), lds, stream, k);
+  return hipGetLastError() == hipSuccess ? TF_OK : TF_ERR_LAUNCH;
+}

@@ -92,6 +92,7 @@ _SIGNATURES = {
     "tf_conv2d": (i32, [C.POINTER(ConvArgs), vp]),
     "tf_pack_weight": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp]),
     "tf_conv2d_wgrad": (i32, [C.POINTER(WgradArgs), vp]),
+    "tf_conv2d_wgrad_group": (i32, [C.POINTER(WgradArgs), i32, vp]),
     "tf_wgrad_workspace_bytes": (sz, [C.POINTER(WgradArgs)]),
     "tf_unpack_dw": (i32, [vp, i32, i32, i32, vp, vp]),
     "tf_stem_im2col": (i32, [vp, i32, i32, i32, i32, vp, i32, vp]),

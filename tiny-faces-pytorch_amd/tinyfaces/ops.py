@@ -394,3 +394,24 @@ def conv2d_wgrad(x, dy, Cin, Cout, KH, KW, stride, pad, pro=None, splitk=0, tile
     with torch.cuda.device(x.device):
         check(lib().tf_conv2d_wgrad(C.byref(a), stream()), "tf_conv2d_wgrad")
     return dw
+
+
+def conv2d_wgrad_group(problems, K, pad):
+    """The weight gradients of a GROUP of convolutions in one launch (tf_conv2d_wgrad_group: every output tile reduced over all pixels
+    in-block, dW overwritten).  problems: [(x (N,H,W,ldx), dy (N,H,W,lddy), Cin, Cout)] bf16, stride 1; K = 1 (pad 0; any channel counts,
+    one pixel count) or K = 3 (pad 1; identical shapes).  Returns the list of dW (Cout,Cin,K,K) fp32, allocated with NaN so that an
+    element the launch does not write is seen."""
+    args = (_hip.WgradArgs * len(problems))()
+    outs = []
+    for a, (x, dy, Cin, Cout) in zip(args, problems):
+        require_gpu(x, "conv2d_wgrad_group")
+        N, H, W, ldx = x.shape
+        dw = torch.full((Cout, Cin, K, K), float("nan"), dtype=torch.float32, device=x.device)
+        a.dtype = _hip.tf_dtype(x.dtype)
+        a.N, a.H, a.W, a.Cin, a.OH, a.OW, a.Cout, a.KH, a.KW, a.stride, a.pad = N, H, W, Cin, H, W, Cout, K, K, 1, pad
+        a.ldx, a.lddy, a.x, a.dy, a.dw_oihw, a.dw_ld = ldx, dy.shape[3], ptr(x), ptr(dy), ptr(dw), Cin * K * K
+        outs.append(dw)
+    with torch.cuda.device(problems[0][0].device):
+        check(lib().tf_conv2d_wgrad_group(args, len(problems), stream()), "tf_conv2d_wgrad_group")
+    return outs
+
