@@ -32,9 +32,7 @@ pw = [prob(1024, 256) for _ in range(nblk)] + [prob(256, 1024) for _ in range(nb
 c3 = [prob(256, 256) for _ in range(nblk)]
 gf_pw = sum(2.0 * N * H * W * ci * co for _, _, ci, co in pw) / 1e9
 gf_c3 = sum(2.0 * N * H * W * ci * co * 9 for _, _, ci, co in c3) / 1e9
-for ns in ("4", "5"):
-    os.environ["TINYFACES_WGRADG_NS"] = ns       # (read once per process: only the first value takes effect; kept for the log)
-    break
+print("TINYFACES_WGRADG_NS =", os.environ.get("TINYFACES_WGRADG_NS", "default"), flush=True)      # ring depth of the grouped pointwise kernel: read once per process
 us = timeit(lambda: ops.conv2d_wgrad_group(pw, 1, 0))
 print(f"grouped pointwise  n={len(pw):2d}  {us:8.1f} us  {gf_pw / us * 1e3:7.1f} TFLOP/s  ({gf_pw:.0f} GFLOP)", flush=True)
 us = timeit(lambda: ops.conv2d_wgrad_group(c3, 3, 1))

@@ -57,3 +57,14 @@ for r in main:
 print("main-queue kernel totals:")
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:18]:
     print(f"    {k:42s} {v[0]:8.1f} us n={v[1]:4d} avg {v[0]/v[1]:6.1f}")
+# r4: who are the small blit dispatches?  (queue, kernel before, kernel after) of every copyBuffer / fillBuffer of the step, aggregated
+blit = collections.Counter()
+for q, rs in byq.items():
+    for i, r in enumerate(rs):
+        if r["n"].startswith("__amd_rocclr"):
+            prev = rs[i - 1]["n"][:34] if i else "-"
+            nxt = rs[i + 1]["n"][:34] if i + 1 < len(rs) else "-"
+            blit[(q == mainq, r["n"][13:], int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0), prev, nxt)] += 1
+print("blit dispatches of the step (main queue?, kind, grid, previous kernel, next kernel): count")
+for k, v in sorted(blit.items(), key=lambda kv: -kv[1])[:40]:
+    print(f"    {str(k[0]):5s} {k[1]:18s} grid={k[2]:6d} {k[3]:34s} -> {k[4]:34s} x{v}")

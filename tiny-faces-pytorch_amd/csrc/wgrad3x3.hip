@@ -194,20 +194,36 @@ __device__ __forceinline__ void wgrad3x3_body(const W3K& a, const char* const gx
     issue_y(); issue_x();                                // pair st + 2 (dY slot (st+2) % 3, X chunk st + D + 2)
     if (!(a.dbg & 1)) {
       const char* ys = yring + cs * YT;
+      // r4: ALL 22 fragment reads of a k-step are issued before its first MFMA, and the reads of the second k-step before the MFMAs of the
+      // first (two fragment sets, 88 registers).  The r2-r3 loop read tap t+1 while the two MFMAs of tap t ran: 32 cycles of cover for an
+      // LDS round trip of > 100 -- every tap of every stage waited (1.3 us per stage against 0.48 us of MFMA time for the two waves of a
+      // SIMD, profiles/r04_wgrad_group.txt).  The full-K grouped form runs 217 stages per block: the loop IS the kernel now.
+      bf16x8 fy0[2], fy1[2], fx0[9], fx1[9];
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        bf16x8 fy[2];
+      for (int n = 0; n < 2; ++n) fy0[n] = read_tr_pair(ys, yoff[0][n], yoff[0][n] + 16 * 128);
 #pragma unroll
-        for (int n = 0; n < 2; ++n) fy[n] = read_tr_pair(ys, yoff[k][n], yoff[k][n] + 16 * 128);
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-          const int o = xoff[t][k];
-          const bf16x8 fx = read_tr_pair(xring, o, (o + 16 * 128) & (XBYTES - 1));          // fsw(row + 16) == fsw(row)
-          xoff[t][k] = (o + PK * 128) & (XBYTES - 1);                                         // next stage: 64 rows further round the ring
-#pragma unroll
-          for (int n = 0; n < 2; ++n) acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[n], fx, acc[t][n], 0, 0, 0);
-        }
+      for (int t = 0; t < 9; ++t) {
+        const int o = xoff[t][0];
+        fx0[t] = read_tr_pair(xring, o, (o + 16 * 128) & (XBYTES - 1));                     // fsw(row + 16) == fsw(row)
+        xoff[t][0] = (o + PK * 128) & (XBYTES - 1);                                         // next stage: 64 rows further round the ring
       }
+#pragma unroll
+      for (int n = 0; n < 2; ++n) fy1[n] = read_tr_pair(ys, yoff[1][n], yoff[1][n] + 16 * 128);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int o = xoff[t][1];
+        fx1[t] = read_tr_pair(xring, o, (o + 16 * 128) & (XBYTES - 1));
+        xoff[t][1] = (o + PK * 128) & (XBYTES - 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);                   // (hipcc would sink the reads back in front of their consumers)
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy0[n], fx0[t], acc[t][n], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy1[n], fx1[t], acc[t][n], 0, 0, 0);
     }
     if (++cs == NS) cs = 0;
   }

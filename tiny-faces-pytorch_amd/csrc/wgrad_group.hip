@@ -181,6 +181,140 @@ __global__ void __launch_bounds__(256, 2) wgrad_group_kernel(const GpK a) {
     }
 }
 
+
+// ---- the fast form (r4b): every problem has 128-multiples of channels and the pixel count is a multiple of NS x 32.
+// The SQ pass over the generic kernel above (profiles/r04_wgrad_group.txt) says where its time goes: matrix pipe busy 34 % of a wave's cycles,
+// wave ACTIVE (issuing) 50 %, 742 cycles per 32-pixel stage against 256 of MFMA -- one wave per SIMD, ~100 non-MFMA instructions per stage
+// (64-bit source pointers selected against the zero page and advanced per lane, ring-slot arithmetic on the 8 fragment addresses, M0
+// juggling), issued in a burst BEHIND the 16 back-to-back MFMAs instead of underneath them.  Here:
+//   * the DMA addresses are a SCALAR base (advanced with two SALU instructions per operand and stage) + a loop-invariant 32-bit lane
+//     offset (`global_load_lds_dwordx4 voffset, s[base]`): no per-lane address arithmetic, no zero-page select (full tiles only; the
+//     stages issued past the end re-read the last one into slots nobody consumes);
+//   * the loop is unrolled over the ring (NS steps per trip), so every LDS address -- fragment reads and DMA destinations -- is a
+//     loop-invariant register plus an immediate;
+//   * each MFMA is followed by one fragment read of the NEXT stage (sched_group_barrier pairs): the LDS latency and the issue slots of the
+//     reads hide under the matrix pipe of the same wave.
+template <int NS>
+__global__ void __launch_bounds__(256, NS <= 4 ? 2 : 1) wgrad_group_fast_kernel(const GpK a) {
+  static_assert(NS == 4 || NS == 8, "ring depth");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int logical;
+  {
+    const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  int pi = 0;
+  while (pi + 1 < a.nprob && logical >= a.p[pi + 1].tile0) ++pi;
+  const GpProb P = a.p[pi];
+  const int t = logical - P.tile0;
+  const int tco = t / P.nci, tci = t - tco * P.nci;
+  const int tid = threadIdx.x, lrow = tid >> 3, pslot = tid & 7;
+  const int ls = pslot ^ fsw(lrow);
+  // loop-invariant lane offsets (bytes) of this thread's 16-byte pieces: row lrow, logical slot ls of the two 64-channel halves
+  const uint32_t voy0 = (uint32_t)((lrow * P.lddy + ls * 8) * 2), voy1 = voy0 + 128u;
+  const uint32_t vox0 = (uint32_t)((lrow * P.ldx + ls * 8) * 2), vox1 = vox0 + 128u;
+  // scalar bases of the stage about to be issued, advanced by one 32-pixel stage per issue and clamped at the last stage
+  const char* ysb = P.dy + (size_t)tco * 256;
+  const char* xsb = P.x + (size_t)tci * 256;
+  const uint32_t ystep = (uint32_t)(GP_PK * P.lddy * 2), xstep = (uint32_t)(GP_PK * P.ldx * 2);
+  const int nst = a.M / GP_PK;
+  int issued = 0;
+  const uint32_t lds0 = tf::lds_addr_uniform(smem + (tid & ~63) * 16);
+  auto issue = [&](int slot) {
+    const uint32_t st = lds0 + (uint32_t)(slot * GP_STAGE);
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %7\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %5\n\t"
+        "s_mov_b32 m0, %8\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %2, %5\n\t"
+        "s_mov_b32 m0, %9\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %3, %6\n\t"
+        "s_mov_b32 m0, %10\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %4, %6\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voy0), "v"(voy1), "v"(vox0), "v"(vox1), "s"(ysb), "s"(xsb), "s"(st), "s"(st + GP_SUB), "s"(st + 2 * GP_SUB), "s"(st + 3 * GP_SUB)
+        : "memory");
+    if (++issued < nst) { ysb += ystep; xsb += xstep; }       // (scalar; past the end: the last stage again, into a slot nobody reads)
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int wave = tid >> 6, wco = wave & 1, wci = wave >> 1;
+  const int l = tid & 63, li = l & 15, lg = l >> 4;
+  // fragment bases: slot 0, operand sub-tile of this wave; everything else is an immediate (NS = 8: slots 4-7 through a second set of
+  // registers 64 KiB further, the DS offset field has 16 bits)
+  const char* yb[4]; const char* xb[4];
+  {
+    const int row = lg * 4 + (li >> 2), fs = (li & 3) >> 1, fhalf = (li & 1) << 3;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const int o = row * 128 + (((2 * n + fs) ^ fsw(row)) << 4) + fhalf;
+      yb[n] = smem + wco * GP_SUB + o; xb[n] = smem + 2 * GP_SUB + wci * GP_SUB + o;
+    }
+  }
+  auto read = [&](Frags& f, int slot) {
+    const int so = slot * GP_STAGE;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(yb[n] + so));
+      const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(yb[n] + so + 16 * 128));
+      f.y[n] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(xb[m] + so));
+      const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(xb[m] + so + 16 * 128));
+      f.x[m] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+  };
+
+#pragma unroll
+  for (int j = 0; j < NS - 1; ++j) issue(j);
+  wait_vm<GP_L*(NS - 2)>();
+  __builtin_amdgcn_s_barrier();
+  Frags fa, fb;
+  read(fa, 0);
+  // step j of a trip (stage st = trip * NS + j): the fragments of stage st are in `cur`; stage st+1 must have landed -> barrier ->
+  // DMA of stage st + NS - 1 into the slot stage st-1 left -> reads of stage st+1 into `nxt`, one behind each MFMA of stage st
+  auto step = [&](Frags& cur, Frags& nxt, int j) {
+    wait_vm<GP_L*(NS - 3)>();
+    __builtin_amdgcn_s_barrier();
+    issue((j + NS - 1) % NS);
+    read(nxt, (j + 1) % NS);
+    mma_frags(acc, cur);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // one MFMA ...
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // ... one fragment read of the next stage
+    }
+  };
+  for (int trip = 0; trip < nst / NS; ++trip) {
+#pragma unroll
+    for (int j = 0; j < NS; j += 2) { step(fa, fb, j); step(fb, fa, j + 1); }
+  }
+  wait_vm<0>();
+
+  const int co0 = tco * 128, ci0 = tci * 128;
+#pragma unroll
+  for (int n = 0; n < 4; ++n)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float* drow = P.dw + (size_t)(co0 + wco * 64 + n * 16 + lg * 4 + r) * P.dw_ld + ci0 + wci * 64 + li;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) drow[m * 16] = acc[n][m][r];
+    }
+}
+
 }  // namespace
 
 // n pointwise problems (1x1, stride 1, pad 0, bf16, no prologue, all with the same pixel count) in one launch; dw is OVERWRITTEN.
@@ -204,18 +338,31 @@ int tf_wgrad_pw_group_launch(const tf_wgrad_args* A, int n, hipStream_t stream) 
     bytes += ((double)k.M * q.Cout + (double)k.M * q.Cin) * 2 + (double)q.Cout * q.Cin * 4;
   }
   k.ntiles = tiles;
-  // ring depth: 4 (64 KiB per block: two blocks fit a CU beside nothing, one beside the data-gradient chain's kernels) or 5
-  static const int ns = [] { const char* e = getenv("TINYFACES_WGRADG_NS"); const int v = e ? atoi(e) : 4; return v == 5 ? 5 : 4; }();
-  const size_t lds = (size_t)ns * GP_STAGE;
+  bool full = k.M % GP_PK == 0;
+  for (int i = 0; i < n; ++i) full = full && A[i].Cout % 128 == 0 && A[i].Cin % 128 == 0;
+  // Measured on the layer-3 group of eight (256 tiles, M = 12 288; profiles/r04_wgrad_group.txt): generic kernel 161 us with a 4-deep ring,
+  // 147 us with 8; fast kernel 148 / 136 us (4 / 8 slots) = 0.30 of the bf16 MFMA peak.  What bounds it is the ISSUE of the LDS-DMA itself:
+  // a 1 KiB piece stalls the issuing wave ~100 cycles (MI355X_MICROARCH.md: 60-185) and a 128 x 128 x 32 stage is four pieces per wave
+  // against 256 cycles of MFMA, one wave per SIMD -- the matrix pipe idles while its only wave feeds the DMA queue (SQ pass: MFMA busy
+  // 38 %, issue-stalled 44 %).  The step does not see the difference any more (A/B 1177.7 / 1177.7 img/s): the second stream is off the
+  // critical path since the grouping.
+  const size_t lds = (size_t)4 * GP_STAGE;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_group_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_group_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_group_fast_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_group_fast_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   // kind 18 = grouped pointwise weight gradient (bench.py tables); the GEMM view is the SUM over the group
   tf::ProfScope prof(18, flops, bytes, stream, k.M, A[0].Cout, A[0].Cin, 1, 2, 0, -1.0, true);
-  if (ns == 5) TF_LAUNCH_TIMED((wgrad_group_kernel<5>), dim3(tiles), dim3(256), lds, stream, k);
-  else TF_LAUNCH_TIMED((wgrad_group_kernel<4>), dim3(tiles), dim3(256), lds, stream, k);
+  static const int fast_ns = [] { const char* e = getenv("TINYFACES_WGRADG_FAST"); return e ? atoi(e) : 8; }();      // 0: the generic kernel (A/B); 4 / 8: ring depth of the fast one
+  if (full && fast_ns == 4 && (k.M / GP_PK) % 4 == 0) {
+    TF_LAUNCH_TIMED((wgrad_group_fast_kernel<4>), dim3(tiles), dim3(256), (size_t)4 * GP_STAGE, stream, k);
+  } else if (full && fast_ns == 8 && (k.M / GP_PK) % 8 == 0) {
+    TF_LAUNCH_TIMED((wgrad_group_fast_kernel<8>), dim3(tiles), dim3(256), (size_t)8 * GP_STAGE, stream, k);
+  } else {
+    TF_LAUNCH_TIMED((wgrad_group_kernel<4>), dim3(tiles), dim3(256), lds, stream, k);       // ragged shapes: zero-page selects, 64 KiB ring
+  }
   return hipGetLastError() == hipSuccess ? TF_OK : TF_ERR_LAUNCH;
 }
