@@ -162,8 +162,16 @@ __device__ __forceinline__ void dma16(const void* gsrc, void* lds_wave_base) {
 // MMA = 16: 16x16 fragments (fp32: 16x16x4, bf16/fp16: 16x16x32), up to five blocks of waves per SIMD;
 // MMA = 32: 32x32x16 fragments (bf16/fp16), accumulators of a 64 x 64 wave tile = 64 registers -> two waves per SIMD
 //           (__launch_bounds__(256, 2): up to 256 VGPR+AGPR per lane, no spills; profiles/r02*_kernel_resources.txt)
-template <typename T, int BM, int BN, int NS, int KIND, int MMA = 16>
-__global__ void __launch_bounds__(256, MMA == 32 ? 2 : (NS == 1 && BM == 128 ? 4 : 5)) conv_dma_kernel(const DmaK a) {
+// EPIC (r4): -1 = the epilogue flags are read at run time (a.epi); >= 0 = they are THIS compile-time constant.  Every 16x16-fragment
+// instantiation of rounds 1-3 spilled (12-18 VGPRs, 20-52 B of scratch per lane, profiles/r03_kernel_resources.txt) because the generic
+// epilogue keeps the coefficient vectors of all its modes alive (affine 16 + mask 16 + statistic shift 8 registers) next to the prefetched
+// residual / mask operands (32) and the accumulators; a training step uses three flag sets on 90 % of its launches (STATS;
+// MASK | STATS2; RES | MASK2 | STATS3), which get an instantiation each for the hot pointwise tiles: dead modes fold away.
+template <typename T, int BM, int BN, int NS, int KIND, int MMA = 16, int EPIC = -1>
+__global__ void __launch_bounds__(256, MMA == 32 ? 2 : (NS == 1 && BM == 128 ? (EPIC == (TF_EPI_RES | TF_EPI_MASK2 | TF_EPI_STATS3) ? 3 : 4) : 5)) conv_dma_kernel(const DmaK a) {
+  // (the hand-over instantiation of the ring-less 128 x 64 tile keeps three operand tiles in registers: 3 blocks per CU without spills --
+  //  768 resident blocks, exactly two rounds of the 1536 tiles of a layer-3 launch -- instead of 4 with 8 spilled registers)
+  const int epi_flags = EPIC >= 0 ? EPIC : a.epi;
   constexpr int KCH = MmaD<T>::KCH;
   constexpr int EPS = tf::Elem<T>::kPer16B;
   constexpr int XR = BM / 32, WR = BN / 32;
@@ -233,16 +241,23 @@ __global__ void __launch_bounds__(256, MMA == 32 ? 2 : (NS == 1 && BM == 128 ? 4
   // whole HBM latency exposed once per block.  Request them NOW: they travel while the K stages are DMA-ed and multiplied.
   // (Older loads retire first, so the counted vmcnt waits of the K loop are unaffected.)
   constexpr bool PREF = (NS == 1 && KIND == 1);      // the pointwise ring-less variants: every hot instance (the gather variants would spill)
+  // r4, hand-over instantiation (RES | MASK2 | STATS3 known at compile time): two of its three epilogue operands are COLD -- aux2 (the
+  // previous block's output y) and aux3 (its conv3 output) were written in the forward pass -- and the third, the residual gradient, was
+  // written a few launches ago and is cache-resident.  The early requests go to the cold pair; rounds 1-3 prefetched aux + aux2 and
+  // paid the HBM latency of aux3 once per epilogue pass.
+  constexpr bool PF_COLD3 = PREF && EPIC >= 0 && (EPIC & TF_EPI_STATS3) && (EPIC & TF_EPI_RES) && !(EPIC & (TF_EPI_MASK | TF_EPI_STATS2 | TF_EPI_JOIN));
   constexpr int P_CPR = BN / EPS, P_RPP = 256 / P_CPR, P_PASSES = BM / P_RPP;
   uint4 pf1[P_PASSES], pf2[P_PASSES];      // (the third operand, STATS3's / JOIN's aux3, stays a late load: registers)
   if constexpr (PREF) {
     const int pchunk = tid % P_CPR, prl = tid / P_CPR, pc0 = n0 + pchunk * EPS;
-    const bool w1 = a.epi & (TF_EPI_RES | TF_EPI_MASK | TF_EPI_STATS2), w2 = a.epi & (TF_EPI_JOIN | TF_EPI_MASK2);
+    const bool w1 = epi_flags & (TF_EPI_RES | TF_EPI_MASK | TF_EPI_STATS2), w2 = epi_flags & (TF_EPI_JOIN | TF_EPI_MASK2);
 #pragma unroll
     for (int ps = 0; ps < P_PASSES; ++ps) {
       const int p = m0 + prl + ps * P_RPP;
       const bool ok = p < a.M && pc0 < a.ldy;
       const size_t o = (orow(ok ? p : 0) * a.ldy + (ok ? pc0 : 0)) * sizeof(T);
+      if constexpr (PF_COLD3) pf1[ps] = ok ? *reinterpret_cast<const uint4*>(a.aux3 + o) : make_uint4(0, 0, 0, 0);
+      else
       pf1[ps] = (ok && w1) ? *reinterpret_cast<const uint4*>(a.aux + o) : make_uint4(0, 0, 0, 0);
       pf2[ps] = (ok && w2) ? *reinterpret_cast<const uint4*>(a.aux2 + o) : make_uint4(0, 0, 0, 0);
     }
@@ -421,15 +436,15 @@ __global__ void __launch_bounds__(256, MMA == 32 ? 2 : (NS == 1 && BM == 128 ? 4
 #pragma unroll
   for (int j = 0; j < EPS; ++j) { es[j] = 1.f; eh[j] = 0.f; ms[j] = 0.f; mh[j] = 0.f; s1[j] = 0.f; s2[j] = 0.f; sft[j] = 0.f; }
   if (cok) {
-    if ((a.epi & TF_EPI_STATS) && a.stat_shift) {    // sums of (x - shift), (x - shift)^2: see tf_conv_args.stat_shift
+    if ((epi_flags & TF_EPI_STATS) && a.stat_shift) {    // sums of (x - shift), (x - shift)^2: see tf_conv_args.stat_shift
 #pragma unroll
       for (int j = 0; j < EPS; ++j) sft[j] = a.stat_shift[c0 + j];
     }
-    if (a.epi & TF_EPI_AFFINE) {
+    if (epi_flags & TF_EPI_AFFINE) {
 #pragma unroll
       for (int j = 0; j < EPS; ++j) { es[j] = a.epi_scale[c0 + j]; eh[j] = a.epi_shift[c0 + j]; }
     }
-    if (a.epi & TF_EPI_MASK) {
+    if (epi_flags & TF_EPI_MASK) {
 #pragma unroll
       for (int j = 0; j < EPS; ++j) { ms[j] = a.mask_scale[c0 + j]; mh[j] = a.mask_shift[c0 + j]; }
     }
@@ -444,59 +459,59 @@ __global__ void __launch_bounds__(256, MMA == 32 ? 2 : (NS == 1 && BM == 128 ? 4
       const f32x4 t = *reinterpret_cast<const f32x4*>(stg + row * PITCH + chunk * EPS + j);
       v[j] = t[0]; v[j + 1] = t[1]; v[j + 2] = t[2]; v[j + 3] = t[3];
     }
-    if ((a.epi & TF_EPI_STATS) && p < a.M) {        // (rows >= M hold exact zeros, but not after the shift)
+    if ((epi_flags & TF_EPI_STATS) && p < a.M) {        // (rows >= M hold exact zeros, but not after the shift)
 #pragma unroll
       for (int j = 0; j < EPS; ++j) { const float t = v[j] - sft[j]; s1[j] += t; s2[j] += t * t; }
     }
     if (p < a.M && cok) {
       const size_t o = (orow(p) * a.ldy + c0) * sizeof(T);
       float ax[EPS];
-      if (a.epi & (TF_EPI_RES | TF_EPI_MASK | TF_EPI_STATS2)) {
-        if constexpr (PREF) tf::unpack16<T>(pf1[ps], ax); else tf::unpack16<T>(*reinterpret_cast<const uint4*>(a.aux + o), ax);
+      if (epi_flags & (TF_EPI_RES | TF_EPI_MASK | TF_EPI_STATS2)) {
+        if constexpr (PREF && !PF_COLD3) tf::unpack16<T>(pf1[ps], ax); else tf::unpack16<T>(*reinterpret_cast<const uint4*>(a.aux + o), ax);
       }
-      if (a.epi & TF_EPI_AFFINE) {
+      if (epi_flags & TF_EPI_AFFINE) {
 #pragma unroll
         for (int j = 0; j < EPS; ++j) v[j] = v[j] * es[j] + eh[j];
       }
-      if (a.epi & TF_EPI_RES) {
+      if (epi_flags & TF_EPI_RES) {
 #pragma unroll
         for (int j = 0; j < EPS; ++j) v[j] += ax[j];
       }
-      if (a.epi & TF_EPI_MASK) {
+      if (epi_flags & TF_EPI_MASK) {
 #pragma unroll
         for (int j = 0; j < EPS; ++j) v[j] = (ax[j] * ms[j] + mh[j] > 0.f) ? v[j] : 0.f;
       }
-      if (a.epi & TF_EPI_JOIN) {
+      if (epi_flags & TF_EPI_JOIN) {
         float y2[EPS], g3[EPS];
         if constexpr (PREF) tf::unpack16<T>(pf2[ps], y2); else tf::unpack16<T>(*reinterpret_cast<const uint4*>(a.aux2 + o), y2);
         tf::unpack16<T>(*reinterpret_cast<const uint4*>(a.aux3 + o), g3);
 #pragma unroll
         for (int j = 0; j < EPS; ++j) v[j] += (y2[j] > 0.f) ? g3[j] : 0.f;
       }
-      if (a.epi & TF_EPI_MASK2) {
+      if (epi_flags & TF_EPI_MASK2) {
         float y2[EPS];
         if constexpr (PREF) tf::unpack16<T>(pf2[ps], y2); else tf::unpack16<T>(*reinterpret_cast<const uint4*>(a.aux2 + o), y2);
 #pragma unroll
         for (int j = 0; j < EPS; ++j) v[j] = (y2[j] > 0.f) ? v[j] : 0.f;
       }
-      if (a.epi & TF_EPI_RELU) {
+      if (epi_flags & TF_EPI_RELU) {
 #pragma unroll
         for (int j = 0; j < EPS; ++j) v[j] = fmaxf(v[j], 0.f);
       }
-      if (a.epi & TF_EPI_STATS2) {
+      if (epi_flags & TF_EPI_STATS2) {
 #pragma unroll
         for (int j = 0; j < EPS; ++j) { s1[j] += v[j]; s2[j] += v[j] * ax[j]; }
       }
-      if (a.epi & TF_EPI_STATS3) {
+      if (epi_flags & TF_EPI_STATS3) {
         float x3[EPS];
-        tf::unpack16<T>(*reinterpret_cast<const uint4*>(a.aux3 + o), x3);
+        if constexpr (PF_COLD3) tf::unpack16<T>(pf1[ps], x3); else tf::unpack16<T>(*reinterpret_cast<const uint4*>(a.aux3 + o), x3);
 #pragma unroll
         for (int j = 0; j < EPS; ++j) { s1[j] += v[j]; s2[j] += v[j] * x3[j]; }
       }
       *reinterpret_cast<uint4*>(a.y + o) = tf::pack16<T>(v);
     }
   }
-  if (a.epi & (TF_EPI_STATS | TF_EPI_STATS2 | TF_EPI_STATS3)) {       // block-uniform: column sums of the tile
+  if (epi_flags & (TF_EPI_STATS | TF_EPI_STATS2 | TF_EPI_STATS3)) {       // block-uniform: column sums of the tile
     // lanes sharing a chunk inside a wave differ in the lane bits >= log2(CPR)
     if (a.dbg & 16) {                                // A/B knob (TF_CONV_DBG=16): the ds_bpermute form
 #pragma unroll
@@ -516,7 +531,7 @@ __global__ void __launch_bounds__(256, MMA == 32 ? 2 : (NS == 1 && BM == 128 ? 4
       for (int j = 0; j < EPS; ++j) { red[(wave * 2 + 0) * BN + lane * EPS + j] = s1[j]; red[(wave * 2 + 1) * BN + lane * EPS + j] = s2[j]; }
     }
     __syncthreads();
-    if ((a.epi & TF_EPI_STATS) && a.stat_shift && a.stat_shift_out && mt == 0) {   // the shift this launch used, once per channel
+    if ((epi_flags & TF_EPI_STATS) && a.stat_shift && a.stat_shift_out && mt == 0) {   // the shift this launch used, once per channel
       for (int cl = tid; cl < BN; cl += 256)
         if (n0 + cl < a.ldy) a.stat_shift_out[n0 + cl] = a.stat_shift[n0 + cl];
     }
@@ -620,7 +635,26 @@ int launch_kind(const tf_conv_args* A, hipStream_t stream, int pcls = -1) {
       const hipError_t e = (A->epi & TF_EPI_RES) ? hipMemcpyAsync(A->y, A->aux, ybytes, hipMemcpyDeviceToDevice, stream) : hipMemsetAsync(A->y, 0, ybytes, stream);
       if (e != hipSuccess) return TF_ERR_LAUNCH;
     }
-    TF_LAUNCH_TIMED((conv_dma_kernel<T, BM, BN, NS, KIND, MMA>), dim3(mtiles * k.ntiles), dim3(256), lds, stream, k);
+    // r4: the three flag sets of a training step get instantiations of their own for the hot pointwise bf16 tiles (EPIC, see the kernel)
+    constexpr bool SPEC = std::is_same<T, tf::bf16_t>::value && KIND == 1 && MMA == 16 && ((BM == 128 && BN == 64 && NS == 1) || (BM == 64 && BN == 64 && NS <= 3));
+    static const bool spec_off = getenv("TINYFACES_EPI_SPEC_OFF") != nullptr;       // A/B knob
+    const dim3 grid(mtiles * k.ntiles);
+    bool done = false;
+    if constexpr (SPEC) {
+      if (!spec_off && !k.pro) {
+        auto go = [&](auto epic) {
+          constexpr int E = decltype(epic)::value;
+          static bool set = false;
+          if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<T, BM, BN, NS, KIND, MMA, E>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+          TF_LAUNCH_TIMED((conv_dma_kernel<T, BM, BN, NS, KIND, MMA, E>), grid, dim3(256), lds, stream, k);
+          done = true;
+        };
+        if (A->epi == TF_EPI_STATS) go(std::integral_constant<int, TF_EPI_STATS>{});
+        else if (A->epi == (TF_EPI_MASK | TF_EPI_STATS2)) go(std::integral_constant<int, TF_EPI_MASK | TF_EPI_STATS2>{});
+        else if (A->epi == (TF_EPI_RES | TF_EPI_MASK2 | TF_EPI_STATS3)) go(std::integral_constant<int, TF_EPI_RES | TF_EPI_MASK2 | TF_EPI_STATS3>{});
+      }
+    }
+    if (!done) TF_LAUNCH_TIMED((conv_dma_kernel<T, BM, BN, NS, KIND, MMA>), grid, dim3(256), lds, stream, k);
   }
   return hipGetLastError() == hipSuccess ? TF_OK : TF_ERR_LAUNCH;
 }

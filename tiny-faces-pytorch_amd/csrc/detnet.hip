@@ -307,6 +307,9 @@ struct Ctx {
   std::vector<tf_pack_job> jobs;
   std::vector<tf_pack2_job> jobs2;
   hipStream_t side = nullptr;                 // weight gradients run here, concurrently with the data-gradient chain
+  hipStream_t gside = nullptr;                // r4: the GROUPED weight gradients of layer 3 (two launches of 150-300 us per group): a queue of their own, so that the
+                                              // per-block gradients of layer 3.0 / layers 1-2 -- whose completion the chain waits for two blocks later (parity buffers) --
+                                              // do not queue up behind a group
   std::vector<hipEvent_t>* events = nullptr; size_t ev_next = 0;
   hipEvent_t next_event() {
     if (ev_next == events->size()) { hipEvent_t e; if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { chk(TF_ERR_LAUNCH); return nullptr; } events->push_back(e); }
@@ -319,12 +322,15 @@ struct Ctx {
   hipEvent_t pending = nullptr;
   static bool kernel_events() { static const bool on = getenv("TINYFACES_FORK_BY_RECORD") == nullptr; return on; }
   void arm_fork() { if (!side || !kernel_events()) return; pending = next_event(); if (pending) tf::set_next_stop_event(pending); }
-  void fork_armed() {
+  void fork_armed(hipStream_t to = nullptr) {
     if (!side) return;
+    if (!to) to = side;
     if (tf::take_next_stop_event()) pending = nullptr;     // armed but no kernel took it (the producer refused its arguments): plain fork
-    if (pending) { (void)hipStreamWaitEvent(side, pending, 0); pending = nullptr; }
-    else fork();
+    if (pending) { (void)hipStreamWaitEvent(to, pending, 0); pending = nullptr; }
+    else { hipEvent_t e = next_event(); if (e) { (void)hipEventRecord(e, stream); (void)hipStreamWaitEvent(to, e, 0); } }
   }
+  hipStream_t gstream() const { return gside ? gside : wstream(); }
+  hipEvent_t mark(hipStream_t s) { if (!side || !s) return nullptr; hipEvent_t e = next_event(); if (e) (void)hipEventRecord(e, s); return e; }
   // everything enqueued on `stream` so far becomes a dependency of what is enqueued on `side` next
   void fork() { if (!side) return; hipEvent_t e = next_event(); if (e) { (void)hipEventRecord(e, stream); (void)hipStreamWaitEvent(side, e, 0); } }
   hipEvent_t mark_side() { if (!side) return nullptr; hipEvent_t e = next_event(); if (e) (void)hipEventRecord(e, side); return e; }
@@ -461,9 +467,11 @@ extern "C" size_t tf_detnet_param_region_bytes(int dtype, int nout, int training
 // (hipExtStreamCreateWithCUMask: 603 img/s whatever the mask) looked the same.  TINYFACES_SIDE_PRIO_LOW=1 brings the low priority back.
 static bool g_force_single = false;      // tf_detnet_set_dual_stream(0): everything on the caller's stream
 namespace {
-hipStream_t side_stream() {               // one per device (a process normally drives one GPU; the binding may load before set_device)
-  static hipStream_t streams[64] = {};
-  static bool tried_dev[64] = {};
+hipStream_t side_stream(int which = 0) {  // one per device and role (a process normally drives one GPU; the binding may load before set_device)
+  static hipStream_t streams2[2][64] = {};
+  static bool tried_dev2[2][64] = {};
+  hipStream_t* streams = streams2[which & 1];
+  bool* tried_dev = tried_dev2[which & 1];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
   hipStream_t& g_side = streams[dev];
@@ -732,6 +740,10 @@ static void record_grad_events(int block, hipStream_t s, int& rc) {
     }
   if (registered && g_grad_cb) g_grad_cb(block, (void*)s, g_grad_cb_user);
 }
+static bool grad_event_registered(int block) {
+  for (const auto& e : g_grad_events) if (e.first == block) return true;
+  return false;
+}
 // 1 = weight gradients on a second stream (default), 0 = everything on the caller's stream (A/B + race tests)
 extern "C" int tf_detnet_set_dual_stream(int on) { g_force_single = !on; return TF_OK; }
 
@@ -749,6 +761,11 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
   if (!g_single_env && !g_force_single) {
     hipStream_t g_side = side_stream();
     c.side = g_side; c.events = &g_events;
+    // r4, measured NEGATIVE, opt-in (TINYFACES_GROUP_STREAM=1): the grouped launches on a third queue, so that the per-block gradients of
+    // layer 3.0 / layers 1-2 do not queue up behind a group: 1170 / 1164 img/s against 1177 / 1181 on the second stream (A/B on one box,
+    // main-queue idle time of the backward pass 508 instead of 379 us): a third busy queue costs more than the queueing it removes.
+    static const bool gstream_on = getenv("TINYFACES_GROUP_STREAM") != nullptr;
+    if (g_side && gstream_on) c.gside = side_stream(1);
   }
   tf_conv_args a;
   const int M3 = N * P.H3 * P.W3, M4 = N * P.H4 * P.W4;
@@ -830,14 +847,17 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
     if (!skip) {
       // the 3x3 group first: 16 tiles per problem = half a machine for a group of eight; the pointwise launch behind it fills the CUs its
       // tail leaves (both are enqueued behind the same fork)
-      int rc = tf_conv2d_wgrad_group(pend_c3.data(), (int)pend_c3.size(), c.wstream());
-      if (rc == TF_ERR_UNSUPPORTED) for (const tf_wgrad_args& w : pend_c3) c.chk(tf_conv2d_wgrad(&w, c.wstream()));      // (atomics into the zeroed gradient)
+      int rc = tf_conv2d_wgrad_group(pend_c3.data(), (int)pend_c3.size(), c.gstream());
+      if (rc == TF_ERR_UNSUPPORTED) for (const tf_wgrad_args& w : pend_c3) c.chk(tf_conv2d_wgrad(&w, c.gstream()));      // (atomics into the zeroed gradient)
       else c.chk(rc);
-      rc = tf_conv2d_wgrad_group(pend_pw.data(), (int)pend_pw.size(), c.wstream());
-      if (rc == TF_ERR_UNSUPPORTED) for (const tf_wgrad_args& w : pend_pw) c.chk(tf_conv2d_wgrad(&w, c.wstream()));
+      rc = tf_conv2d_wgrad_group(pend_pw.data(), (int)pend_pw.size(), c.gstream());
+      if (rc == TF_ERR_UNSUPPORTED) for (const tf_wgrad_args& w : pend_pw) c.chk(tf_conv2d_wgrad(&w, c.gstream()));
       else c.chk(rc);
     }
-    for (int blk : pend_blocks) record_grad_events(blk, c.wstream(), c.rc);
+    // a gradient-ready event of a grouped block promises "every gradient of the blocks >= it, and of the heads": the heads and layer3.x
+    // per-block launches live on the second stream, so the group's stream first orders itself behind that stream's position
+    if (c.gside && !pend_blocks.empty()) { hipEvent_t e = c.mark(c.side); if (e) (void)hipStreamWaitEvent(c.gside, e, 0); }
+    for (int blk : pend_blocks) record_grad_events(blk, c.gstream(), c.rc);
     pend_pw.clear(); pend_c3.clear(); pend_blocks.clear();
   };
   // ---- bottlenecks in reverse
@@ -935,7 +955,7 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
     if (grouped) {
       pend_pw.push_back(wgrad_args(c, B.c1, pl, N, b.Hin, b.Win, b.Hin, b.Win, yin, B.cin, U1, pl));
       pend_blocks.push_back(i);
-      if (closes_group) { c.fork_armed(); flush_group(); }
+      if (closes_group) { c.fork_armed(c.gstream()); flush_group(); }
     } else if (fork_each) { c.fork_armed(); if (late) { wg3(); wg2(); } wg1(); }
     // (10) gradient w.r.t. the block input -> Gnext.  Fused flow: the conv that completes it also applies the ReLU mask of
     //      the previous block's output (MASK2 with aux2 = yin) and, unless that block has a downsample branch, accumulates
@@ -976,7 +996,15 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
     }
     if (!grouped) {
       block_done[i] = c.mark_side();
-      record_grad_events(i, c.wstream(), c.rc);      // everything up to here on that stream: the weight/BN gradients of blocks >= i and of the heads
+      // everything up to here: the weight / BN gradients of blocks >= i and of the heads.  With a group stream they are spread over two
+      // queues: the event goes to the group stream, ordered behind the second stream's position (never the other way round: the second
+      // stream must not wait for a group)
+      if (c.gside && grad_event_registered(i)) {
+        hipEvent_t e = c.mark(c.side); if (e) (void)hipStreamWaitEvent(c.gside, e, 0);
+        record_grad_events(i, c.gside, c.rc);
+      } else {
+        record_grad_events(i, c.wstream(), c.rc);
+      }
     }                                                // (grouped blocks: no parity buffer to protect; their events fire in flush_group)
     void* t = Gcur; Gcur = Gnext; Gnext = t;
   }
@@ -996,6 +1024,7 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
     wgrad(c, s, 64, 1, 1, M1, 1, M1, P.col, kStemK, gz, 64, nullptr, 147, 1, 147);
   }
   c.wait_on_main(c.mark_side());           // join: the caller's stream sees every weight gradient
+  if (c.gside) c.wait_on_main(c.mark(c.gside));
   record_grad_events(-1, c.stream, c.rc);
   if (hipGetLastError() != hipSuccess && c.rc == TF_OK) c.rc = TF_ERR_LAUNCH;
   return c.rc;
