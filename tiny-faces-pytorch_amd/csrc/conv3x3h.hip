@@ -82,8 +82,11 @@ __device__ __forceinline__ void dma16(const void* gsrc, void* lds_wave_base) {
 // points of each K stage in LDS and dumps them after the loop, and the TINYFACES_CONV3H_DBG ablation bits (1: no steady-state
 // DMA, 2: no LDS reads / MFMAs) are honoured; never launched unless a trace buffer was registered.
 constexpr int TRACE_BYTES = 8 * 64 * 8 * 8;
-template <typename T, bool TRACE>
+// EPIC (r4): the epilogue flag set as a compile-time constant (-1: read a.epi), like conv_dma_kernel's: the three sets a training step and
+// an evaluation forward use get their own instantiation, the dead modes of the generic epilogue fold away.
+template <typename T, bool TRACE, int EPIC = -1>
 __global__ void __launch_bounds__(NT, 2) conv3x3h_kernel(const HK a) {
+  const int epi_flags = EPIC >= 0 ? EPIC : a.epi;
   typedef typename Frag<T>::t frag;
   constexpr int EPS = 8, TRACE_AT = RING_BYTES;       // (the stamps are dumped before the epilogue overlays them)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -278,15 +281,15 @@ __global__ void __launch_bounds__(NT, 2) conv3x3h_kernel(const HK a) {
 #pragma unroll
   for (int j = 0; j < EPS; ++j) { es[j] = 1.f; eh[j] = 0.f; ms[j] = 0.f; mh[j] = 0.f; s1[j] = 0.f; s2[j] = 0.f; sft[j] = 0.f; }
   if (cok) {
-    if ((a.epi & TF_EPI_STATS) && a.stat_shift) {    // sums of (x - shift), (x - shift)^2: see tf_conv_args.stat_shift
+    if ((epi_flags & TF_EPI_STATS) && a.stat_shift) {    // sums of (x - shift), (x - shift)^2: see tf_conv_args.stat_shift
 #pragma unroll
       for (int j = 0; j < EPS; ++j) sft[j] = a.stat_shift[ch0 + j];
     }
-    if (a.epi & TF_EPI_AFFINE) {
+    if (epi_flags & TF_EPI_AFFINE) {
 #pragma unroll
       for (int j = 0; j < EPS; ++j) { es[j] = a.epi_scale[ch0 + j]; eh[j] = a.epi_shift[ch0 + j]; }
     }
-    if (a.epi & TF_EPI_MASK) {
+    if (epi_flags & TF_EPI_MASK) {
 #pragma unroll
       for (int j = 0; j < EPS; ++j) { ms[j] = a.mask_scale[ch0 + j]; mh[j] = a.mask_shift[ch0 + j]; }
     }
@@ -308,47 +311,47 @@ __global__ void __launch_bounds__(NT, 2) conv3x3h_kernel(const HK a) {
                       *reinterpret_cast<const f32x4*>(stg + STG_FLOATS + row * PITCH + chunk8 * EPS + j);
       v[j] = t[0]; v[j + 1] = t[1]; v[j + 2] = t[2]; v[j + 3] = t[3];
     }
-    if (a.epi & TF_EPI_STATS) {
+    if (epi_flags & TF_EPI_STATS) {
 #pragma unroll
       for (int j = 0; j < EPS; ++j) { const float t = v[j] - sft[j]; s1[j] += t; s2[j] += t * t; }
     }
     const size_t o = ((((size_t)img * a.H + oh) * a.W + ow) * a.ldy + ch0) * sizeof(T);
     float ax[EPS];
-    if (a.epi & (TF_EPI_RES | TF_EPI_MASK | TF_EPI_STATS2)) tf::unpack16<T>(*reinterpret_cast<const uint4*>(a.aux + o), ax);
-    if (a.epi & TF_EPI_AFFINE) {
+    if (epi_flags & (TF_EPI_RES | TF_EPI_MASK | TF_EPI_STATS2)) tf::unpack16<T>(*reinterpret_cast<const uint4*>(a.aux + o), ax);
+    if (epi_flags & TF_EPI_AFFINE) {
 #pragma unroll
       for (int j = 0; j < EPS; ++j) v[j] = v[j] * es[j] + eh[j];
     }
-    if (a.epi & TF_EPI_RES) {
+    if (epi_flags & TF_EPI_RES) {
 #pragma unroll
       for (int j = 0; j < EPS; ++j) v[j] += ax[j];
     }
-    if (a.epi & TF_EPI_MASK) {
+    if (epi_flags & TF_EPI_MASK) {
 #pragma unroll
       for (int j = 0; j < EPS; ++j) v[j] = (ax[j] * ms[j] + mh[j] > 0.f) ? v[j] : 0.f;
     }
-    if (a.epi & TF_EPI_JOIN) {
+    if (epi_flags & TF_EPI_JOIN) {
       float y2[EPS], g3[EPS];
       tf::unpack16<T>(*reinterpret_cast<const uint4*>(a.aux2 + o), y2);
       tf::unpack16<T>(*reinterpret_cast<const uint4*>(a.aux3 + o), g3);
 #pragma unroll
       for (int j = 0; j < EPS; ++j) v[j] += (y2[j] > 0.f) ? g3[j] : 0.f;
     }
-    if (a.epi & TF_EPI_MASK2) {
+    if (epi_flags & TF_EPI_MASK2) {
       float y2[EPS];
       tf::unpack16<T>(*reinterpret_cast<const uint4*>(a.aux2 + o), y2);
 #pragma unroll
       for (int j = 0; j < EPS; ++j) v[j] = (y2[j] > 0.f) ? v[j] : 0.f;
     }
-    if (a.epi & TF_EPI_RELU) {
+    if (epi_flags & TF_EPI_RELU) {
 #pragma unroll
       for (int j = 0; j < EPS; ++j) v[j] = fmaxf(v[j], 0.f);
     }
-    if (a.epi & TF_EPI_STATS2) {
+    if (epi_flags & TF_EPI_STATS2) {
 #pragma unroll
       for (int j = 0; j < EPS; ++j) { s1[j] += v[j]; s2[j] += v[j] * ax[j]; }
     }
-    if (a.epi & TF_EPI_STATS3) {
+    if (epi_flags & TF_EPI_STATS3) {
       float x3[EPS];
       tf::unpack16<T>(*reinterpret_cast<const uint4*>(a.aux3 + o), x3);
 #pragma unroll
@@ -357,7 +360,7 @@ __global__ void __launch_bounds__(NT, 2) conv3x3h_kernel(const HK a) {
     *reinterpret_cast<uint4*>(a.y + o) = tf::pack16<T>(v);
   }
   if constexpr (TRACE) e_t[2] = __builtin_amdgcn_s_memtime();
-  if (a.epi & (TF_EPI_STATS | TF_EPI_STATS2 | TF_EPI_STATS3)) {       // block-uniform: column sums of the tile
+  if (epi_flags & (TF_EPI_STATS | TF_EPI_STATS2 | TF_EPI_STATS3)) {       // block-uniform: column sums of the tile
 #pragma unroll
     for (int j = 0; j < EPS; ++j) { s1[j] = tf::lane_group_sum<CPR>(s1[j]); s2[j] = tf::lane_group_sum<CPR>(s2[j]); }       // DPP / row swaps, no LDS crossbar
     __syncthreads();                                 // staging tile fully consumed
@@ -368,7 +371,7 @@ __global__ void __launch_bounds__(NT, 2) conv3x3h_kernel(const HK a) {
       for (int j = 0; j < EPS; ++j) { red[(wave * 2 + 0) * BN + lane * EPS + j] = s1[j]; red[(wave * 2 + 1) * BN + lane * EPS + j] = s2[j]; }
     }
     __syncthreads();
-    if ((a.epi & TF_EPI_STATS) && a.stat_shift && a.stat_shift_out && mt == 0) {
+    if ((epi_flags & TF_EPI_STATS) && a.stat_shift && a.stat_shift_out && mt == 0) {
       for (int cl = tid; cl < BN; cl += NT)
         if (n0 + cl < a.ldy) a.stat_shift_out[n0 + cl] = a.stat_shift[n0 + cl];
     }
@@ -410,14 +413,14 @@ int min_blocks() {
   return v;
 }
 
-template <typename T, bool TRACE>
+template <typename T, bool TRACE, int EPIC = -1>
 void launch_var(const HK& k, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3h_kernel<T, TRACE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3h_kernel<T, TRACE, EPIC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  TF_LAUNCH_TIMED((conv3x3h_kernel<T, TRACE>), dim3(k.mtiles * k.ntiles), dim3(NT), TRACE && RING_BYTES + TRACE_BYTES > LDS_BYTES ? RING_BYTES + TRACE_BYTES : LDS_BYTES, stream, k);
+  TF_LAUNCH_TIMED((conv3x3h_kernel<T, TRACE, EPIC>), dim3(k.mtiles * k.ntiles), dim3(NT), TRACE && RING_BYTES + TRACE_BYTES > LDS_BYTES ? RING_BYTES + TRACE_BYTES : LDS_BYTES, stream, k);
 }
 
 template <typename T>
@@ -440,7 +443,13 @@ int launch(const tf_conv_args* A, hipStream_t stream) {
   if (A->epi & TF_EPI_MASK2) bytes += M * A->Cout * es;
   if (A->epi & TF_EPI_STATS3) bytes += M * A->Cout * es;
   tf::ProfScope prof(A->dtype == TF_BF16 ? 6 : 7, 2.0 * M * A->Cout * Kt, bytes, stream, (int)M, A->Cout, k.Ktot, 9, A->mode, A->epi, -1.0, true);   // 6 = conv3x3h bf16, 7 = f16
-  if (g_trace) launch_var<T, true>(k, stream); else launch_var<T, false>(k, stream);
+  static const bool spec_off = getenv("TINYFACES_EPI_SPEC_OFF") != nullptr;       // A/B knob (shared with conv_dma)
+  if (g_trace) launch_var<T, true>(k, stream);
+  else if (spec_off) launch_var<T, false>(k, stream);
+  else if (A->epi == TF_EPI_STATS) launch_var<T, false, TF_EPI_STATS>(k, stream);                                           // training forward
+  else if (A->epi == (TF_EPI_MASK | TF_EPI_STATS2)) launch_var<T, false, TF_EPI_MASK | TF_EPI_STATS2>(k, stream);           // training data gradient
+  else if (A->epi == (TF_EPI_AFFINE | TF_EPI_RELU)) launch_var<T, false, TF_EPI_AFFINE | TF_EPI_RELU>(k, stream);           // evaluation (folded BN + ReLU)
+  else launch_var<T, false>(k, stream);
   return hipGetLastError() == hipSuccess ? TF_OK : TF_ERR_LAUNCH;
 }
 
