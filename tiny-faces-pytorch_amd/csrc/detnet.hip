@@ -166,16 +166,15 @@ struct Plan {                    // everything a forward carves; backward re-der
     void *a1, *a2;                   // relu(bn1(c1)), relu(bn2(c2)) materialised in training (operands of conv2/conv3 and of their weight gradients)
     void *w1, *w2, *w3, *wd;         // packed forward weights
     void *w1t, *w2t, *w3t, *wdt;     // packed data-gradient (transposed) weights, training only
-    void *gT1, *gT2, *gU1;           // r4, grouped weight gradients: this block's own g_c3 / g_c2 / g_c1 (alive until its group's launch)
+    void *gT1, *gT2, *gU1, *gT3;     // r4: this block's own g_c3 / g_c2 / g_c1 / downsample-branch gradient (alive until its weight gradients ran)
     BnBuf b1, b2, b3, bd;
   };
   std::vector<Blk> blk;
   void *w_h3, *w_h4, *w_h3t, *w_h4t, *s3, *s4; float *hbias3, *hbias4, *ones, *wup_diag;
-  float* partial; size_t partial_floats;
+  float *partial, *partial_b; size_t partial_floats;      // per-tile partial rows of the forward / backward pass (each behind its statistic region)
   float *stat_fwd, *stat_bwd; size_t stat_fwd_floats, stat_bwd_floats;   // per-BN statistic regions (fused finalize)
   // backward-only
   void *g3, *g4, *G0, *G1, *T4, *R3, *wt; float* dwp; size_t dwp_floats;
-  void *S1[2], *S2[2], *S3[2], *SD[2];   // per block parity: g_c3, g_c2, g_c1, g_d (read by the weight-gradient stream)   // gradient buffers (roles in tf_detnet_backward) + transposed-weight scratch
   int H3, W3, H4, W4;
   size_t total, param_bytes;
 };
@@ -188,8 +187,22 @@ void build_plan(Plan& P, Arena& ar, int dtype, int N, int H, int W, int nout, in
   P.dtype = dtype; P.N = N; P.H = H; P.W = W; P.nout = nout; P.training = training;
   P.H1 = down2(H); P.W1 = down2(W); P.H2 = down2(P.H1); P.W2 = down2(P.W1);
   const size_t M1 = (size_t)N * P.H1 * P.W1, M2 = (size_t)N * P.H2 * P.W2;
+  // rows of per-tile partial sums the unfolded (tf_set_stat_rows(0)) flow and colstats need: known from the shapes alone
   size_t max_partial = 0;
-  auto part = [&](size_t M, int C) { size_t t = ((M + 63) / 64) * 2 * (size_t)C; if (t > max_partial) max_partial = t; };
+  {
+    auto part = [&](size_t M, int C) { size_t t = ((M + 63) / 64) * 2 * (size_t)C; if (t > max_partial) max_partial = t; };
+    part(M1, 64);
+    int h = P.H2, w = P.W2;
+    for (size_t i = 0; i < A.blocks.size(); ++i) {
+      const Block& B = A.blocks[i];
+      const int ho = B.stride == 2 ? down2(h) : h, wo = B.stride == 2 ? down2(w) : w;
+      part((size_t)N * h * w, B.planes); part((size_t)N * ho * wo, B.planes * 4);
+      h = ho; w = wo;
+      if ((int)i == A.layer_end[1]) part((size_t)N * h * w, kHeadLd);
+    }
+    if (max_partial < (size_t)1100 * 3 * 1024) max_partial = (size_t)1100 * 3 * 1024;   // colstats: up to ~1024 blocks x 3 sums x 1024 channels
+  }
+  P.partial_floats = max_partial + 4096;
   // ---- parameter-derived buffers first: their offsets depend on (dtype, nout, training) only, never on the image size, so an
   //      eval-mode caller may keep them across forwards of different sizes (TF_DETNET_WEIGHTS_READY)
   P.bn_stem = bn_alloc(ar, 64);
@@ -231,7 +244,10 @@ void build_plan(Plan& P, Arena& ar, int dtype, int N, int H, int W, int nout, in
     // forward region of a BN: TF_STAT_ROWS x (sum, sum of squares) + ONE row holding the shift the producer subtracted (r3)
     for (BnBuf* q : bns) { nf += (size_t)(TF_STAT_ROWS * 2 + 1) * q->C; nb += (size_t)TF_STAT_ROWS * 3 * q->C; }
     P.stat_fwd_floats = training ? nf : 0; P.stat_bwd_floats = training ? nb : 0;
-    P.stat_fwd = ar.f32(P.stat_fwd_floats); P.stat_bwd = ar.f32(P.stat_bwd_floats);
+    // r4: [forward statistic rows | forward partial rows] and [backward statistic rows | backward partial rows] are contiguous pairs, so that
+    // ONE memset per pass clears the statistic region AND the head of the pass's partial buffer (two dispatches per pass in rounds 1-3)
+    P.stat_fwd = ar.f32(P.stat_fwd_floats); P.partial = ar.f32(P.partial_floats);
+    P.stat_bwd = ar.f32(P.stat_bwd_floats); P.partial_b = training ? ar.f32(P.partial_floats) : nullptr;
     size_t of = 0, ob = 0;
     for (BnBuf* q : bns) {
       q->fst = training && P.stat_fwd ? P.stat_fwd + of : nullptr; q->bst = training && P.stat_bwd ? P.stat_bwd + ob : nullptr;
@@ -243,7 +259,6 @@ void build_plan(Plan& P, Arena& ar, int dtype, int N, int H, int W, int nout, in
   P.cstem = ar.get(M1 * 64 * es);
   P.pool = ar.get(M2 * 64 * es);
   P.pool_idx = (uint8_t*)ar.get(training ? M2 * 64 : 0);
-  part(M1, 64);
   int h = P.H2, w = P.W2;
   size_t max_act = M1 * 64 * es;
   for (size_t i = 0; i < A.blocks.size(); ++i) {
@@ -257,11 +272,14 @@ void build_plan(Plan& P, Arena& ar, int dtype, int N, int H, int W, int nout, in
     b.c3 = training ? ar.get(Mout * c4 * es) : nullptr;
     b.d = B.has_ds ? ar.get(Mout * c4 * es) : nullptr;
     b.y = ar.get(Mout * c4 * es);
-    b.gT1 = b.gT2 = b.gU1 = nullptr;
-    if (wgrad_group_mode(dtype, training) && (int)i > A.layer_end[1] && !B.has_ds) {
+    // r4: every block owns its backward operands (g_c3, g_c2, g_c1, downsample-branch gradient).  Rounds 1-3 shared two parity sets and
+    // made the chain wait for the weight gradients of block i+2 before it reused their buffers: with the second stream behind by a group
+    // launch the chain stalled there (79 us at the top of layer 2, profiles/r04_step_timeline.txt).  0.85 GB of 288 (bf16, bs = 12).
+    b.gT1 = b.gT2 = b.gU1 = b.gT3 = nullptr;
+    if (training) {
       b.gT1 = ar.get(Mout * c4 * es); b.gT2 = ar.get(Mout * pl * es); b.gU1 = ar.get(Min * pl * es);
+      if (B.has_ds) b.gT3 = ar.get(Mout * c4 * es);
     }
-    part(Min, pl); part(Mout, c4);
     if (Min * (size_t)B.cin * es > max_act) max_act = Min * B.cin * es;
     if (Mout * c4 * es > max_act) max_act = Mout * c4 * es;
     h = b.Hout; w = b.Wout;
@@ -272,14 +290,9 @@ void build_plan(Plan& P, Arena& ar, int dtype, int N, int H, int W, int nout, in
   const size_t M3 = (size_t)N * P.H3 * P.W3, M4 = (size_t)N * P.H4 * P.W4;
   P.a1tmp = nullptr;
   P.s3 = ar.get(M3 * kHeadLd * es); P.s4 = ar.get(M4 * kHeadLd * es);
-  part(M3, kHeadLd);
-  if (max_partial < (size_t)1100 * 3 * 1024) max_partial = (size_t)1100 * 3 * 1024;   // colstats: up to ~1024 blocks x 3 sums x 1024 channels
-  P.partial_floats = max_partial + 4096;
-  P.partial = ar.f32(P.partial_floats);
   if (training) {
     P.g3 = ar.get(M3 * kHeadLd * es); P.g4 = ar.get(M4 * kHeadLd * es);
     P.G0 = ar.get(max_act); P.G1 = ar.get(max_act); P.T4 = ar.get(max_act); P.R3 = ar.get(max_act);
-    for (int k = 0; k < 2; ++k) { P.S1[k] = ar.get(max_act); P.S2[k] = ar.get(max_act); P.S3[k] = ar.get(max_act); P.SD[k] = ar.get(max_act); }
     if (packed_bytes(dtype, 1024, 1, kHeadLd) > max_wt) max_wt = packed_bytes(dtype, 1024, 1, kHeadLd);
     P.wt = ar.get(max_wt);
     // scratch of the 3x3 weight gradients: the partial [slice][tile][tap][64][64] tiles of the all-taps kernel (one block per CU:
@@ -288,7 +301,6 @@ void build_plan(Plan& P, Arena& ar, int dtype, int N, int H, int W, int nout, in
     P.dwp = ar.f32(P.dwp_floats);
   } else {
     P.g3 = P.g4 = P.G0 = P.G1 = P.T4 = P.R3 = P.wt = nullptr; P.dwp = nullptr; P.dwp_floats = 0;
-    for (int k = 0; k < 2; ++k) P.S1[k] = P.S2[k] = P.S3[k] = P.SD[k] = nullptr;
   }
   P.total = ar.off;
 }
@@ -509,8 +521,8 @@ extern "C" int tf_detnet_forward(int dtype, int training, const float* x, int N,
   const int srows = tf_get_stat_rows();
   static const bool g_unfused_env = getenv("TINYFACES_UNFUSED_BN") != nullptr;     // A/B knob
   const bool fused = tr && srows <= TF_STAT_ROWS && !g_unfused_env;
-  if (fused && hipMemsetAsync(P.stat_fwd, 0, P.stat_fwd_floats * 4, c.stream) != hipSuccess) c.chk(TF_ERR_LAUNCH);
-  if (tr && hipMemsetAsync(P.partial, 0, (size_t)TF_STAT_ROWS * 3 * 1024 * 4, c.stream) != hipSuccess) c.chk(TF_ERR_LAUNCH);   // statistic rows start at zero
+  // statistic rows start at zero: the per-BN regions and, right behind them in the arena, the head of the shared partial buffer -- ONE memset
+  if (tr && hipMemsetAsync(P.stat_fwd, 0, (size_t)((char*)P.partial - (char*)P.stat_fwd) + (size_t)TF_STAT_ROWS * 3 * 1024 * 4, c.stream) != hipSuccess) c.chk(TF_ERR_LAUNCH);
   // ---- stem: im2col + GEMM (+BN+ReLU) + maxpool
   const int M1 = N * P.H1 * P.W1;
   // r3 experiment, NEGATIVE, kept behind TINYFACES_PACK_SIDE=1: the weight re-packing of a training step (three launches, ~170 us: 111 MB
@@ -772,13 +784,41 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
   const void* res3 = P.blk[A.layer_end[1]].y;
   const void* res4 = P.blk[A.layer_end[2]].y;
 
-  if (hipMemsetAsync(P.partial, 0, (size_t)TF_STAT_ROWS * 3 * 1024 * 4, c.stream) != hipSuccess) c.chk(TF_ERR_LAUNCH);   // statistic rows start at zero
   const int srows = tf_get_stat_rows();
   static const bool g_unfused_env = getenv("TINYFACES_UNFUSED_BN") != nullptr;
   const bool fused = srows <= TF_STAT_ROWS && !g_unfused_env;   // see tf_detnet_forward
-  if (fused && hipMemsetAsync(P.stat_bwd, 0, P.stat_bwd_floats * 4, c.stream) != hipSuccess) c.chk(TF_ERR_LAUNCH);
-  if (grad_flat && grad_flat_bytes) {                     // one memset for every weight gradient (atomics accumulate into them)
-    if (hipMemsetAsync(grad_flat, 0, grad_flat_bytes, c.stream) != hipSuccess) c.chk(TF_ERR_LAUNCH);
+  // statistic rows start at zero: the per-BN backward regions + the head of this pass's partial buffer right behind them, ONE memset
+  if (hipMemsetAsync(P.stat_bwd, 0, (size_t)((char*)P.partial_b - (char*)P.stat_bwd) + (size_t)TF_STAT_ROWS * 3 * 1024 * 4, c.stream) != hipSuccess) c.chk(TF_ERR_LAUNCH);
+  const bool group_on = wgrad_group_mode(dtype, 1) && fused;
+  const int first_id = A.layer_end[1] + 2, last_id = A.layer_end[2];           // the identity bottlenecks of layer 3: blocks 8 .. 29
+  if (grad_flat && grad_flat_bytes) {                     // one memset for every weight gradient (atomics accumulate into them) ...
+    // r4: ... except where nothing accumulates: the grouped weight gradients OVERWRITE theirs, and the BatchNorm gradients in between are
+    // published with plain stores (bn_fused.hip) -- the 22 identity bottlenecks of layer 3 are 98 of the 111 MB of the flat gradient.
+    // With the table in executor order (DetectionModel.flatten_parameters) they are ONE range: [layer3.1.conv1.weight, score_res3.weight).
+    char* lo = group_on ? (char*)c.G(A.blocks[first_id].c1.w) : nullptr;
+    char* hi = group_on ? (char*)c.G(A.head3.w) : nullptr;
+    char* g0 = (char*)grad_flat; char* g1 = g0 + grad_flat_bytes;
+    bool split = lo && hi && lo >= g0 && hi <= g1 && lo < hi;
+    for (int i = first_id; split && i <= last_id; ++i) {          // every trained tensor of these blocks must lie inside the range
+      const Block& B = A.blocks[i];
+      const int idx[9] = {B.c1.w, B.c1.gamma, B.c1.beta, B.c2.w, B.c2.gamma, B.c2.beta, B.c3.w, B.c3.gamma, B.c3.beta};
+      for (int q : idx) { char* t = (char*)c.G(q); split = split && t >= lo && t < hi; }
+    }
+    for (int q = 0; split && q < (int)A.names.size(); ++q) {       // ... and nothing else may
+      char* t = (char*)c.G(q);
+      if (!t || t < lo || t >= hi) continue;
+      bool mine = false;
+      for (int i = first_id; i <= last_id && !mine; ++i) {
+        const Block& B = A.blocks[i];
+        mine = q == B.c1.w || q == B.c1.gamma || q == B.c1.beta || q == B.c2.w || q == B.c2.gamma || q == B.c2.beta || q == B.c3.w || q == B.c3.gamma || q == B.c3.beta;
+      }
+      split = split && mine;
+    }
+    static const bool split_off = getenv("TINYFACES_GRAD_MEMSET_FULL") != nullptr;     // A/B + safety knob
+    if (split && !split_off) {
+      if (lo > g0 && hipMemsetAsync(g0, 0, (size_t)(lo - g0), c.stream) != hipSuccess) c.chk(TF_ERR_LAUNCH);
+      if (g1 > hi && hipMemsetAsync(hi, 0, (size_t)(g1 - hi), c.stream) != hipSuccess) c.chk(TF_ERR_LAUNCH);
+    } else if (hipMemsetAsync(grad_flat, 0, grad_flat_bytes, c.stream) != hipSuccess) c.chk(TF_ERR_LAUNCH);
     c.grads_zeroed = true;
   }
   // (the transposed weight operands w*t were packed by the training forward, together with the forward operands)
@@ -787,10 +827,10 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
   c.chk(tf_upsample_add_crop_bwd(dtype, gout, P.wup_diag, N, nout, kHeadLd, P.H3, P.W3, P.H4, P.W4, P.g3, P.g4, c.stream));
   {
     const int nb3 = tf_colstats_blocks(M3, kHeadLd, dtype), nb4 = tf_colstats_blocks(M4, kHeadLd, dtype);
-    c.chk(tf_colstats(dtype, P.g3, nullptr, nullptr, nullptr, M3, kHeadLd, kHeadLd, P.partial, c.stream));
-    c.chk(tf_reduce_partials(P.partial, nb3, 1, 0, kHeadLd, nout, c.G(A.head3.bias), 1, c.stream));
-    c.chk(tf_colstats(dtype, P.g4, nullptr, nullptr, nullptr, M4, kHeadLd, kHeadLd, P.partial, c.stream));
-    c.chk(tf_reduce_partials(P.partial, nb4, 1, 0, kHeadLd, nout, c.G(A.head4.bias), 1, c.stream));
+    c.chk(tf_colstats(dtype, P.g3, nullptr, nullptr, nullptr, M3, kHeadLd, kHeadLd, P.partial_b, c.stream));
+    c.chk(tf_reduce_partials(P.partial_b, nb3, 1, 0, kHeadLd, nout, c.G(A.head3.bias), 1, c.stream));
+    c.chk(tf_colstats(dtype, P.g4, nullptr, nullptr, nullptr, M4, kHeadLd, kHeadLd, P.partial_b, c.stream));
+    c.chk(tf_reduce_partials(P.partial_b, nb4, 1, 0, kHeadLd, nout, c.G(A.head4.bias), 1, c.stream));
   }
   {
     ConvUnit h3 = A.head3, h4 = A.head4;
@@ -799,7 +839,11 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
     wgrad(c, h4, nout, N, P.H4, P.W4, P.H4, P.W4, res4, 1024, P.g4, kHeadLd, nullptr);
   }
   // score4_upsample.weight has lr 0 (model.py:84): its gradient is defined as zero here
-  if (c.G(A.upsample_w) && hipMemsetAsync(c.G(A.upsample_w), 0, (size_t)nout * nout * 16 * 4, c.stream) != hipSuccess) c.chk(TF_ERR_LAUNCH);
+  {
+    char* u = (char*)c.G(A.upsample_w);
+    const bool covered = c.grads_zeroed && u >= (char*)grad_flat && u + (size_t)nout * nout * 16 * 4 <= (char*)grad_flat + grad_flat_bytes;     // (the flat buffer's memset)
+    if (u && !covered && hipMemsetAsync(u, 0, (size_t)nout * nout * 16 * 4, c.stream) != hipSuccess) c.chk(TF_ERR_LAUNCH);
+  }
 
   // Buffer roles: Gcur/Gnext ping-pong the gradient w.r.t. a block output / input; T1 = g_c3 then g_c1;
   // T2 = gz2 -> g_c2; T3 = g_d; T4 = downsample-branch input gradient; R3 = gradient w.r.t. res3 from the head.
@@ -832,8 +876,6 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
   // ONE fork hands the second stream two launches (tf_conv2d_wgrad_group): the 2 x n pointwise problems (128 x 128 tiles, each reduced
   // over all 12 288 pixels in-block) and the n 3x3 problems (all-taps kernel, splitk = 1).  No split-K, no atomics, no partial tiles, no
   // reduce kernel, 3 forks instead of 22 for these blocks; the gradient-ready events of the group's blocks fire behind the group.
-  const bool group_on = wgrad_group_mode(dtype, 1) && fused;
-  const int first_id = A.layer_end[1] + 2, last_id = A.layer_end[2];           // the identity bottlenecks of layer 3: blocks 8 .. 29
   std::vector<int> group_close;                                                 // block index that closes each group (descending)
   if (group_on) {
     const int nid = last_id - first_id + 1, gs = wgrad_group_size(), ng = (nid + gs - 1) / gs;
@@ -861,7 +903,6 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
     pend_pw.clear(); pend_c3.clear(); pend_blocks.clear();
   };
   // ---- bottlenecks in reverse
-  std::vector<hipEvent_t> block_done(A.blocks.size(), nullptr);
   for (int i = (int)A.blocks.size() - 1; i >= 0; --i) {
     const Block& B = A.blocks[i];
     Plan::Blk& b = P.blk[i];
@@ -869,19 +910,15 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
     const int Min = N * b.Hin * b.Win, Mout = N * b.Hout * b.Wout;
     const void* yin = i == 0 ? P.pool : P.blk[i - 1].y;
     const void* extra = (i == A.layer_end[1] + 1) ? P.R3 : nullptr;     // the block whose INPUT is res3
-    const int par = i & 1;
-    const bool grouped = group_on && i >= first_id && i <= last_id && b.gT1 != nullptr;
+    const bool grouped = group_on && i >= first_id && i <= last_id;
     bool closes_group = false;
     if (grouped) for (int gc : group_close) closes_group |= gc == i;
     const bool late = !grouped && fused && fork_each && l3_single_fork && i > A.layer_end[1] && !B.has_ds;    // the three gradients behind ONE fork
-    void *T1 = P.S1[par], *T2 = P.S2[par], *U1 = P.S3[par], *T3 = P.SD[par];
-    if (grouped) { T1 = b.gT1; T2 = b.gT2; U1 = b.gU1; }
-    // this parity's buffers were last read by the weight gradients of block i+2: wait for them
-    if (i + 2 < (int)A.blocks.size()) c.wait_on_main(block_done[i + 2]);
+    void *T1 = b.gT1, *T2 = b.gT2, *U1 = b.gU1, *T3 = b.gT3;      // the block's own buffers: nothing on this stream ever waits for a weight gradient
     // (1) per-channel sums for bn3 (and the downsample BN) with gz = g_y * (y > 0)
     const int nb = tf_colstats_blocks(Mout, c4, dtype);
     const int nk = B.has_ds ? 3 : 2;
-    if (!fused) c.chk(tf_colstats(dtype, Gcur, b.y, b.c3, b.d, Mout, c4, c4, P.partial, c.stream));
+    if (!fused) c.chk(tf_colstats(dtype, Gcur, b.y, b.c3, b.d, Mout, c4, c4, P.partial_b, c.stream));
     else if (B.has_ds) c.chk(tf_colstats(dtype, Gcur, nullptr, b.c3, b.d, Mout, c4, c4, b.b3.bst, c.stream));   // Gcur is already masked
     // (2) g_c3 -> T1.  r3: in bf16 the apply can ride on the operand path of the data gradient that consumes it (tf_conv2d_bnbwd,
     //     conv_pwx.hip): steps (2) and (4) in ONE launch, T1 its side output for the weight gradient.  Measured (scripts/microbench_pwx.py,
@@ -908,8 +945,8 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
       if (fork_each && !late && !grouped) c.arm_fork();
       c.chk(tf_bn_bwd_apply_fused(dtype, Gcur, nullptr, b.c3, &d, srows, Mout, c4, (float)Mout, T1, c.stream));
     } else {
-      bn_backward_coefs(c, B.c3, c4, b.b3, P.partial, nb, nk, 1, c4, (float)Mout, B.has_ds ? 0 : 1);   // the last reader clears the partial rows
-      if (B.has_ds) bn_backward_coefs(c, B.ds, c4, b.bd, P.partial, nb, nk, 2, c4, (float)Mout, 1);
+      bn_backward_coefs(c, B.c3, c4, b.b3, P.partial_b, nb, nk, 1, c4, (float)Mout, B.has_ds ? 0 : 1);   // the last reader clears the partial rows
+      if (B.has_ds) bn_backward_coefs(c, B.ds, c4, b.bd, P.partial_b, nb, nk, 2, c4, (float)Mout, 1);
       c.chk(tf_bn_bwd_apply(dtype, Gcur, b.y, b.c3, b.b3.cA, b.b3.cB, b.b3.cD, Mout, c4, T1, c.stream));
     }
     // (3) wgrad conv3 (its input is relu(bn2(c2)), materialised in the forward)
@@ -920,7 +957,7 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
     if (!fused24) {
       conv_fill(a, dtype, 1, N, b.Hout, b.Wout, c4, b.Hout, b.Wout, pl, 1, 1, 0, pl, T1, b.w3t, T2);
       a.epi = TF_EPI_MASK | TF_EPI_STATS2; a.aux = b.c2; a.mask_scale = b.b2.scale; a.mask_shift = b.b2.shift;
-      a.stat_out = fused ? b.b2.bst : P.partial;
+      a.stat_out = fused ? b.b2.bst : P.partial_b;
       c.chk(tf_conv2d(&a, c.stream));
     }
     // (5) g_c2 in place
@@ -929,7 +966,7 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
       if (fork_each && !late && !grouped) c.arm_fork();
       c.chk(tf_bn_bwd_apply_fused(dtype, T2, nullptr, b.c2, &d, srows, Mout, pl, (float)Mout, T2, c.stream));
     } else {
-      bn_backward_coefs(c, B.c2, pl, b.b2, P.partial, tf_conv_mtiles(&a), 2, 1, pl, (float)Mout);
+      bn_backward_coefs(c, B.c2, pl, b.b2, P.partial_b, tf_conv_mtiles(&a), 2, 1, pl, (float)Mout);
       c.chk(tf_bn_bwd_apply(dtype, T2, nullptr, b.c2, b.b2.cA, b.b2.cB, b.b2.cD, Mout, pl, T2, c.stream));
     }
     // (6) wgrad conv2 (input relu(bn1(c1)))
@@ -939,7 +976,7 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
     // (7) dgrad conv2 -> gz1 in U1 (+ sums); output spatial = conv2's input
     conv_fill(a, dtype, 1, N, b.Hout, b.Wout, pl, b.Hin, b.Win, pl, 3, B.stride, 1, pl, T2, b.w2t, U1);
     a.epi = TF_EPI_MASK | TF_EPI_STATS2; a.aux = b.c1; a.mask_scale = b.b1.scale; a.mask_shift = b.b1.shift;
-    a.stat_out = fused ? b.b1.bst : P.partial;
+    a.stat_out = fused ? b.b1.bst : P.partial_b;
     c.chk(tf_conv2d(&a, c.stream));
     // (8) g_c1 in place
     if (fused) {
@@ -947,7 +984,7 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
       if (grouped ? closes_group : fork_each) c.arm_fork();       // grouped: only the kernel that completes a GROUP's operands carries a fork
       c.chk(tf_bn_bwd_apply_fused(dtype, U1, nullptr, b.c1, &d, srows, Min, pl, (float)Min, U1, c.stream));
     } else {
-      bn_backward_coefs(c, B.c1, pl, b.b1, P.partial, tf_conv_mtiles(&a), 2, 1, pl, (float)Min);
+      bn_backward_coefs(c, B.c1, pl, b.b1, P.partial_b, tf_conv_mtiles(&a), 2, 1, pl, (float)Min);
       c.chk(tf_bn_bwd_apply(dtype, U1, nullptr, b.c1, b.b1.cA, b.b1.cB, b.b1.cD, Min, pl, U1, c.stream));
     }
     // (9) wgrad conv1 (input = block input, already activated)
@@ -995,7 +1032,6 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
       if (B.has_ds) wgrad(c, B.ds, c4, N, b.Hin, b.Win, b.Hout, b.Wout, yin, B.cin, T3, c4, nullptr);
     }
     if (!grouped) {
-      block_done[i] = c.mark_side();
       // everything up to here: the weight / BN gradients of blocks >= i and of the heads.  With a group stream they are spread over two
       // queues: the event goes to the group stream, ordered behind the second stream's position (never the other way round: the second
       // stream must not wait for a group)
@@ -1005,7 +1041,7 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
       } else {
         record_grad_events(i, c.wstream(), c.rc);
       }
-    }                                                // (grouped blocks: no parity buffer to protect; their events fire in flush_group)
+    }                                                // (grouped blocks: their events fire in flush_group)
     void* t = Gcur; Gcur = Gnext; Gnext = t;
   }
 
@@ -1014,8 +1050,8 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
   void* gz = P.T4;                          // main-stream scratch (its last reader, block 0's conv1 dgrad, is ahead on this stream)
   c.chk(tf_maxpool_bwd(dtype, Gcur, P.pool_idx, P.cstem, P.bn_stem.scale, P.bn_stem.shift, N, P.H1, P.W1, 64, gz, c.stream));
   const int nb = tf_colstats_blocks(M1, 64, dtype);
-  c.chk(tf_colstats(dtype, gz, nullptr, P.cstem, nullptr, M1, 64, 64, P.partial, c.stream));
-  bn_backward_coefs(c, A.stem, 64, P.bn_stem, P.partial, nb, 2, 1, 64, (float)M1);
+  c.chk(tf_colstats(dtype, gz, nullptr, P.cstem, nullptr, M1, 64, 64, P.partial_b, c.stream));
+  bn_backward_coefs(c, A.stem, 64, P.bn_stem, P.partial_b, nb, 2, 1, 64, (float)M1);
   c.chk(tf_bn_bwd_apply(dtype, gz, nullptr, P.cstem, P.bn_stem.cA, P.bn_stem.cB, P.bn_stem.cD, M1, 64, gz, c.stream));
   // P.col still holds the im2col matrix of this forward (nothing else is carved from that range)
   {
