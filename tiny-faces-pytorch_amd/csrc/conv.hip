@@ -379,6 +379,8 @@ int pick_tile(const tf_conv_args* a) {
     // 32x32x16 fragments with a 2-deep ring moves the same bytes faster (1920x2560 pyramid level: 256 -> 1024 at M = 19 200 35.6 -> 30.7 us,
     // 128 -> 512 at M = 76 800 49.1 -> 40.8 us, 64 -> 256 at M = 307 200 103 -> 95 us; profiles/r03_microbench_eval.txt)
     static const bool t46_off = getenv("TINYFACES_T46_SHORTK_OFF") != nullptr;
+    // (r4: a 128 x 128 / eight-wave pointwise kernel, conv_pw8, was built for the K >= 512 GEMMs and measured no faster on any layer shape:
+    //  profiles/r04_conv_pw8_negative.txt -- removed again)
     if (!t46_off && a->dtype != TF_F32 && nst <= 4 && M >= 16384 && a->Cout % 128 == 0 && a->Cout >= 256) return 46;
     if (!t12_off && a->dtype != TF_F32 && nst <= 4) return 32;
     // 32x32x16 fragments (64 pixels x 128 channels per block, 32 x 64 per wave, 2-deep ring) win where a launch still has several

@@ -999,6 +999,8 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
     //      its BN3-backward sums (STATS3 with aux3 = its c3), so the next iteration starts at step (2).
     auto hand_over = [&](tf_conv_args& q) {
       if (!fused || i == 0) return;                        // block 0's input is the max-pool output: no ReLU in between
+      static const int ho_tile = [] { const char* e = getenv("TINYFACES_HANDOVER_TILE"); return e ? atoi(e) : 0; }();     // A/B knob: tile code of the hand-over data gradients
+      if (ho_tile) q.tile = ho_tile;
       q.epi |= TF_EPI_MASK2; q.aux2 = yin;
       if (!A.blocks[i - 1].has_ds) { q.epi |= TF_EPI_STATS3; q.aux3 = P.blk[i - 1].c3; q.stat_out = P.blk[i - 1].b3.bst; }
     };
