@@ -638,7 +638,7 @@ def main():
                 m._run_forward(b["x"], training=True)
             e1.record(); torch.cuda.synchronize()
             extra["fwd_ms"] = e0.elapsed_time(e1) / 10
-            _hip.lib().tf_detnet_set_dual_stream(0)
+            m.single_stream = True
             step(0); torch.cuda.synchronize()
             _hip.lib().tf_profile_enable(1)
             t1 = time.perf_counter()
@@ -652,7 +652,7 @@ def main():
             extra["error"] = repr(e)
         finally:
             _hip.lib().tf_profile_enable(0)
-            _hip.lib().tf_detnet_set_dual_stream(1)
+            eng.model.single_stream = False
     if args.layer_table:
         write_layer_table(_hip, args.layer_table, args.steps, dt)
     ms_per_step = dt / args.steps * 1e3

@@ -342,28 +342,73 @@ size_t tf_detnet_param_region_bytes(int dtype, int num_out, int training);
 int tf_detnet_forward(int dtype, int training, const float* x_nchw, int N, int H, int W, int num_out,
                       void* const* params, float bn_eps, float bn_momentum,
                       float* out_nchw, void* ws, size_t ws_bytes, int flags, void* stream);
-/* 1 (default): weight gradients run on an internal second stream concurrently with the data-gradient chain; 0: single stream */
-int tf_detnet_set_dual_stream(int on);
-/* Data-parallel overlap: hipEvent_t handles recorded by the NEXT tf_detnet_backward calls when the gradients of all
- * bottlenecks >= blocks[k] (and of the heads) are enqueued (blocks[k] = -1: at the very end, stem included).  A
- * communication stream that waits on events[k] can all-reduce that bucket while the rest of the backward pass runs
- * (the reference has no distributed path; this serves the 8-GPU data-parallel row of SURVEY.md section 8e).
- * n = 0 clears.  The registration is process-wide in the library; the Python surface keeps the events in the model object and
- * installs them around that model's own backward call only (tinyfaces/models/model.py:_run_backward).  BN gamma/beta gradients of a block are written on the caller's stream BEFORE the fork that precedes the
- * event's stream position, so one event covers them too. */
-int tf_detnet_set_grad_events(const int* blocks, void* const* events, int n);
-/* r3: `fn(block, stream, user)` is called from inside tf_detnet_backward, on the calling thread, at every point registered with
- * tf_detnet_set_grad_events (whose events[k] may now be NULL), with the stream that carries the bucket's gradients: work the callee
- * enqueues on `stream` (or orders behind it) sees the bucket final.  The data-parallel engine issues the bucket's all-reduce there
- * (reference: loss.backward() + optimizer.step() of trainer.py:86-87 under DistributedDataParallel-style averaging).  NULL: off. */
+/* ---- executor context + gradient-ready hooks (r4) ------------------------------------------------------------------------------------
+ * tf_detnet_ctx owns what the executor needs beyond `ws`: the second HIP stream of the device it was created on (weight gradients of the
+ * backward pass run there, concurrently with the data-gradient chain; the weights of layer 3 are packed there beside the start of a
+ * training forward) and its pool of fork / join events.  One context per model (or per thread that drives models): two contexts never
+ * share a stream or an event, a context must only be used on the device that was current when it was created.  NULL selects the
+ * process-wide default context of the current device (the behaviour of rounds 1-3).
+ * tf_detnet_hooks is the data-parallel interface of ONE backward call (the reference has no distributed path; this serves the 8-GPU
+ * data-parallel row of SURVEY.md section 8e): when the gradients of all bottlenecks >= blocks[k] (and of the heads) are enqueued
+ * (blocks[k] = -1: at the very end, stem included), events[k] -- a hipEvent_t, may be NULL -- is recorded on the stream that carries them
+ * and fn(blocks[k], stream, user) is called on the calling thread: work the callee enqueues on `stream` (or orders behind it) sees the
+ * bucket final, e.g. tf_comm_allreduce_hook below.  BN gamma / beta gradients of a block are written on the caller's stream BEFORE the
+ * fork that precedes the event's stream position, so one event covers them too.  single_stream = 1: no second stream (A/B, race tests). */
+typedef struct tf_detnet_ctx tf_detnet_ctx;
+int tf_detnet_ctx_create(tf_detnet_ctx** out);       /* binds to the CURRENT device */
+int tf_detnet_ctx_destroy(tf_detnet_ctx* ctx);       /* waits for the context's streams, then frees them */
 typedef void (*tf_grad_ready_fn)(int block, void* stream, void* user);
-int tf_detnet_set_grad_callback(tf_grad_ready_fn fn, void* user);
-/* grad_flat (optional): when every entry of `grads` lies inside [grad_flat, grad_flat + grad_flat_bytes) the whole
- * range is zeroed with ONE memset instead of one per weight gradient. */
+typedef struct tf_detnet_hooks {
+  const int* blocks; void* const* events; int n;
+  tf_grad_ready_fn fn; void* user;
+  int single_stream;
+} tf_detnet_hooks;
+int tf_detnet_forward_ctx(tf_detnet_ctx* ctx, int single_stream, int dtype, int training, const float* x_nchw, int N, int H, int W, int num_out,
+                          void* const* params, float bn_eps, float bn_momentum, float* out_nchw, void* ws, size_t ws_bytes, int flags, void* stream);
+/* grad_flat (optional): when every entry of `grads` lies inside [grad_flat, grad_flat + grad_flat_bytes) the ranges that are accumulated
+ * into are zeroed with at most two memsets instead of one per weight gradient. */
+int tf_detnet_backward_ctx(tf_detnet_ctx* ctx, const tf_detnet_hooks* hooks /* NULL: none */, int dtype, const float* x_nchw, int N, int H, int W,
+                           int num_out, void* const* params, void* const* grads, const float* gout_nchw,
+                           void* grad_flat, size_t grad_flat_bytes, void* ws, size_t ws_bytes, void* stream);
+/* Context-free forms of rounds 1-3, kept for callers that drive ONE model from ONE thread: they use the default context of the current
+ * device and hooks registered PROCESS-WIDE with the three setters below (not thread-safe; the Python surface no longer uses them). */
+int tf_detnet_set_dual_stream(int on);               /* 1 (default): second stream; 0: everything on the caller's stream */
+int tf_detnet_set_grad_events(const int* blocks, void* const* events, int n);      /* n = 0 clears */
+int tf_detnet_set_grad_callback(tf_grad_ready_fn fn, void* user);                  /* NULL: off */
 int tf_detnet_backward(int dtype, const float* x_nchw, int N, int H, int W, int num_out,
                        void* const* params, void* const* grads, const float* gout_nchw,
                        void* grad_flat, size_t grad_flat_bytes,
                        void* ws, size_t ws_bytes, void* stream);
+
+/* ---- gradient exchange of the data-parallel path over RCCL (the reference has no distributed code) -------------
+ * One process per GPU; the gradients are SUMMED over the ranks bucket by bucket while the backward pass runs, the 1/world goes into
+ * tf_sgd_step's grad_scale.  librccl.so is resolved at run time (the copy already mapped into the process first): tf_comm_available() == 0
+ * on a host without it, and every other entry then returns TF_ERR_UNSUPPORTED.
+ *   tf_comm_unique_id  rank 0 draws the 128-byte identifier of a new communicator (HOST memory); ship it to the other ranks out of band
+ *   tf_comm_init       collective over all ranks; binds to the CURRENT device; owns a communication stream (default priority) + events
+ *   tf_allreduce_bucket  buf[0..n) <- sum over ranks, in place, on the communicator's stream, ordered behind the current tail of `after`
+ *                        (the executor stream that carries the bucket: tf_detnet_hooks) without holding that stream up
+ *   tf_comm_join       `stream` waits for every collective issued so far (call it on the training stream before tf_sgd_step)
+ *   tf_comm_allreduce_hook  a ready-made tf_grad_ready_fn: tf_detnet_hooks.fn = tf_comm_allreduce_hook, .user = a tf_comm_plan that maps
+ *                        the registered blocks to element ranges of the flat gradient; plan.rc keeps the first error, plan.issued counts */
+#define TF_COMM_ID_BYTES 128
+typedef struct tf_comm tf_comm;
+int tf_comm_available(void);
+int tf_comm_unique_id(void* host_id_out /*[TF_COMM_ID_BYTES]*/);
+int tf_comm_init(const void* host_id /*[TF_COMM_ID_BYTES]*/, int rank, int world, tf_comm** out);
+int tf_comm_destroy(tf_comm* comm);
+int tf_comm_rank(const tf_comm* comm);
+int tf_comm_world(const tf_comm* comm);
+int tf_allreduce_bucket(tf_comm* comm, float* buf, size_t n, void* after_stream);
+int tf_comm_join(tf_comm* comm, void* stream);
+typedef struct tf_comm_plan {
+  void* comm;                    /* tf_comm* */
+  float* grad_flat;              /* the flat fp32 gradient the buckets are slices of */
+  int n; const int* blocks;      /* the blocks registered in tf_detnet_hooks (backward order; -1 = the end of the pass) */
+  const int64_t* start; const int64_t* end;      /* element range of bucket k */
+  int rc, issued;                /* out: first error (TF_OK), collectives issued since the caller reset it */
+} tf_comm_plan;
+void tf_comm_allreduce_hook(int block, void* stream, void* user /* tf_comm_plan* */);
 
 /* ---- image preparation in front of the detector -----------------------------------
  * One pass from the decoded uint8 RGB image to the normalised fp32 CHW tensor: PIL BILINEAR resize (bit-exact with Pillow's

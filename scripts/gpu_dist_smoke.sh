@@ -9,6 +9,8 @@ export HSA_ENABLE_IPC_MODE_LEGACY=0
 run() { python bench.py --steps 4 --warmup 0 --no-profile --no-eval --no-cpu-baseline --no-fp32-path 2>gpurun_out/dist_$1.err | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$1', d['value'], d['ms_per_step'], d['loss'])"; }
 run plain
 TINYFACES_FORCE_DIST=1 run rccl1 || tail -5 gpurun_out/dist_rccl1.err
+# (1b) r4: the NATIVE exchange (tf_comm_allreduce_hook: ncclAllReduce issued from C inside the backward enqueue) with the same 1-rank group
+TINYFACES_FORCE_DIST=1 TINYFACES_ALLREDUCE_NATIVE=1 run rccl1_native || tail -5 gpurun_out/dist_rccl1_native.err
 export TINYFACES_BENCH_SHARE_GPU=1
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 3 --warmup 1 --no-profile > gpurun_out/bench_dist2.json 2> gpurun_out/bench_dist2.err
 echo "dist exit $?"; tail -3 gpurun_out/bench_dist2.err; cut -c1-400 gpurun_out/bench_dist2.json

@@ -98,7 +98,7 @@ def test_gradient_bucket_slices_are_final_when_their_event_fires():
     handles = (C.c_void_p * len(ranges))(*[int(e.cuda_event) for e in evs])
     snaps = []
     try:
-        assert _hip.lib().tf_detnet_set_grad_events(blocks, handles, len(ranges)) == 0
+        m._grad_events = (blocks, handles, len(ranges))
         for rep in range(3):
             m._sync_tables(x.device)
             out = m._run_forward(x, training=True)
@@ -114,9 +114,74 @@ def test_gradient_bucket_slices_are_final_when_their_event_fires():
             torch.cuda.synchronize()
             snaps.append([bool(torch.equal(c_, gflat[s:e])) and bool(c_.abs().sum() > 0) for c_, (blk, s, e) in zip(cur, ranges)])
     finally:
-        _hip.lib().tf_detnet_set_grad_events(None, None, 0)
+        m._grad_events = None
     report("grad_slice_finality", buckets=len(ranges), mb=str([round((e - s) * 4 / 2**20, 1) for _, s, e in ranges]), final=str(snaps))
     assert all(all(s) for s in snaps), snaps
+
+
+def test_native_exchange_one_rank_communicator_and_hook():
+    """include/tinyfaces_hip.h tf_comm_* / tf_allreduce_bucket / tf_comm_allreduce_hook (csrc/comm.hip) on the one GPU of the box: a 1-rank RCCL
+    communicator (RCCL refuses two ranks on one device, profiles/r03_dist_smoke.txt) -- the sum over one rank is the identity, so the test pins
+    the plumbing: librccl resolved at run time, the collective ordered behind the carrying stream, the hook called once per registered
+    bucket from inside the backward enqueue with NO Python in between, tf_comm_join, and gradients equal to a run without hooks."""
+    import ctypes as C
+    from oracle.model import OracleDetectionModel, tame_init_
+    from tinyfaces import _hip
+    from tinyfaces._hip import lib
+    from tinyfaces.engine import TrainEngine
+    from tinyfaces.models.model import DetectionModel
+    assert lib().tf_comm_available() == 1
+    ident = C.create_string_buffer(_hip.TF_COMM_ID_BYTES)
+    assert lib().tf_comm_unique_id(ident) == 0
+    comm = C.c_void_p()
+    assert lib().tf_comm_init(ident, 0, 1, C.byref(comm)) == 0
+    try:
+        assert lib().tf_comm_world(comm) == 1 and lib().tf_comm_rank(comm) == 0
+        # a bucket behind a busy stream
+        side = torch.cuda.Stream()
+        buf = torch.zeros(1 << 20, device="cuda")
+        with torch.cuda.stream(side):
+            torch.cuda._sleep(int(5e7))
+            buf.fill_(3.0)                                                   # the "gradient kernel" the collective must wait for
+        assert lib().tf_allreduce_bucket(comm, buf.data_ptr(), buf.numel(), side.cuda_stream) == 0
+        assert lib().tf_comm_join(comm, torch.cuda.current_stream().cuda_stream) == 0
+        total = float(buf.sum())                                             # (on the current stream: behind the join)
+        assert total == 3.0 * buf.numel()
+        # the hook inside the executor
+        m = DetectionModel(num_templates=25)
+        m.load_state_dict(tame_init_(OracleDetectionModel(num_templates=25), 0).state_dict(), strict=True)
+        m = m.cuda().set_compute_dtype(torch.bfloat16).train()
+        flat = m.flatten_parameters()
+        firsts = TrainEngine.auto_first_blocks(m._segments, flat.numel(), 10)
+        ranges = [r for r in TrainEngine.bucket_ranges(m._segments, flat.numel(), firsts) if r[2] > r[1]]
+        n = len(ranges)
+        x = torch.randn(2, 3, 160, 192, generator=torch.Generator().manual_seed(4)).cuda()
+        m._sync_tables(x.device)
+        lib().tf_set_stat_rows(0)
+        out = m._run_forward(x, training=True)
+        ref = m._run_backward(x, torch.ones_like(out), persistent=True).clone()
+        blocks = (C.c_int * n)(*[r[0] for r in ranges])
+        start, end = (C.c_int64 * n)(*[r[1] for r in ranges]), (C.c_int64 * n)(*[r[2] for r in ranges])
+        plan = _hip.CommPlan()
+        plan.comm, plan.grad_flat, plan.n = comm, m._grad_flat_persistent.data_ptr(), n
+        plan.blocks, plan.start, plan.end = C.cast(blocks, C.POINTER(C.c_int)), C.cast(start, C.POINTER(C.c_int64)), C.cast(end, C.POINTER(C.c_int64))
+        m._grad_events = (blocks, (C.c_void_p * n)(*([None] * n)), n)
+        m._grad_callback = C.cast(lib().tf_comm_allreduce_hook, C.c_void_p)
+        m._grad_callback_user = C.cast(C.pointer(plan), C.c_void_p)
+        try:
+            m._run_forward(x, training=True)
+            g = m._run_backward(x, torch.ones_like(out), persistent=True)
+            assert plan.rc == 0 and plan.issued == n, (plan.rc, plan.issued, n)
+            assert lib().tf_comm_join(comm, torch.cuda.current_stream().cuda_stream) == 0
+            torch.cuda.synchronize()
+        finally:
+            m._grad_events = None; m._grad_callback = None; m._grad_callback_user = None
+            lib().tf_set_stat_rows(8)
+        rel = float((g - ref).abs().max() / ref.abs().max())
+        report("native_exchange_1rank", buckets=n, rel=rel)
+        assert rel < 1e-3
+    finally:
+        lib().tf_comm_destroy(comm)
 
 
 def test_evaluate_model_two_ranks_write_what_one_process_writes(tmp_path):

@@ -319,7 +319,7 @@ def test_dual_stream_backward_equals_single_stream(dtype):
     x = torch.randn(3, 3, 224, 288, generator=g).cuda()
 
     def grads(dual):
-        _hip.lib().tf_detnet_set_dual_stream(int(dual))
+        m.single_stream = not dual           # (r4: a property of the model's own calls -- tf_detnet_hooks.single_stream -- not a process-wide switch)
         m.zero_grad(set_to_none=True)
         y = m(x)
         gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(9)).cuda()
@@ -337,7 +337,7 @@ def test_dual_stream_backward_equals_single_stream(dtype):
                 d = float((got[k] - ref[k]).abs().max() / (ref[k].abs().max() + 1e-30))
                 worst = max(worst, d)
     finally:
-        _hip.lib().tf_detnet_set_dual_stream(1)
+        m.single_stream = False
         _hip.lib().tf_set_stat_rows(8)                  # the library default
     report(f"dual_stream[{dtype}]", worst_rel=worst)
     assert worst < 1e-4
@@ -411,8 +411,8 @@ def test_forward_levels_on_lanes_is_bit_identical(models, dtype):
 
 
 def test_grad_ready_events_are_recorded_in_backward_order():
-    """tf_detnet_set_grad_events (data-parallel overlap): the executor records the caller's events while enqueuing the
-    backward pass.  The event of a LATER bucket (lower block index) must not complete before an earlier one, all of them
+    """tf_detnet_hooks.events (data-parallel overlap; r4: an argument of the model's own backward call, `model._grad_events`): the executor
+    records the caller's events while enqueuing the backward pass.  The event of a LATER bucket (lower block index) must not complete before an earlier one, all of them
     must complete, and once the last (-1) has, the gradients equal those of a run without events."""
     import ctypes as C
     from tinyfaces import _hip
@@ -437,18 +437,18 @@ def test_grad_ready_events_are_recorded_in_backward_order():
     handles = (C.c_void_p * 4)(*[int(e.cuda_event) for e in evs])
     try:
         _hip.lib().tf_set_stat_rows(0)          # reproducible BN statistics: two runs differ by weight-gradient atomics only
-        assert _hip.lib().tf_detnet_set_grad_events(blocks, handles, 4) == 0
+        m._grad_events = (blocks, handles, 4)
         t0 = torch.cuda.Event(enable_timing=True)
         t0.record()
         grads()
         evs[-1].synchronize()
         got = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
         times = [t0.elapsed_time(e) for e in evs]
-        assert _hip.lib().tf_detnet_set_grad_events(None, None, 0) == 0
+        m._grad_events = None
         grads()
         torch.cuda.synchronize()
     finally:
-        _hip.lib().tf_detnet_set_grad_events(None, None, 0)
+        m._grad_events = None
         _hip.lib().tf_set_stat_rows(8)
     assert all(t > 0 for t in times) and times == sorted(times), times
     worst = max(float((got[k] - p.grad).abs().max() / (p.grad.abs().max() + 1e-30)) for k, p in m.named_parameters() if p.grad is not None)
@@ -456,8 +456,53 @@ def test_grad_ready_events_are_recorded_in_backward_order():
     assert worst < 1e-3
 
 
+def test_context_free_entry_points_equal_the_context_form():
+    """include/tinyfaces_hip.h keeps tf_detnet_forward / tf_detnet_backward + the process-wide setters of rounds 1-3 as wrappers over a default
+    context: the same gradients as the model's own (context + per-call hooks) path, and a registered event is recorded."""
+    import ctypes as C
+    from tinyfaces import _hip
+    from tinyfaces._hip import lib, ptr, stream
+    from tinyfaces.models.model import DetectionModel
+    m = DetectionModel(num_templates=25)
+    _load_oracle_weights(m)
+    m = m.cuda().set_compute_dtype(torch.bfloat16).train()
+    m.flatten_parameters()
+    x = torch.randn(2, 3, 160, 192, generator=torch.Generator().manual_seed(5)).cuda()
+    m._sync_tables(x.device)
+    try:
+        lib().tf_set_stat_rows(0)                # reproducible BN statistics
+        out = m._run_forward(x, training=True)
+        gout = torch.ones_like(out)
+        ref = m._run_backward(x, gout, persistent=True).clone()
+        # the same pass through the context-free entry points
+        N, _, H, W = x.shape
+        bn = m.model.bn1
+        out2 = torch.empty_like(out)
+        assert lib().tf_detnet_forward(m.compute_dtype, 1, ptr(x), N, H, W, m.num_out, m._param_ptrs, float(bn.eps), float(bn.momentum), ptr(out2),
+                                       ptr(m._ws), m._ws.numel(), 0, stream()) == 0
+        ev = torch.cuda.Event()
+        ev.record(); torch.cuda.synchronize()
+        blocks, handles = (C.c_int * 1)(-1), (C.c_void_p * 1)(int(ev.cuda_event))
+        g2 = torch.zeros_like(ref)
+        table = (C.c_void_p * len(m._names))(*[(g2.data_ptr() + 4 * m._segments[k][0]) if k in m._segments else 0 for k in m._names])
+        assert lib().tf_detnet_set_grad_events(blocks, handles, 1) == 0
+        try:
+            assert lib().tf_detnet_backward(m.compute_dtype, ptr(x), N, H, W, m.num_out, m._param_ptrs, table, ptr(gout), ptr(g2), g2.numel() * 4,
+                                            ptr(m._ws), m._ws.numel(), stream()) == 0
+        finally:
+            lib().tf_detnet_set_grad_events(None, None, 0)
+        ev.synchronize()                          # the registered event was recorded behind the whole pass
+        torch.cuda.synchronize()
+    finally:
+        lib().tf_set_stat_rows(8)
+    assert torch.equal(out2, out)
+    rel = float((g2 - ref).abs().max() / ref.abs().max())
+    report("context_free_entry_points", rel=rel)
+    assert rel < 1e-3                             # (fp32 atomics of the non-grouped weight gradients)
+
+
 def test_grad_ready_callback_is_called_per_bucket_with_the_carrying_stream():
-    """r3, tf_detnet_set_grad_callback: while it enqueues the backward pass the executor calls the registered function once per registered
+    """tf_detnet_hooks.fn (r3: tf_detnet_set_grad_callback): while it enqueues the backward pass the executor calls the registered function once per registered
     block, in backward order, with the stream that carries that bucket's gradients -- its second stream for the bottleneck buckets, the
     caller's stream for the final one (-1) -- and with NULL events (callback-only registration).  Work enqueued by the callee on that stream
     (here: a snapshot copy of a bucket's gradient slice) sees the bucket final; an exception inside the callback does not unwind through

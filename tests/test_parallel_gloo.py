@@ -49,6 +49,49 @@ def test_broadcast_and_gradient_average_world2():
     assert all(r[2] and r[3] for r in res)          # averaged, and in place in the flat buffer
 
 
+def _dying_worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(ROOT, "tiny-faces-pytorch_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      TINYFACES_DIST_TIMEOUT_S="20")
+    import time
+    from tinyfaces import parallel
+    assert parallel.init_from_env("gloo")
+    lin = torch.nn.Linear(6, 4)
+    parallel.broadcast_module(lin)
+    red = parallel.GradientReducer(list(lin.parameters()), bucket_mb=1e-4)
+    for p in lin.parameters():
+        p.grad = torch.full_like(p, float(rank + 1))
+    red.average_gradients()                                      # step 1: both ranks alive
+    if rank == 1:
+        os._exit(17)                                             # dies "mid-step": no barrier, no destroy, connections drop
+    t0 = time.time()
+    try:
+        for p in lin.parameters():
+            p.grad = torch.full_like(p, 1.0)
+        red.average_gradients()                                  # step 2: the peer is gone
+        q.put(("no error", time.time() - t0))
+    except Exception as e:                                       # noqa: BLE001 (gloo raises RuntimeError / DistBackendError depending on the version)
+        q.put((type(e).__name__, time.time() - t0))
+
+
+def test_a_dead_rank_fails_the_survivor_fast_world2():
+    """SURVEY.md section 5 (failure detection): rank 1 exits between two steps; rank 0's next gradient exchange must RAISE within the
+    collective deadline (TINYFACES_DIST_TIMEOUT_S) instead of hanging or silently returning unreduced gradients."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_dying_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    what, dt = q.get(timeout=90)
+    [p.join(30) for p in procs]
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+    assert what != "no error", "the survivor completed a collective with a dead peer"
+    assert dt < 30.0, (what, dt)
+    assert procs[1].exitcode == 17
+
+
 def test_single_process_is_a_noop():
     sys.path.insert(0, os.path.join(ROOT, "tiny-faces-pytorch_amd"))
     from tinyfaces import parallel

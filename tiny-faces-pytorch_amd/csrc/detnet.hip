@@ -477,31 +477,71 @@ extern "C" size_t tf_detnet_param_region_bytes(int dtype, int nout, int training
 // kernels of BOTH queues stretch ~1.6x and the step takes 16.7-17.6 ms instead of 10.6 (profiles/r03_stream_priority.txt; GPU_MAX_HW_QUEUES,
 // creation order and the number of streams of our own made no difference, the priority does).  The round-2 CU-mask experiment
 // (hipExtStreamCreateWithCUMask: 603 img/s whatever the mask) looked the same.  TINYFACES_SIDE_PRIO_LOW=1 brings the low priority back.
-static bool g_force_single = false;      // tf_detnet_set_dual_stream(0): everything on the caller's stream
+// ---- r4: the executor's own state lives in an explicit CONTEXT (tf_detnet_ctx): the second stream of the device it was created on (weight
+// gradients of the backward pass; the packing of the layer-3 weights beside the start of the forward pass), the optional group stream, the
+// pool of fork / join events, and -- per backward call -- the caller's gradient-ready hooks (tf_detnet_hooks).  Rounds 1-3 kept all of this in
+// process-wide statics behind an ABI documented as stateless (events created on whichever device ran
+// first).  The entry points without a context (tf_detnet_forward / tf_detnet_backward / tf_detnet_set_*) remain as wrappers over ONE
+// default context per device and thread-unsafe process-wide hooks, for callers that drive one model from one thread.
+// The second stream is created at the DEFAULT priority.  Rounds 1-2 created it at the LOWEST priority ("the weight gradients are off the
+// critical chain"; +0.4 % on the step); r3 found what that costs as soon as the process has a few more busy queues -- RCCL with its
+// collectives overlapping the backward pass, i.e. the data-parallel path -- the kernels of BOTH queues stretch ~1.6x
+// (profiles/r03_stream_priority.txt).  TINYFACES_SIDE_PRIO_LOW=1 brings the low priority back.
+struct tf_detnet_ctx {
+  int device = -1;
+  hipStream_t side = nullptr, gside = nullptr;
+  hipEvent_t pack_fork = nullptr, pack_join = nullptr;
+  std::vector<hipEvent_t> events;
+};
 namespace {
-hipStream_t side_stream(int which = 0) {  // one per device and role (a process normally drives one GPU; the binding may load before set_device)
-  static hipStream_t streams2[2][64] = {};
-  static bool tried_dev2[2][64] = {};
-  hipStream_t* streams = streams2[which & 1];
-  bool* tried_dev = tried_dev2[which & 1];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  hipStream_t& g_side = streams[dev];
-  bool& tried = tried_dev[dev];
-  if (tried) return g_side;
-  tried = true;
+hipStream_t make_stream() {
+  hipStream_t s = nullptr;
   int least = 0, greatest = 0;
   static const bool low_prio = getenv("TINYFACES_SIDE_PRIO_LOW") != nullptr;      // A/B knob (the default of rounds 1-2)
   if (!low_prio || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess ||
-      hipStreamCreateWithPriority(&g_side, hipStreamNonBlocking, least) != hipSuccess) {
-    if (hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) != hipSuccess) g_side = nullptr;
+      hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) s = nullptr;
   }
-  return g_side;
+  return s;
+}
+// streams and events are created lazily, on the device the context belongs to (the caller has made it current: the binding wraps every
+// call in torch.cuda.device(x.device))
+hipStream_t ctx_side(tf_detnet_ctx* x) { if (x && !x->side) x->side = make_stream(); return x ? x->side : nullptr; }
+hipStream_t ctx_gside(tf_detnet_ctx* x) { if (x && !x->gside) x->gside = make_stream(); return x ? x->gside : nullptr; }
+tf_detnet_ctx* default_ctx() {            // one per device: what the context-free entry points use
+  static tf_detnet_ctx* per_dev[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (!per_dev[dev]) { per_dev[dev] = new tf_detnet_ctx; per_dev[dev]->device = dev; }
+  return per_dev[dev];
 }
 }  // namespace
+extern "C" int tf_detnet_ctx_create(tf_detnet_ctx** out) {
+  if (!out) return TF_ERR_ARG;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return TF_ERR_LAUNCH;
+  tf_detnet_ctx* x = new tf_detnet_ctx; x->device = dev;
+  *out = x;
+  return TF_OK;
+}
+extern "C" int tf_detnet_ctx_destroy(tf_detnet_ctx* x) {
+  if (!x) return TF_OK;
+  if (x->side) (void)hipStreamSynchronize(x->side);
+  if (x->gside) (void)hipStreamSynchronize(x->gside);
+  for (hipEvent_t e : x->events) (void)hipEventDestroy(e);
+  if (x->pack_fork) (void)hipEventDestroy(x->pack_fork);
+  if (x->pack_join) (void)hipEventDestroy(x->pack_join);
+  if (x->side) (void)hipStreamDestroy(x->side);
+  if (x->gside) (void)hipStreamDestroy(x->gside);
+  delete x;
+  return TF_OK;
+}
+// legacy process-wide switches (tf_detnet_set_dual_stream / _grad_events / _grad_callback): hooks of the context-free entry points
+static bool g_force_single = false;      // tf_detnet_set_dual_stream(0): everything on the caller's stream
 
-extern "C" int tf_detnet_forward(int dtype, int training, const float* x, int N, int H, int W, int nout, void* const* params, float eps,
-                                 float mom, float* out, void* ws, size_t ws_bytes, int flags, void* stream_) {
+extern "C" int tf_detnet_forward_ctx(tf_detnet_ctx* xctx, int single_stream, int dtype, int training, const float* x, int N, int H, int W, int nout,
+                                     void* const* params, float eps, float mom, float* out, void* ws, size_t ws_bytes, int flags, void* stream_) {
+  if (!xctx) xctx = default_ctx();
   if (!x || !params || !out || !ws || nout <= 0 || nout > kHeadLd) return TF_ERR_ARG;
   if (dtype != TF_BF16 && dtype != TF_F32 && dtype != TF_F16) return TF_ERR_UNSUPPORTED;
   if (dtype == TF_F16 && training) return TF_ERR_UNSUPPORTED;       // fp16 operands: the inference graph only (BASELINE.json configs[4])
@@ -528,24 +568,24 @@ extern "C" int tf_detnet_forward(int dtype, int training, const float* x, int N,
   // r3 experiment, NEGATIVE, kept behind TINYFACES_PACK_SIDE=1: the weight re-packing of a training step (three launches, ~170 us: 111 MB
   // of masters read, 2 x 55 MB written) on a second stream BESIDE the stem's im2col (~130 us) -- both are HBM-bound, side by side they
   // take as long as back to back and the fork / join events cost a little: 1153 / 1153 img/s against 1161 / 1159 inline (A/B on one box).
-  static hipStream_t g_pack_stream = nullptr;      // = the executor's second stream: idle during the forward pass, no further hardware queue
-  static hipEvent_t g_pack_fork = nullptr, g_pack_join = nullptr;
+  bool pack_joined = false;
+  hipStream_t g_pack_stream = nullptr;             // = the context's second stream: idle during the forward pass, no further hardware queue
   static const bool pack_side_env = getenv("TINYFACES_PACK_SIDE") != nullptr;
   // r3, second form: only the weights of layer 3 and of the heads (62 % of the bytes) go to the second stream, forked at the top of the step
   // and joined in front of the first layer-3 bottleneck: they are packed beside the stem and layers 1-2, whose launches are latency-bound
   // at bs = 12, instead of in front of them.  TINYFACES_PACK_SPLIT_OFF=1: everything inline.
   static const bool pack_split_off = getenv("TINYFACES_PACK_SPLIT_OFF") != nullptr;
   static const bool single_env = getenv("TINYFACES_SINGLE_STREAM") != nullptr;
-  const bool pack_split = tr && !ready && !pack_side_env && !pack_split_off && !single_env && !g_force_single;
+  const bool pack_split = tr && !ready && !pack_side_env && !pack_split_off && !single_env && !single_stream && xctx;
   bool pack_side = tr && !ready && (pack_side_env || pack_split);
   if (pack_side) {
-    g_pack_stream = side_stream();
-    if (g_pack_stream && !g_pack_fork && (hipEventCreateWithFlags(&g_pack_fork, hipEventDisableTiming) != hipSuccess ||
-                                          hipEventCreateWithFlags(&g_pack_join, hipEventDisableTiming) != hipSuccess)) g_pack_stream = nullptr;
+    g_pack_stream = ctx_side(xctx);
+    if (g_pack_stream && !xctx->pack_fork && (hipEventCreateWithFlags(&xctx->pack_fork, hipEventDisableTiming) != hipSuccess ||
+                                              hipEventCreateWithFlags(&xctx->pack_join, hipEventDisableTiming) != hipSuccess)) g_pack_stream = nullptr;
   }
   if (!g_pack_stream) pack_side = false;
   if (pack_side) {           // everything enqueued so far (the previous step's SGD: the masters) precedes the packing
-    if (hipEventRecord(g_pack_fork, c.stream) != hipSuccess || hipStreamWaitEvent(g_pack_stream, g_pack_fork, 0) != hipSuccess) c.chk(TF_ERR_LAUNCH);
+    if (hipEventRecord(xctx->pack_fork, c.stream) != hipSuccess || hipStreamWaitEvent(g_pack_stream, xctx->pack_fork, 0) != hipSuccess) c.chk(TF_ERR_LAUNCH);
   }
   c.chk(tf_stem_im2col(x, N, H, W, dtype, P.col, kStemK, c.stream));
   // ---- every weight of the pass re-packed from the fp32 master copy in two launches
@@ -569,8 +609,8 @@ extern "C" int tf_detnet_forward(int dtype, int training, const float* x, int N,
   }
   c.flush_packs(pack_side ? g_pack_stream : nullptr);
   if (pack_side) {
-    if (hipEventRecord(g_pack_join, g_pack_stream) != hipSuccess) c.chk(TF_ERR_LAUNCH);
-    if (!pack_split && hipStreamWaitEvent(c.stream, g_pack_join, 0) != hipSuccess) c.chk(TF_ERR_LAUNCH);
+    if (hipEventRecord(xctx->pack_join, g_pack_stream) != hipSuccess) c.chk(TF_ERR_LAUNCH);
+    if (!pack_split && hipStreamWaitEvent(c.stream, xctx->pack_join, 0) != hipSuccess) c.chk(TF_ERR_LAUNCH);
   }
   }
   conv_fill(a, dtype, 0, 1, 1, M1, kStemK, 1, M1, 64, 1, 1, 0, 64, P.col, P.wstem, P.cstem);
@@ -592,7 +632,7 @@ extern "C" int tf_detnet_forward(int dtype, int training, const float* x, int N,
     Plan::Blk& b = P.blk[i];
     const int pl = B.planes, c4 = pl * 4;
     const int Min = N * b.Hin * b.Win, Mout = N * b.Hout * b.Wout;
-    if (pack_side && pack_split && (int)i == A.layer_end[1] + 1 && hipStreamWaitEvent(c.stream, g_pack_join, 0) != hipSuccess) c.chk(TF_ERR_LAUNCH);
+    if (pack_side && pack_split && (int)i == A.layer_end[1] + 1) { pack_joined = true; if (hipStreamWaitEvent(c.stream, xctx->pack_join, 0) != hipSuccess) c.chk(TF_ERR_LAUNCH); }
     // conv1 1x1
     conv_fill(a, dtype, 0, N, b.Hin, b.Win, B.cin, b.Hin, b.Win, pl, 1, 1, 0, pl, yin, b.w1, b.c1);
     if (tr) { a.epi = TF_EPI_STATS; a.stat_out = fused ? b.b1.fst : P.partial; stat_shift(a, c, B.c1, b.b1, fused); }
@@ -669,8 +709,13 @@ extern "C" int tf_detnet_forward(int dtype, int training, const float* x, int N,
   a.epi = TF_EPI_AFFINE; a.epi_scale = P.ones; a.epi_shift = P.hbias4; a.alg_n = nout;
   c.chk(tf_conv2d(&a, c.stream));
   c.chk(tf_upsample_add_crop(dtype, P.s3, P.s4, P.wup_diag, N, nout, kHeadLd, P.H3, P.W3, P.H4, P.W4, out, c.stream));
+  if (pack_side && pack_split && !pack_joined) (void)hipStreamWaitEvent(c.stream, xctx->pack_join, 0);      // (never leave the caller's stream un-joined)
   if (hipGetLastError() != hipSuccess && c.rc == TF_OK) c.rc = TF_ERR_LAUNCH;
   return c.rc;
+}
+extern "C" int tf_detnet_forward(int dtype, int training, const float* x, int N, int H, int W, int nout, void* const* params, float eps,
+                                 float mom, float* out, void* ws, size_t ws_bytes, int flags, void* stream_) {
+  return tf_detnet_forward_ctx(nullptr, g_force_single ? 1 : 0, dtype, training, x, N, H, W, nout, params, eps, mom, out, ws, ws_bytes, flags, stream_);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -727,57 +772,60 @@ void wgrad(Ctx& c, const ConvUnit& u, int cout, int N, int H, int W, int OH, int
 
 }  // namespace
 
-// gradient-ready events (data-parallel overlap): after the weight gradients of bottleneck `block` (backward order: the
-// LAST block of a bucket) are enqueued, the caller's event is recorded on the stream that carries them, so a communication
-// stream can start reducing that bucket while the rest of the backward pass runs.  block -1 = the very end (stem done).
-static std::vector<std::pair<int, hipEvent_t>> g_grad_events;
+// gradient-ready hooks (data-parallel overlap): after the weight gradients of bottleneck `block` (backward order: the LAST block of a
+// bucket) are enqueued, the caller's event is recorded on the stream that carries them and / or the caller's function is called with that
+// stream, so that the bucket's all-reduce starts while the rest of the backward pass runs.  block -1 = the very end (stem done).
+// r4: the hooks are an ARGUMENT of the backward call (tf_detnet_hooks), not a process-wide registration.
+static std::vector<std::pair<int, hipEvent_t>> g_grad_events;      // legacy registration (tf_detnet_set_grad_events), used by tf_detnet_backward only
 extern "C" int tf_detnet_set_grad_events(const int* blocks, void* const* events, int n) {
   g_grad_events.clear();
   if (n < 0 || (n > 0 && (!blocks || !events))) return TF_ERR_ARG;       // (events[k] itself may be NULL)
   for (int k = 0; k < n; ++k) g_grad_events.emplace_back(blocks[k], (hipEvent_t)events[k]);      // a NULL event: the callback only
   return TF_OK;
 }
-// r3: ... or the caller's FUNCTION is called at that point with the stream that carries the bucket (tf_detnet_set_grad_callback): whatever it
-// enqueues there -- the bucket's all-reduce -- is stream-ordered behind the bucket's last gradient kernel with no stream of its own in
-// between (the event form needs a communication stream that does nothing but wait for the events).
 static tf_grad_ready_fn g_grad_cb = nullptr;
 static void* g_grad_cb_user = nullptr;
 extern "C" int tf_detnet_set_grad_callback(tf_grad_ready_fn fn, void* user) { g_grad_cb = fn; g_grad_cb_user = user; return TF_OK; }
-static void record_grad_events(int block, hipStream_t s, int& rc) {
+static void record_grad_events(const tf_detnet_hooks* h, int block, hipStream_t s, int& rc) {
+  if (!h) return;
   bool registered = false;
-  for (const auto& e : g_grad_events)
-    if (e.first == block) {
+  for (int k = 0; k < h->n; ++k)
+    if (h->blocks[k] == block) {
       registered = true;
-      if (e.second && hipEventRecord(e.second, s) != hipSuccess && rc == TF_OK) rc = TF_ERR_LAUNCH;
+      hipEvent_t e = h->events ? (hipEvent_t)h->events[k] : nullptr;
+      if (e && hipEventRecord(e, s) != hipSuccess && rc == TF_OK) rc = TF_ERR_LAUNCH;
     }
-  if (registered && g_grad_cb) g_grad_cb(block, (void*)s, g_grad_cb_user);
+  if (registered && h->fn) h->fn(block, (void*)s, h->user);
 }
-static bool grad_event_registered(int block) {
-  for (const auto& e : g_grad_events) if (e.first == block) return true;
+static bool grad_event_registered(const tf_detnet_hooks* h, int block) {
+  if (!h) return false;
+  for (int k = 0; k < h->n; ++k) if (h->blocks[k] == block) return true;
   return false;
 }
 // 1 = weight gradients on a second stream (default), 0 = everything on the caller's stream (A/B + race tests)
 extern "C" int tf_detnet_set_dual_stream(int on) { g_force_single = !on; return TF_OK; }
 
-extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W, int nout, void* const* params, void* const* grads,
-                                  const float* gout, void* grad_flat, size_t grad_flat_bytes, void* ws, size_t ws_bytes, void* stream_) {
+extern "C" int tf_detnet_backward_ctx(tf_detnet_ctx* xctx, const tf_detnet_hooks* hooks, int dtype, const float* x, int N, int H, int W, int nout,
+                                      void* const* params, void* const* grads, const float* gout, void* grad_flat, size_t grad_flat_bytes,
+                                      void* ws, size_t ws_bytes, void* stream_) {
   if (!x || !params || !grads || !gout || !ws) return TF_ERR_ARG;
+  if (hooks && (hooks->n < 0 || (hooks->n > 0 && !hooks->blocks))) return TF_ERR_ARG;
+  if (!xctx) xctx = default_ctx();
   if (dtype != TF_BF16 && dtype != TF_F32) return TF_ERR_UNSUPPORTED;
   const Arch& A = arch();
   Plan P; Arena ar(ws, ws_bytes);
   build_plan(P, ar, dtype, N, H, W, nout, 1);
   if (!ar.ok) return TF_ERR_WORKSPACE;
   Ctx c{dtype, (hipStream_t)stream_, params, grads, TF_OK};   // (grads_zeroed / jobs default-initialised)
-  static std::vector<hipEvent_t> g_events;
   static const bool g_single_env = getenv("TINYFACES_SINGLE_STREAM") != nullptr;
-  if (!g_single_env && !g_force_single) {
-    hipStream_t g_side = side_stream();
-    c.side = g_side; c.events = &g_events;
+  if (!g_single_env && !(hooks && hooks->single_stream) && xctx) {
+    hipStream_t g_side = ctx_side(xctx);
+    c.side = g_side; c.events = &xctx->events;
     // r4, measured NEGATIVE, opt-in (TINYFACES_GROUP_STREAM=1): the grouped launches on a third queue, so that the per-block gradients of
     // layer 3.0 / layers 1-2 do not queue up behind a group: 1170 / 1164 img/s against 1177 / 1181 on the second stream (A/B on one box,
     // main-queue idle time of the backward pass 508 instead of 379 us): a third busy queue costs more than the queueing it removes.
     static const bool gstream_on = getenv("TINYFACES_GROUP_STREAM") != nullptr;
-    if (g_side && gstream_on) c.gside = side_stream(1);
+    if (g_side && gstream_on) c.gside = ctx_gside(xctx);
   }
   tf_conv_args a;
   const int M3 = N * P.H3 * P.W3, M4 = N * P.H4 * P.W4;
@@ -899,7 +947,7 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
     // a gradient-ready event of a grouped block promises "every gradient of the blocks >= it, and of the heads": the heads and layer3.x
     // per-block launches live on the second stream, so the group's stream first orders itself behind that stream's position
     if (c.gside && !pend_blocks.empty()) { hipEvent_t e = c.mark(c.side); if (e) (void)hipStreamWaitEvent(c.gside, e, 0); }
-    for (int blk : pend_blocks) record_grad_events(blk, c.gstream(), c.rc);
+    for (int blk : pend_blocks) record_grad_events(hooks, blk, c.gstream(), c.rc);
     pend_pw.clear(); pend_c3.clear(); pend_blocks.clear();
   };
   // ---- bottlenecks in reverse
@@ -1037,11 +1085,11 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
       // everything up to here: the weight / BN gradients of blocks >= i and of the heads.  With a group stream they are spread over two
       // queues: the event goes to the group stream, ordered behind the second stream's position (never the other way round: the second
       // stream must not wait for a group)
-      if (c.gside && grad_event_registered(i)) {
+      if (c.gside && grad_event_registered(hooks, i)) {
         hipEvent_t e = c.mark(c.side); if (e) (void)hipStreamWaitEvent(c.gside, e, 0);
-        record_grad_events(i, c.gside, c.rc);
+        record_grad_events(hooks, i, c.gside, c.rc);
       } else {
-        record_grad_events(i, c.wstream(), c.rc);
+        record_grad_events(hooks, i, c.wstream(), c.rc);
       }
     }                                                // (grouped blocks: their events fire in flush_group)
     void* t = Gcur; Gcur = Gnext; Gnext = t;
@@ -1063,7 +1111,17 @@ extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W
   }
   c.wait_on_main(c.mark_side());           // join: the caller's stream sees every weight gradient
   if (c.gside) c.wait_on_main(c.mark(c.gside));
-  record_grad_events(-1, c.stream, c.rc);
+  record_grad_events(hooks, -1, c.stream, c.rc);
   if (hipGetLastError() != hipSuccess && c.rc == TF_OK) c.rc = TF_ERR_LAUNCH;
   return c.rc;
+}
+
+// context-free form (rounds 1-3): the default context of the current device + the process-wide hooks registered with tf_detnet_set_*
+extern "C" int tf_detnet_backward(int dtype, const float* x, int N, int H, int W, int nout, void* const* params, void* const* grads,
+                                  const float* gout, void* grad_flat, size_t grad_flat_bytes, void* ws, size_t ws_bytes, void* stream_) {
+  std::vector<int> blocks; std::vector<void*> events;
+  for (const auto& e : g_grad_events) { blocks.push_back(e.first); events.push_back((void*)e.second); }
+  tf_detnet_hooks h;
+  h.blocks = blocks.data(); h.events = events.data(); h.n = (int)blocks.size(); h.fn = g_grad_cb; h.user = g_grad_cb_user; h.single_stream = g_force_single ? 1 : 0;
+  return tf_detnet_backward_ctx(nullptr, &h, dtype, x, N, H, W, nout, params, grads, gout, grad_flat, grad_flat_bytes, ws, ws_bytes, stream_);
 }

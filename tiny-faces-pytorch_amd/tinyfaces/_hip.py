@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtinyfaces_hip.so")
 
 TF_F32, TF_BF16, TF_F16 = 0, 1, 2
+TF_COMM_ID_BYTES = 128
 EPI_AFFINE, EPI_RES, EPI_RELU, EPI_STATS, EPI_MASK, EPI_STATS2, EPI_JOIN, EPI_MASK2, EPI_STATS3 = 1, 2, 4, 8, 16, 32, 64, 128, 256
 ERRORS = {-1: "TF_ERR_ARG", -2: "TF_ERR_LAUNCH", -3: "TF_ERR_UNSUPPORTED", -4: "TF_ERR_WORKSPACE"}
 
@@ -45,6 +46,17 @@ class BnFwdDesc(C.Structure):
 class BnBwdDesc(C.Structure):
     """tf_bn_bwd_desc (include/tinyfaces_hip.h)."""
     _fields_ = [("stat", vp), ("gamma", vp), ("mean", vp), ("invstd", vp), ("dgamma", vp), ("dbeta", vp), ("nk", i32), ("kidx", i32)]
+
+
+class DetnetHooks(C.Structure):
+    """tf_detnet_hooks (include/tinyfaces_hip.h): the gradient-ready hooks of ONE backward call."""
+    _fields_ = [("blocks", C.POINTER(i32)), ("events", C.POINTER(vp)), ("n", i32), ("fn", vp), ("user", vp), ("single_stream", i32)]
+
+
+class CommPlan(C.Structure):
+    """tf_comm_plan (include/tinyfaces_hip.h): block -> element range of the flat gradient, for tf_comm_allreduce_hook."""
+    _fields_ = [("comm", vp), ("grad_flat", vp), ("n", i32), ("blocks", C.POINTER(i32)), ("start", C.POINTER(i64)), ("end", C.POINTER(i64)),
+                ("rc", i32), ("issued", i32)]
 
 
 class ConvArgs(C.Structure):
@@ -122,6 +134,19 @@ _SIGNATURES = {
     "tf_detnet_set_grad_events": (i32, [vp, vp, i32]),
     "tf_detnet_forward": (i32, [i32, i32, vp, i32, i32, i32, i32, vp, f32, f32, vp, vp, sz, i32, vp]),
     "tf_detnet_backward": (i32, [i32, vp, i32, i32, i32, i32, vp, vp, vp, vp, sz, vp, sz, vp]),
+    "tf_comm_available": (i32, []),
+    "tf_comm_unique_id": (i32, [vp]),
+    "tf_comm_init": (i32, [vp, i32, i32, C.POINTER(vp)]),
+    "tf_comm_destroy": (i32, [vp]),
+    "tf_comm_rank": (i32, [vp]),
+    "tf_comm_world": (i32, [vp]),
+    "tf_allreduce_bucket": (i32, [vp, vp, sz, vp]),
+    "tf_comm_join": (i32, [vp, vp]),
+    "tf_comm_allreduce_hook": (None, [i32, vp, vp]),
+    "tf_detnet_ctx_create": (i32, [C.POINTER(vp)]),
+    "tf_detnet_ctx_destroy": (i32, [vp]),
+    "tf_detnet_forward_ctx": (i32, [vp, i32, i32, i32, vp, i32, i32, i32, i32, vp, f32, f32, vp, vp, sz, i32, vp]),
+    "tf_detnet_backward_ctx": (i32, [vp, C.POINTER(DetnetHooks), i32, vp, i32, i32, i32, i32, vp, vp, vp, vp, sz, vp, sz, vp]),
     "tf_pack_weights_batched": (i32, [i32, vp, i32, vp]),
     "tf_pack_weights_tiled": (i32, [i32, vp, i32, vp]),
     "tf_detnet_set_dual_stream": (i32, [i32]),

@@ -24,7 +24,7 @@ from ._hip import lib
 
 
 class TrainEngine:
-    def __init__(self, model, criterion, lr=1e-4, momentum=0.9, weight_decay=5e-4, device="cuda", bucket_mb=10):
+    def __init__(self, model, criterion, lr=1e-4, momentum=0.9, weight_decay=5e-4, device="cuda", bucket_mb=10, native_exchange=False):
         self.device = torch.device(device)
         self.model = model.to(self.device).train()
         self.criterion = criterion
@@ -36,8 +36,10 @@ class TrainEngine:
         self.lr, self.momentum, self.weight_decay = lr, momentum, weight_decay
         self.bucket_elems = int(bucket_mb * (1 << 20) // 4)
         self.steps = 0
+        self.native_exchange = bool(native_exchange)
         self.skip_allreduce = False          # measurement knob (bench.py): a step without the exchange, to size what the overlap hides
         self._overlap = None
+        self._native = None
         # r3 experiment, NEGATIVE, opt-in (TINYFACES_SGD_PER_BUCKET=1): the gradient buckets (and the events the executor records when a
         # bucket is final) also drive the optimizer -- the SGD update of a bucket on the communication stream as soon as the bucket is
         # final (after its all-reduce when data-parallel), beside the rest of the backward pass, instead of over all 42.5 M parameters
@@ -103,12 +105,48 @@ class TrainEngine:
         # of ours any more (TINYFACES_ALLREDUCE_COMM_STREAM=1 brings the event-waiting stream of rounds 1-2 back).  Checked on one GPU with
         # a 1-rank RCCL group (TINYFACES_FORCE_DIST=1): 1106 img/s against 1124 without the collectives.
         self._use_comm_stream = bool(os.environ.get("TINYFACES_ALLREDUCE_COMM_STREAM")) or bool(os.environ.get("TINYFACES_ALLREDUCE_ON_MAIN"))
+        # r4: the NATIVE exchange (TINYFACES_ALLREDUCE_NATIVE=1 / native_exchange=True): the executor's gradient hook is the library's own
+        # tf_comm_allreduce_hook -- ncclAllReduce issued from C on the communicator's stream, no Python (no GIL) inside the backward enqueue,
+        # the path a maintainer binding only the C ABI gets (include/tinyfaces_hip.h: tf_comm_*).  The communicator's identifier travels
+        # through the torch.distributed group that already exists (any backend).  Opt-in: like the torch path it has only ever seen a
+        # 1-rank group on hardware (tests/test_gpu_dist.py); the default stays the torch.distributed callback below.
+        self._native = None
+        if (self.native_exchange or os.environ.get("TINYFACES_ALLREDUCE_NATIVE")) and not self._use_comm_stream and not self.sgd_per_bucket:
+            self._native = self._setup_native(ranges)
         self._works, self._cb_error, self._ext_streams = [], None, {}
         self._block_range = {r[0]: (r[1], r[2]) for r in ranges}
         self._cb = C.CFUNCTYPE(None, C.c_int, C.c_void_p, C.c_void_p)(self._on_bucket)
         self.model._grad_callback = None if self._use_comm_stream else self._cb
+        self.model._grad_callback_user = None
+        if self._native is not None:          # the C hook + its plan instead of the ctypes callback
+            self.model._grad_callback = C.cast(lib().tf_comm_allreduce_hook, C.c_void_p)
+            self.model._grad_callback_user = C.cast(C.pointer(self._native["plan"]), C.c_void_p)
         self._overlap = dict(ranges=ranges, events=events, comm=torch.cuda.Stream(device=self.device) if self._use_comm_stream or self.sgd_per_bucket else None,
                              keep=(blocks, handles))
+
+    def _setup_native(self, ranges):
+        from . import _hip
+        if not lib().tf_comm_available():
+            raise RuntimeError("TINYFACES_ALLREDUCE_NATIVE: librccl.so could not be resolved at run time")
+        ident = [bytes(_hip.TF_COMM_ID_BYTES)]
+        if parallel.rank() == 0:
+            buf = C.create_string_buffer(_hip.TF_COMM_ID_BYTES)
+            _hip.check(lib().tf_comm_unique_id(buf), "tf_comm_unique_id")
+            ident = [buf.raw]
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            dist.broadcast_object_list(ident, src=0)
+        comm = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _hip.check(lib().tf_comm_init(ident[0], parallel.rank(), parallel.world_size(), C.byref(comm)), "tf_comm_init")
+        n = len(ranges)
+        blocks = (C.c_int * n)(*[r[0] for r in ranges])
+        start = (C.c_int64 * n)(*[r[1] for r in ranges])
+        end = (C.c_int64 * n)(*[r[2] for r in ranges])
+        plan = _hip.CommPlan()
+        plan.comm, plan.grad_flat, plan.n = comm, self.model._grad_flat_persistent.data_ptr(), n
+        plan.blocks, plan.start, plan.end = C.cast(blocks, C.POINTER(C.c_int)), C.cast(start, C.POINTER(C.c_int64)), C.cast(end, C.POINTER(C.c_int64))
+        plan.rc, plan.issued = 0, 0
+        return dict(comm=comm, plan=plan, keep=(blocks, start, end), n=n)
 
     def _on_bucket(self, block, stream_ptr, _user):
         """Called by the executor while it enqueues the backward pass: bucket `block` is final at the tail of `stream_ptr`."""
@@ -136,6 +174,10 @@ class TrainEngine:
             if getattr(self.model, "_grad_events", None) is not None and self.model._grad_events[0] is self._overlap["keep"][0]:
                 self.model._grad_events = None
                 self.model._grad_callback = None
+                self.model._grad_callback_user = None
+            if getattr(self, "_native", None) is not None:
+                lib().tf_comm_destroy(self._native["comm"])
+                self._native = None
             self._overlap = None
 
     def __del__(self):
@@ -214,6 +256,17 @@ class TrainEngine:
             for (_, start, end) in (self._overlap["ranges"] if self._overlap is not None else [(0, 0, gflat.numel())]):
                 dist.all_reduce(gflat[start:end], op=dist.ReduceOp.SUM)
             return
+        if self._native is not None:
+            # the collectives were issued by tf_comm_allreduce_hook during the backward call: the training stream waits for the communicator
+            plan = self._native["plan"]
+            issued, rc = plan.issued, plan.rc
+            plan.issued, plan.rc = 0, 0
+            if rc != 0 or issued != self._native["n"]:
+                raise RuntimeError(f"data-parallel step (native exchange): {issued} of {self._native['n']} gradient buckets were reduced, rc = {rc}")
+            from . import _hip
+            with torch.cuda.device(self.device):
+                _hip.check(lib().tf_comm_join(self._native["comm"], torch.cuda.current_stream(self.device).cuda_stream), "tf_comm_join")
+            return
         if self._overlap is not None and not self._use_comm_stream:
             # the collectives were issued by _on_bucket during the backward call: the training stream waits for them here
             works, self._works = self._works, []
@@ -288,6 +341,8 @@ class TrainEngine:
         out = m._run_forward(x, training=True)
         loss2, grad, _ = ops.criterion_fwd_bwd(out, class_map, regression_map, c.n_templates, c.reg_weight, c.ohem_thresh, c.max_pos,
                                                c.max_neg, c._pos_keep, c._neg_keep, c._next_seed())
+        if self._native is not None:         # (bench.py measures a step without the exchange: the C hook is simply not installed for it)
+            m._grad_callback = None if self.skip_allreduce else C.cast(lib().tf_comm_allreduce_hook, C.c_void_p)
         gflat = m._run_backward(x, grad, persistent=True)
         scale = 1.0
         reduce = parallel.is_distributed() and not self.skip_allreduce

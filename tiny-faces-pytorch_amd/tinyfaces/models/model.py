@@ -242,8 +242,9 @@ class DetectionModel(nn.Module):
         lane["ready"] = key
         bn = self.model.bn1
         with torch.cuda.device(x.device):
-            check(lib().tf_detnet_forward(self.compute_dtype, 0, ptr(x), N, H, W, self.num_out, self._param_ptrs, float(bn.eps), float(bn.momentum),
-                                          ptr(out), ptr(ws), ws.numel(), flags, lane["stream"].cuda_stream), "tf_detnet_forward")
+            check(lib().tf_detnet_forward_ctx(self._ctx(x.device), int(self.single_stream), self.compute_dtype, 0, ptr(x), N, H, W, self.num_out, self._param_ptrs,
+                                              float(bn.eps), float(bn.momentum), ptr(out), ptr(ws), ws.numel(), flags, lane["stream"].cuda_stream),
+                  "tf_detnet_forward_ctx")
         return out
 
     # ---- executor plumbing ---------------------------------------------------------------
@@ -323,6 +324,27 @@ class DetectionModel(nn.Module):
             return seg[ks[0]][0], seg[ks[-1]][0] + (seg[ks[-1]][1] + 3) // 4 * 4
         return [span("model.") + (1.0,), span("score_res3.") + (0.1,), span("score_res4.") + (1.0,), span("score4_upsample.") + (0.0,)]
 
+    def _ctx(self, device):
+        """The executor context of this model on `device` (include/tinyfaces_hip.h: tf_detnet_ctx -- second stream + event pool): created on
+        first use with that device current, destroyed with the model.  Two models never share a stream or an event."""
+        ctxs = self.__dict__.setdefault("_exec_ctx", {})
+        key = (device.type, device.index)
+        if key not in ctxs:
+            h = C.c_void_p()
+            with torch.cuda.device(device):
+                check(lib().tf_detnet_ctx_create(C.byref(h)), "tf_detnet_ctx_create")
+            ctxs[key] = h
+        return ctxs[key]
+
+    def __del__(self):
+        for h in self.__dict__.get("_exec_ctx", {}).values():
+            try:
+                lib().tf_detnet_ctx_destroy(h)
+            except Exception:
+                pass
+
+    single_stream = False            # True: weight gradients on the caller's stream (A/B + race-screen tests)
+
     def _workspace(self, device, nbytes):
         if self._ws is None or self._ws.device != device or self._ws.numel() < nbytes:
             self._ws = None
@@ -368,9 +390,9 @@ class DetectionModel(nn.Module):
                 flags = TF_DETNET_WEIGHTS_READY
             self._ready_key = key
         with torch.cuda.device(x.device):
-            check(lib().tf_detnet_forward(self.compute_dtype, int(training), ptr(x), N, H, W, self.num_out, self._param_ptrs,
-                                          float(bn.eps), float(bn.momentum), ptr(out), ptr(ws), ws.numel(), flags, stream()),
-                  "tf_detnet_forward")
+            check(lib().tf_detnet_forward_ctx(self._ctx(x.device), int(self.single_stream), self.compute_dtype, int(training), ptr(x), N, H, W, self.num_out,
+                                              self._param_ptrs, float(bn.eps), float(bn.momentum), ptr(out), ptr(ws), ws.numel(), flags, stream()),
+                  "tf_detnet_forward_ctx")
         if training:
             if getattr(self, "_flat_nbt", None) is not None:
                 self._flat_nbt += 1                                      # all 94 counters in one launch
@@ -403,26 +425,21 @@ class DetectionModel(nn.Module):
                 self._persist_table = (gflat.data_ptr(), table)
         else:
             table = cache[1]
-        # gradient-ready events of a data-parallel TrainEngine live in THIS model (`_grad_events`, set by the engine that owns it):
-        # they are handed to the executor for the duration of this model's backward call only, so several models / engines in one
-        # process never see each other's events (the executor's registration is a per-call argument in all but the C signature)
+        # gradient-ready hooks of a data-parallel TrainEngine live in THIS model (`_grad_events`, `_grad_callback`, set by the engine that
+        # owns it) and travel as an ARGUMENT of this model's own backward call (tf_detnet_hooks, r4): nothing is registered process-wide,
+        # several models / engines / threads never see each other's events.  The callback reduces slices of the PERSISTENT flat buffer, so
+        # the autograd path (fresh buffer per call; trainer.train reduces behind the backward pass, parallel.GradientReducer) never gets it.
         ev = getattr(self, "_grad_events", None)
-        # ctypes function (block, stream, user), owned by the engine; it reduces slices of the PERSISTENT flat buffer, so the autograd path
-        # (fresh buffer per call; trainer.train reduces behind the backward pass, parallel.GradientReducer) never installs it
         cb = getattr(self, "_grad_callback", None) if (ev is not None and persistent) else None
+        hooks = _hip.DetnetHooks()
+        if ev is not None:
+            hooks.blocks, hooks.events, hooks.n = C.cast(ev[0], C.POINTER(C.c_int)), C.cast(ev[1], C.POINTER(C.c_void_p)), ev[2]
+        hooks.fn = C.cast(cb, C.c_void_p) if cb is not None else None
+        hooks.user = getattr(self, "_grad_callback_user", None) if cb is not None else None
+        hooks.single_stream = int(self.single_stream)
         with torch.cuda.device(x.device):
-            if ev is not None:
-                check(lib().tf_detnet_set_grad_events(ev[0], ev[1], ev[2]), "tf_detnet_set_grad_events")
-            if cb is not None:
-                check(lib().tf_detnet_set_grad_callback(cb, None), "tf_detnet_set_grad_callback")
-            try:
-                check(lib().tf_detnet_backward(self.compute_dtype, ptr(x), N, H, W, self.num_out, self._param_ptrs, table, ptr(gout),
-                                               ptr(gflat), gflat.numel() * 4, ptr(self._ws), self._ws.numel(), stream()), "tf_detnet_backward")
-            finally:
-                if cb is not None:
-                    lib().tf_detnet_set_grad_callback(None, None)
-                if ev is not None:
-                    lib().tf_detnet_set_grad_events(None, None, 0)
+            check(lib().tf_detnet_backward_ctx(self._ctx(x.device), C.byref(hooks), self.compute_dtype, ptr(x), N, H, W, self.num_out, self._param_ptrs, table,
+                                               ptr(gout), ptr(gflat), gflat.numel() * 4, ptr(self._ws), self._ws.numel(), stream()), "tf_detnet_backward_ctx")
         self._last_grad_flat = gflat
         if persistent:
             return gflat

@@ -43,7 +43,12 @@ def init_from_env(backend=None):
         backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        dist.init_process_group(backend=backend)
+        # failure detection: a rank that dies mid-step must take the job down, not hang it -- every collective gets a
+        # deadline (TINYFACES_DIST_TIMEOUT_S, default 600 s; gloo additionally sees the closed connection at once), and with RCCL the
+        # watchdog aborts the communicator when it expires (TORCH_NCCL_ASYNC_ERROR_HANDLING defaults to 1 in torch >= 2.2)
+        import datetime
+        timeout = datetime.timedelta(seconds=float(os.environ.get("TINYFACES_DIST_TIMEOUT_S", "600")))
+        dist.init_process_group(backend=backend, timeout=timeout)
     return True
 
 
