@@ -181,7 +181,10 @@ typedef struct tf_conv_args {
   const void* aux; const void* aux2; const void* aux3;
   const float* mask_scale; const float* mask_shift;
   float* stat_out;    /* [mtiles][2][ldy] fp32 partial sums, mtiles = tf_conv_mtiles() */
-  int tile;           /* 0 = auto; else 1:(128x128) 2:(128x64) 3:(64x64) pixels x channels */
+  int tile;           /* 0 = auto (recommended).  Else a kernel / tile code, pixels x channels: 11 128x128, 12 128x64, 13 64x64 on the LDS-DMA
+                         kernel (3-deep ring; 2x = 4-deep, 3x = ring-less, 4x = 2-deep; x4 / x5 / x6 = 128x128 / 128x64 / 64x128 on 32x32x16
+                         fragments), 50 = halo-resident 3x3 kernel, 60 = conv_pwx.  Codes 1-3 (the register-staged kernel of round 1) were
+                         removed in r4: TF_ERR_UNSUPPORTED, like a prologue (pro_scale != NULL) -- tf_conv2d_wgrad keeps its prologue. */
   /* TF_EPI_STATS only (r3): per-channel value subtracted from every output BEFORE it enters the two sums, so that the consumer computes
    * var = E[(x-s)^2] - E[x-s]^2 around a shift s close to the mean instead of E[x^2] - mean^2 (which loses (mean/std)^2 of the
    * significant bits in fp32).  The executor passes the BN's running mean.  stat_shift_out [Cout] receives the shift that was used
@@ -445,18 +448,8 @@ int tf_profile_collect(double* host_out, int max_rows);
  * (kind, M pixels, N output channels, K reduction length, taps, mode (0 fwd, 1 dgrad, 2 wgrad), epilogue flags, launches, total_ms,
  *  algorithmic flops, algorithmic bytes, executed flops) */
 int tf_profile_shapes(double* host_out, int max_rows);
-/* debugging hook of the halo-resident 3x3 kernel (csrc/conv3x3h.hip): register (NULL: clear) a DEVICE buffer of
- * 8 blocks x 8 waves x 64 stages x 8 uint64; the next launches run an instrumented instantiation that stamps s_memtime at the
- * five points of every K stage (scripts/trace_conv3x3h.py).  Not part of the product path. */
-int tf_debug_conv3x3h_trace(void* device_buf);
-/* interference probe of the two-stream contention measurement (csrc/probe.hip, scripts/contention.py): `blocks` workgroups of 256
- * threads that hog ONE CU resource for `iters` rounds -- kind 0 park (LDS capacity + wave slots only), 1 L2 loads, 2 HBM loads,
- * 3 MFMA, 4 LDS-DMA, 5 fp32 atomics, 6 LDS reads; `buf` / `window_bytes`: device window of the memory kinds.  Not part of the
- * product path. */
-int tf_debug_probe(int kind, int blocks, int lds_bytes, void* buf, size_t window_bytes, int iters, void* stream);
-int tf_debug_probe_chain(int kind, int blocks, int lds_bytes, void* buf, size_t window_bytes, int iters, int repeat, void* stream);   /* `repeat` launches from one host call */
-/* test hook: raw lane mapping of ds_read_b64_tr_b16 (see tests/test_gpu_small_ops.py) */
-int tf_probe_tr16(unsigned short* out256, void* stream);
+/* (r4: the debugging / measurement probes -- tf_debug_conv3x3h_trace, tf_debug_probe, tf_debug_probe_chain, tf_probe_tr16 -- are not part of
+ * this ABI any more: tiny-faces-pytorch_amd/csrc/debug_api.h, bound by the test-suite and scripts/ only.) */
 
 #ifdef __cplusplus
 }

@@ -48,8 +48,6 @@ def test_conv_fp16_eval_epilogue_and_refusals():
                         epi=_hip.EPI_AFFINE | _hip.EPI_RES | _hip.EPI_RELU, epi_scale=sc.cuda(), epi_shift=sh.cuda(), aux=to_nhwc(res, H))
     d = err(from_nhwc(y)[:, :Cout], ref)
     assert d[2] < 1e-3
-    with pytest.raises(RuntimeError):                       # tile 2 = register-staged kernel: bf16 / fp32 only
-        ops.conv2d_nhwc(to_nhwc(x, H), ops.pack_weight(w.cuda(), H), Cout, 1, 1, 1, 0, ldy=128, tile=2)
     m = DetectionModel(num_templates=25).cuda().set_compute_dtype(H).train()
     with pytest.raises(RuntimeError, match="UNSUPPORTED"):  # fp16 is an inference dtype here
         m(torch.zeros(1, 3, 64, 64, device="cuda"))

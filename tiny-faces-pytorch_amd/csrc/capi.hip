@@ -1,5 +1,6 @@
 // Library identity + the list of symbols a binding must resolve (checked by the CPU test-suite).
 #include "common.h"
+#include "debug_api.h"
 
 static const char* const kSymbols[] = {
     "tf_version", "tf_symbol_count", "tf_symbol_name",
@@ -16,7 +17,7 @@ static const char* const kSymbols[] = {
     "tf_detnet_num_params", "tf_detnet_param_name", "tf_detnet_param_numel", "tf_detnet_workspace_bytes",
     "tf_detnet_out_shape", "tf_detnet_param_region_bytes", "tf_detnet_forward", "tf_detnet_backward", "tf_detnet_ctx_create", "tf_detnet_ctx_destroy", "tf_detnet_forward_ctx", "tf_detnet_backward_ctx", "tf_comm_available", "tf_comm_unique_id", "tf_comm_init", "tf_comm_destroy", "tf_comm_rank", "tf_comm_world", "tf_allreduce_bucket", "tf_comm_join", "tf_comm_allreduce_hook",
     "tf_detnet_set_dual_stream", "tf_detnet_set_grad_events", "tf_detnet_set_grad_callback",
-    "tf_probe_tr16", "tf_set_stat_rows", "tf_get_stat_rows", "tf_profile_enable", "tf_profile_collect", "tf_profile_shapes", "tf_debug_conv3x3h_trace", "tf_debug_probe", "tf_debug_probe_chain",
+    "tf_set_stat_rows", "tf_get_stat_rows", "tf_profile_enable", "tf_profile_collect", "tf_profile_shapes",
 };
 
 namespace tf {

@@ -24,6 +24,7 @@
 #include <cstdlib>
 #include <type_traits>
 #include "common.h"
+#include "debug_api.h"
 #include "profile.h"
 
 namespace {

@@ -13,6 +13,7 @@
 //   6 ldsread : ds_read_b128 loops                                           -> the LDS read port
 // Not part of the product path (debug symbol of the C ABI, like tf_debug_conv3x3h_trace).
 #include "common.h"
+#include "debug_api.h"
 
 namespace {
 

@@ -117,8 +117,14 @@ def main():
         # StepLR's constructor takes one step() from the lr it finds in the groups: a checkpoint saved at a multiple of LR_STEP epochs
         # already carries the decayed lr and would be decayed AGAIN (the reference has this quirk, main.py:76-83).  Here the fused and
         # the autograd path must train a resumed run at the SAME lr: put every group on the closed form the fused engine uses.
+        # Deliberate divergence from the reference on resume (documented in INTEGRATION.md): the lr stored in the checkpoint's optimizer
+        # state is REPLACED by the closed form of --lr, so a checkpoint trained with a different --lr continues at the new one -- say so.
         for mult, g in zip((1.0, 0.1, 1.0, 0.0), optimizer.param_groups):
-            g["lr"] = lr_at(args.lr, first_epoch) * mult
+            want = lr_at(args.lr, first_epoch) * mult
+            if state is not None and abs(g["lr"] - want) > 1e-12 * max(1.0, abs(want)) and abs(g["lr"] - want * 0.1) > 1e-12 and parallel.rank() == 0:
+                print(f"WARNING: resumed optimizer group has lr {g['lr']:.3g}; continuing at {want:.3g} (closed form of --lr {args.lr:g} at epoch {first_epoch})")
+            g["lr"] = want
+        scheduler._last_lr = [g["lr"] for g in optimizer.param_groups]       # what get_last_lr() reports must be what the groups hold
 
     for epoch in range(first_epoch, args.epochs):
         if hasattr(train_loader, "set_epoch"):

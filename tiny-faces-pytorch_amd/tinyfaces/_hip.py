@@ -151,12 +151,15 @@ _SIGNATURES = {
     "tf_pack_weights_tiled": (i32, [i32, vp, i32, vp]),
     "tf_detnet_set_dual_stream": (i32, [i32]),
     "tf_detnet_set_grad_callback": (i32, [vp, vp]),
-    "tf_probe_tr16": (i32, [vp, vp]),
     "tf_set_stat_rows": (i32, [i32]),
     "tf_get_stat_rows": (i32, []),
     "tf_profile_enable": (i32, [i32]),
     "tf_profile_shapes": (i32, [C.POINTER(C.c_double), i32]),
     "tf_profile_collect": (i32, [C.POINTER(C.c_double), i32]),
+}
+# debugging / measurement probes (csrc/debug_api.h): exported by the library, NOT part of the C ABI of include/tinyfaces_hip.h
+_DEBUG_SIGNATURES = {
+    "tf_probe_tr16": (i32, [vp, vp]),
     "tf_debug_conv3x3h_trace": (i32, [vp]),
     "tf_debug_probe": (i32, [i32, i32, i32, vp, sz, i32, vp]),
     "tf_debug_probe_chain": (i32, [i32, i32, i32, vp, sz, i32, i32, vp]),
@@ -177,6 +180,10 @@ def lib():
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(l, name)          # AttributeError here == ABI mismatch with include/tinyfaces_hip.h
             fn.restype, fn.argtypes = res, args
+        for name, (res, args) in _DEBUG_SIGNATURES.items():
+            fn = getattr(l, name, None)
+            if fn is not None:
+                fn.restype, fn.argtypes = res, args
         _lib = l
     return _lib
 

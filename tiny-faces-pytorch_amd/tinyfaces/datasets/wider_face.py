@@ -49,7 +49,13 @@ def parse_annotations(path, split="train"):
         at += 2 + max(n, 1)
     # pass 2: every record of the file as one (R, 10) array, sliced per image
     rec_lines = [rows[first + i] for _, n, first in heads for i in range(n)]
-    flat = np.abs(np.array(" ".join(rec_lines).split(), dtype=np.float64)).reshape(-1, 10) if rec_lines else np.empty((0, 10))
+    flat = np.abs(np.array(" ".join(rec_lines).split(), dtype=np.float64)) if rec_lines else np.empty(0)
+    if flat.size != 10 * len(rec_lines):          # a record with a missing / extra field would silently shift boxes between images
+        for name, n, first in heads:
+            for i in range(n):
+                if len(rows[first + i].split()) != 10:
+                    raise ValueError(f"{path}: record {i} of {name!r} (line {first + i + 1}) has {len(rows[first + i].split())} fields, expected 10")
+    flat = flat.reshape(-1, 10)
     out, cursor = [], 0
     for name, n, _ in heads:
         rec = flat[cursor:cursor + n]

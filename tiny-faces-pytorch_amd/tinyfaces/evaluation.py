@@ -64,7 +64,10 @@ def _decode_levels(model, levels, templates, t_d, rf, prob_thresh, mask_axis, de
     """Forward + sigmoid / threshold / ordered compaction / refinement of every level, appended to dets[count...].
     The forwards of the levels run side by side on the model's lanes (DetectionModel.forward_levels); the decodes follow in level
     order on the caller's stream, so the candidate list is the sequential loop's row for row."""
-    outs = model.forward_levels([x.to(device, non_blocking=True) for _, x in levels])
+    xs = [x.to(device, non_blocking=True) for _, x in levels]
+    # any callable nn.Module is accepted, like the reference's get_detections (evaluation.py:56-60): only DetectionModel has lanes (ADVICE r3)
+    fl = getattr(model, "forward_levels", None)
+    outs = fl(xs) if fl is not None else [model(x) for x in xs]
     for (scale, x), out in zip(levels, outs):                         # (1, 5nt, H', W')
         _, _, H, W = out.shape
         vx, vt = ops.template_masks(templates, scale, W, mask_axis)

@@ -1,6 +1,8 @@
-"""Call surface of the reference's tinyfaces/models/utils.py (get_bboxes, regression_refinement,
-balance_sampling, shuffle_index).  get_bboxes is executed by the HIP decode kernel
-(csrc/decode.hip); balance sampling lives inside the criterion kernel (csrc/criterion.hip)."""
+"""Call surface of the reference's tinyfaces/models/utils.py: get_bboxes (:4-76), regression_refinement (:79-100), balance_sampling
+(:103-139), shuffle_index (:142-163).  get_bboxes is executed by the HIP decode kernel (csrc/decode.hip) and the training path samples
+inside the criterion kernel (csrc/criterion.hip); the three helpers below are the reference's HOST bookkeeping under their own names, for
+callers that import them (r4: rounds 1-3 only exported get_bboxes).  They consume np.random exactly like the reference, so a seeded
+script draws the same samples; `balance_sampling_keep` turns those draws into the keep flags DetectionCriterion.inject_sampling takes."""
 import numpy as np
 import torch
 
@@ -35,3 +37,52 @@ def get_bboxes(score_cls, score_reg, prob_cls, templates, prob_thresh, rf, scale
     n = int(count.item())
     out = dets[:n].cpu().numpy()
     return out[:, :4].copy(), out[:, 4:5].astype(np.float32)
+
+
+
+def regression_refinement(tx, ty, tw, th, cx, cy, cw, ch, indices):
+    """utils.py:79-100: centre / size refinement of the selected anchors.  tx..th: regression maps (any shape indexable by `indices`, the
+    tuple np.where returned), cx..ch: (N,) anchor centres and sizes.  Returns the reference's (1, N, 4) array of (x1, y1, x2, y2)."""
+    pick = [np.asarray(t)[indices] for t in (tx, ty, tw, th)]
+    rcx, rcy = cx + cw * pick[0], cy + ch * pick[1]
+    rcw, rch = cw * np.exp(pick[2]), ch * np.exp(pick[3])
+    return np.stack([rcx - rcw / 2, rcy - rch / 2, rcx + rcw / 2, rcy + rch / 2], axis=-1)[None]
+
+
+def shuffle_index(n, n_out):
+    """utils.py:142-163: `n_out` of the indices 0..n-1 in random order (one np.random.permutation(n) draw; nothing drawn when either is 0)."""
+    n, n_out = int(n), int(n_out)
+    if n == 0 or n_out == 0:
+        return np.empty(0)
+    if n_out > n:
+        raise AssertionError("shuffle_index: n_out <= n")          # the reference asserts
+    return np.random.permutation(n)[:n_out]
+
+
+def balance_sampling_keep(label_cls, pos_fraction, sample_size=256):
+    """The draws of balance_sampling as keep flags over the C-order RANK of the positive / negative labels (uint8, 1 = the label survives):
+    what DetectionCriterion.inject_sampling / tf_criterion_fwd_bwd(pos_keep, neg_keep) take.  Positives are drawn first, like the reference."""
+    lab = np.asarray(label_cls)
+    n_pos, n_neg = int((lab == 1).sum()), int((lab == -1).sum())
+    pos_max = sample_size * pos_fraction
+    pos_keep, neg_keep = np.ones(n_pos, np.uint8), np.ones(n_neg, np.uint8)
+    if n_pos > pos_max:
+        pos_keep[shuffle_index(n_pos, n_pos - pos_max).astype(np.int64)] = 0       # the reference draws the positives to DROP ...
+    neg_max = pos_max * (1 - pos_fraction) / pos_fraction
+    if n_neg > neg_max:
+        neg_keep[:] = 0
+        neg_keep[shuffle_index(n_neg, neg_max).astype(np.int64)] = 1               # ... and the negatives to KEEP
+    return pos_keep, neg_keep
+
+
+def balance_sampling(label_cls, pos_fraction, sample_size=256):
+    """utils.py:103-139: at most sample_size * pos_fraction positive and the matching number of negative labels survive, the rest become 0
+    ("ignore").  Mutates and returns `label_cls` (numpy array of {-1, 0, 1}, any shape)."""
+    pos_keep, neg_keep = balance_sampling_keep(label_cls, pos_fraction, sample_size)
+    flat = label_cls.reshape(-1)
+    if flat.base is None and flat is not label_cls:
+        raise ValueError("balance_sampling: label_cls must be C-contiguous (it is edited in place)")
+    pos_at, neg_at = np.flatnonzero(flat == 1), np.flatnonzero(flat == -1)
+    flat[pos_at[pos_keep == 0]] = 0
+    flat[neg_at[neg_keep == 0]] = 0
+    return label_cls
