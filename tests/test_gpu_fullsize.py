@@ -125,11 +125,17 @@ def test_train_step_bs12_500x500_vs_oracle(train_case, dtype):
         # maps 1.5e-2 of a 1.19 range; gradient cosine 0.967 median, 0.888-0.923 minimum depending on the summation order of the fp32
         # atomics (the worst tensor is ALWAYS a layer-1 BN bias: a sum of 187 500 bf16-noisy terms that cancel); every other tensor
         # >= 0.90.  torch's own bf16 autocast on the small fixture: 0.933 / 0.968 (scripts/debug_gpu.py amp).
+        # r4: the bars are the measured values with a margin, the one exception stays explicit.  Measured with the grouped
+        # full-K weight gradients of round 4: minimum 0.9206 (model.layer1.1.bn2.bias), 5th percentile 0.949, median 0.9678, none below 0.90.
         low = sorted((v, k) for k, v in cos.items() if v < 0.90)
-        report(f"fullsize_train_bf16_margin", below_090=len(low), lowest=str(low[:3]), cos_p05=float(np.quantile(cosv, .05)))
+        is_l1_bn = lambda k: ".bn" in k and "layer1" in k                 # noqa: E731
+        rest_min = min(v for k, v in cos.items() if not is_l1_bn(k))
+        report(f"fullsize_train_bf16_margin", below_090=len(low), lowest=str(low[:3]), cos_p05=float(np.quantile(cosv, .05)), cos_min_outside_layer1_bn=rest_min)
         assert dy[0] < 1.8e-2
-        assert cosv.min() > 0.85 and len(low) <= 2 and np.median(cosv) > 0.96, (worst, cos[worst], low)
-        assert all(".bn" in k and "layer1" in k for _, k in low), low      # only cancelling layer-1 BN sums may dip below 0.90
+        assert rest_min >= 0.90, rest_min                                    # EVERY tensor but the layer-1 BN sums: cosine >= 0.90
+        assert np.quantile(cosv, .05) > 0.93 and np.median(cosv) > 0.96, (float(np.quantile(cosv, .05)), float(np.median(cosv)))
+        assert cosv.min() > 0.85 and len(low) <= 2, (worst, cos[worst], low)  # the exception: at most two cancelling layer-1 BN sums in [0.85, 0.90)
+        assert all(is_l1_bn(k) for _, k in low), low
         assert drm < 2e-2 and drv < 2e-2
 
 
