@@ -26,7 +26,7 @@ void set_next_stop_event(hipEvent_t e) { g_next_stop_event = e; }
 hipEvent_t take_next_stop_event() { hipEvent_t e = g_next_stop_event; g_next_stop_event = nullptr; return e; }
 }  // namespace tf
 
-extern "C" int tf_version(void) { return 300; }
+extern "C" int tf_version(void) { return 400; }   // r4: context + hooks + communicator entry points; tile codes 1-3 and pro_scale refused
 static int g_stat_rows = 8;
 extern "C" int tf_set_stat_rows(int rows) { g_stat_rows = rows <= 0 ? (1 << 30) : (rows > TF_STAT_ROWS ? TF_STAT_ROWS : rows); return TF_OK; }
 extern "C" int tf_get_stat_rows(void) { return g_stat_rows; }

@@ -249,7 +249,11 @@ __global__ void __launch_bounds__(256, MMA == 32 ? 2 : (NS == 1 && BM == 128 ? (
   // paid the HBM latency of aux3 once per epilogue pass.
   constexpr bool PF_COLD3 = PREF && EPIC >= 0 && (EPIC & TF_EPI_STATS3) && (EPIC & TF_EPI_RES) && !(EPIC & (TF_EPI_MASK | TF_EPI_STATS2 | TF_EPI_JOIN));
   constexpr int P_CPR = BN / EPS, P_RPP = 256 / P_CPR, P_PASSES = BM / P_RPP;
-  uint4 pf1[P_PASSES], pf2[P_PASSES];      // (the third operand, STATS3's / JOIN's aux3, stays a late load: registers)
+  uint4 pf1[P_PASSES], pf2[P_PASSES];      // (the third operand, JOIN's aux3, stays a late load: registers)
+  // r4: the hand-over instantiation has the registers since its flag set is a compile-time constant (136 of the 168 a 3-wave bound allows):
+  // its third operand -- the residual gradient -- is requested up front too (TF_CONV_DBG=32: late, as before, for the A/B)
+  uint4 pf3[PF_COLD3 ? P_PASSES : 1];
+  const bool pf3_on = PF_COLD3 && !(a.dbg & 32);
   if constexpr (PREF) {
     const int pchunk = tid % P_CPR, prl = tid / P_CPR, pc0 = n0 + pchunk * EPS;
     const bool w1 = epi_flags & (TF_EPI_RES | TF_EPI_MASK | TF_EPI_STATS2), w2 = epi_flags & (TF_EPI_JOIN | TF_EPI_MASK2);
@@ -258,10 +262,14 @@ __global__ void __launch_bounds__(256, MMA == 32 ? 2 : (NS == 1 && BM == 128 ? (
       const int p = m0 + prl + ps * P_RPP;
       const bool ok = p < a.M && pc0 < a.ldy;
       const size_t o = (orow(ok ? p : 0) * a.ldy + (ok ? pc0 : 0)) * sizeof(T);
-      if constexpr (PF_COLD3) pf1[ps] = ok ? *reinterpret_cast<const uint4*>(a.aux3 + o) : make_uint4(0, 0, 0, 0);
-      else
+      if constexpr (PF_COLD3) {
+        pf1[ps] = ok ? *reinterpret_cast<const uint4*>(a.aux3 + o) : make_uint4(0, 0, 0, 0);
+        if (pf3_on) pf3[ps] = ok ? *reinterpret_cast<const uint4*>(a.aux + o) : make_uint4(0, 0, 0, 0);
+      } else
       pf1[ps] = (ok && w1) ? *reinterpret_cast<const uint4*>(a.aux + o) : make_uint4(0, 0, 0, 0);
-      pf2[ps] = (ok && w2) ? *reinterpret_cast<const uint4*>(a.aux2 + o) : make_uint4(0, 0, 0, 0);
+      // (TF_CONV_DBG=64, WRONG results, timing only: the mask operand collapses to one cached 4 KiB window -- what a bit mask instead of the
+      //  25 MB activation could save at most)
+      pf2[ps] = (ok && w2) ? *reinterpret_cast<const uint4*>(a.aux2 + ((a.dbg & 64) ? (size_t)tid * 16 : o)) : make_uint4(0, 0, 0, 0);
     }
   }
 
@@ -469,7 +477,9 @@ __global__ void __launch_bounds__(256, MMA == 32 ? 2 : (NS == 1 && BM == 128 ? (
       const size_t o = (orow(p) * a.ldy + c0) * sizeof(T);
       float ax[EPS];
       if (epi_flags & (TF_EPI_RES | TF_EPI_MASK | TF_EPI_STATS2)) {
-        if constexpr (PREF && !PF_COLD3) tf::unpack16<T>(pf1[ps], ax); else tf::unpack16<T>(*reinterpret_cast<const uint4*>(a.aux + o), ax);
+        if constexpr (PREF && !PF_COLD3) tf::unpack16<T>(pf1[ps], ax);
+        else if (PF_COLD3 && pf3_on) tf::unpack16<T>(pf3[PF_COLD3 ? ps : 0], ax);
+        else tf::unpack16<T>(*reinterpret_cast<const uint4*>(a.aux + o), ax);
       }
       if (epi_flags & TF_EPI_AFFINE) {
 #pragma unroll

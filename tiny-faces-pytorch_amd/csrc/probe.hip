@@ -11,6 +11,10 @@
 //   4 ldsdma  : global_load_lds_dwordx4 from an L2-resident window           -> the LDS-DMA path (TA -> LDS write port)
 //   5 atomic  : fp32 atomicAdd to an L2-resident window                      -> the L2 atomic units
 //   6 ldsread : ds_read_b128 loops                                           -> the LDS read port
+//   7 / 8 gridbar : `iters` device-wide barriers inside ONE launch (7: one atomic arrival counter, 8: per-group counters + a global one;
+//               agent-scope release / acquire fences); with a
+//               window > 4 KiB every thread also writes 16 bytes before and reads another block's 16 bytes after each barrier
+//               -> what a persistent ("cooperative") conv -> BN -> conv kernel would pay INSTEAD of a kernel boundary (r4)
 // Not part of the product path (debug symbol of the C ABI, like tf_debug_conv3x3h_trace).
 #include "common.h"
 #include "debug_api.h"
@@ -87,6 +91,46 @@ __global__ void __launch_bounds__(256) probe_kernel(char* buf, size_t window, in
       for (int u = 0; u < 8; ++u) { const float4 v = p[o]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; o = (o + 256) & 1023; }
     }
     if (acc.x + acc.y + acc.z + acc.w == 123.456f) sink[0] = 1.f;
+  } else if constexpr (KIND == 7 || KIND == 8) {
+    // buf[0..3]: arrival counter (zeroed by the launcher), buf[4..7]: error flag (a barrier that did not complete), data from byte 4096 on.
+    // All blocks must be co-resident (the launcher refuses more than 4 per CU); a spin that runs too long gives up instead of hanging.
+    unsigned* ctr = reinterpret_cast<unsigned*>(buf);
+    const unsigned nb = gridDim.x;
+    const bool data = window > 4096 + (size_t)nb * 256 * 16;
+    uint4* slots = reinterpret_cast<uint4*>(buf + 4096);
+    unsigned chk = 0;
+    volatile int& dead = *reinterpret_cast<volatile int*>(smem);      // (dynamic LDS: a static __shared__ would push the 160 KiB attribute over the limit)
+    if (tid == 0) dead = 0;
+    for (int i = 0; i < iters; ++i) {
+      if (data) slots[(size_t)blockIdx.x * 256 + tid] = make_uint4(i, blockIdx.x, tid, 7);
+      __syncthreads();
+      if (dead) break;
+      if (tid == 0) {
+        __threadfence();                                   // release: this block's stores visible device-wide (L2 write-back across XCDs)
+        unsigned want;
+        if constexpr (KIND == 7) {                         // one arrival counter: nb same-address device-scope atomics per barrier
+          atomicAdd(ctr, 1u);
+          want = (unsigned)(i + 1) * nb;
+        } else {                                           // two levels: 8 group counters 128 B apart (block % 8 ~ the XCD a block lands on), the
+          const unsigned G = 8, gs = nb / G;               // last arrival of a group bumps the global one: nb/8 + 8 serialised atomics per barrier
+          if (atomicAdd(ctr + 32 * (1 + blockIdx.x % G), 1u) == (unsigned)(i + 1) * gs - 1) atomicAdd(ctr, 1u);
+          want = (unsigned)(i + 1) * G;
+        }
+        int spins = 0;
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > (1 << 22)) { ctr[1] = 1u; dead = 1; break; }
+        }
+        __threadfence();                                   // acquire
+      }
+      __syncthreads();
+      if (dead) break;
+      if (data) {
+        const uint4 v = slots[(size_t)((blockIdx.x + nb / 2 + 1) % nb) * 256 + tid];
+        chk += (v.x < (unsigned)i);                        // stale = older than this round (a faster block may already have written round i + 1)
+      }
+    }
+    if (chk) ctr[2] = chk;                                 // a stale read after the barrier (must stay 0)
   }
 }
 
@@ -116,6 +160,10 @@ extern "C" int tf_debug_probe(int kind, int blocks, int lds_bytes, void* buf, si
     case 4: return launch<4>(blocks, lds_bytes, b, window_bytes, iters, s);
     case 5: return launch<5>(blocks, lds_bytes, b, window_bytes, iters, s);
     case 6: return launch<6>(blocks, lds_bytes, b, 4096, iters, s);
+    case 7: case 8:
+      if (blocks > 1024 || blocks % 8) return TF_ERR_ARG;   // every block must be resident at once (256 CUs x 4)
+      if (hipMemsetAsync(b, 0, 4096, s) != hipSuccess) return TF_ERR_LAUNCH;
+      return kind == 7 ? launch<7>(blocks, 64, b, window_bytes, iters, s) : launch<8>(blocks, 64, b, window_bytes, iters, s);
   }
   return TF_ERR_ARG;
 }

@@ -31,6 +31,9 @@ class TrainEngine:
         if parallel.is_distributed():
             parallel.broadcast_module(self.model)
         self.flat_p = self.model.flatten_parameters()
+        # the engine owns the flat storages from here on: the per-step identity walk over the 571 tensors is skipped (model._sync_tables;
+        # anything that moves the module -- .to(), flatten_parameters -- unfreezes it).  TINYFACES_SYNC_TABLES_ALWAYS=1: the walk of rounds 1-3
+        self.model._tables_frozen = os.environ.get("TINYFACES_SYNC_TABLES_ALWAYS") is None
         self.flat_m = torch.zeros_like(self.flat_p)
         self.groups = self.model.group_ranges()
         self.lr, self.momentum, self.weight_decay = lr, momentum, weight_decay
@@ -45,7 +48,6 @@ class TrainEngine:
         # final (after its all-reduce when data-parallel), beside the rest of the backward pass, instead of over all 42.5 M parameters
         # at the end of the step.  Same numbers bit for bit; 1113-1117 img/s against 1118-1123 at the end (A/B on one box): the update
         # is HBM-bound (850 MB) and takes from the backward pass what it saves at the tail.
-        import os
         self.sgd_per_bucket = bool(os.environ.get("TINYFACES_SGD_PER_BUCKET"))
         if parallel.is_distributed() or self.sgd_per_bucket:
             self._setup_overlap()

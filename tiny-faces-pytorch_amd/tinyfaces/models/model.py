@@ -253,11 +253,21 @@ class DetectionModel(nn.Module):
         d.update(dict(self.named_buffers()))
         return d
 
+    def _apply(self, fn, *a, **kw):
+        # .to() / .cuda() / .float(): every storage may move -> the pointer tables are rebuilt on the next call even when frozen
+        self._table_key = None
+        self._tables_frozen = False
+        return super()._apply(fn, *a, **kw)
+
     def _sync_tables(self, device):
-        """(Re)build the device-pointer tables the executor reads; cheap, keyed on storage identity."""
+        """(Re)build the device-pointer tables the executor reads, keyed on storage identity.  The check itself walks 571 tensors
+        (~0.4 ms of Python): an owner that pins the storages (TrainEngine after flatten_parameters) sets `_tables_frozen` and the walk is
+        skipped until something moves the module (`_apply`, flatten_parameters)."""
+        if getattr(self, "_tables_frozen", False) and self._table_key is not None:
+            return
         named = self._named_tensors()
         n = lib().tf_detnet_num_params()
-        names = [lib().tf_detnet_param_name(i).decode() for i in range(n)]
+        names = self._names if getattr(self, "_names", None) and len(self._names) == n else [lib().tf_detnet_param_name(i).decode() for i in range(n)]
         key = tuple(named[k].data_ptr() for k in names)
         if key == self._table_key:
             return
