@@ -170,7 +170,7 @@ __device__ __forceinline__ void dma16(const void* gsrc, void* lds_wave_base) {
 // residual / mask operands (32) and the accumulators; a training step uses three flag sets on 90 % of its launches (STATS;
 // MASK | STATS2; RES | MASK2 | STATS3), which get an instantiation each for the hot pointwise tiles: dead modes fold away.
 template <typename T, int BM, int BN, int NS, int KIND, int MMA = 16, int EPIC = -1>
-__global__ void __launch_bounds__(256, MMA == 32 ? 2 : (NS == 1 && BM == 128 ? (EPIC == (TF_EPI_RES | TF_EPI_MASK2 | TF_EPI_STATS3) ? 3 : 4) : 5)) conv_dma_kernel(const DmaK a) {
+__global__ void __launch_bounds__(256, MMA == 32 ? 2 : (NS <= 2 && BM == 128 && EPIC == (TF_EPI_RES | TF_EPI_MASK2 | TF_EPI_STATS3) ? 3 : (NS == 1 && BM == 128 ? 4 : 5))) conv_dma_kernel(const DmaK a) {
   // (the hand-over instantiation of the ring-less 128 x 64 tile keeps three operand tiles in registers: 3 blocks per CU without spills --
   //  768 resident blocks, exactly two rounds of the 1536 tiles of a layer-3 launch -- instead of 4 with 8 spilled registers)
   const int epi_flags = EPIC >= 0 ? EPIC : a.epi;
@@ -242,19 +242,21 @@ __global__ void __launch_bounds__(256, MMA == 32 ? 2 : (NS == 1 && BM == 128 ? (
   // mask / statistic operands (up to three tensors as large as the output) used to be requested only after the K loop, with the
   // whole HBM latency exposed once per block.  Request them NOW: they travel while the K stages are DMA-ed and multiplied.
   // (Older loads retire first, so the counted vmcnt waits of the K loop are unaffected.)
-  constexpr bool PREF = (NS == 1 && KIND == 1);      // the pointwise ring-less variants: every hot instance (the gather variants would spill)
+  // (r4: also the 2-deep form of the 128 x 64 tile for the hand-over class: TINYFACES_HANDOVER_TILE=42)
+  constexpr bool PREF = (NS == 1 && KIND == 1) || (NS == 2 && KIND == 1 && BM == 128 && BN == 64 && MMA == 16 && EPIC == (TF_EPI_RES | TF_EPI_MASK2 | TF_EPI_STATS3));
   // r4, hand-over instantiation (RES | MASK2 | STATS3 known at compile time): two of its three epilogue operands are COLD -- aux2 (the
   // previous block's output y) and aux3 (its conv3 output) were written in the forward pass -- and the third, the residual gradient, was
-  // written a few launches ago and is cache-resident.  The early requests go to the cold pair; rounds 1-3 prefetched aux + aux2 and
-  // paid the HBM latency of aux3 once per epilogue pass.
+  // written a few launches ago.  It has the registers to request all three up front since its flag set is a compile-time constant (152 of
+  // the 168 a 3-wave bound allows; +0.5 % on the step against a late residual).  The requests are issued BEHIND the DMAs of the first K
+  // stage and that stage is waited for with vmcnt(NPF): the K loop starts after an L2 latency, not after the HBM latency of the cold
+  // operands (loads retire in order, so every later wait covers them).  For the count to be exact the requests are unconditional
+  // (clamped addresses, the zero is selected afterwards).
   constexpr bool PF_COLD3 = PREF && EPIC >= 0 && (EPIC & TF_EPI_STATS3) && (EPIC & TF_EPI_RES) && !(EPIC & (TF_EPI_MASK | TF_EPI_STATS2 | TF_EPI_JOIN));
   constexpr int P_CPR = BN / EPS, P_RPP = 256 / P_CPR, P_PASSES = BM / P_RPP;
+  constexpr int NPF = PF_COLD3 ? 3 * P_PASSES : 0;
   uint4 pf1[P_PASSES], pf2[P_PASSES];      // (the third operand, JOIN's aux3, stays a late load: registers)
-  // r4: the hand-over instantiation has the registers since its flag set is a compile-time constant (136 of the 168 a 3-wave bound allows):
-  // its third operand -- the residual gradient -- is requested up front too (TF_CONV_DBG=32: late, as before, for the A/B)
   uint4 pf3[PF_COLD3 ? P_PASSES : 1];
-  const bool pf3_on = PF_COLD3 && !(a.dbg & 32);
-  if constexpr (PREF) {
+  auto prefetch = [&]() {
     const int pchunk = tid % P_CPR, prl = tid / P_CPR, pc0 = n0 + pchunk * EPS;
     const bool w1 = epi_flags & (TF_EPI_RES | TF_EPI_MASK | TF_EPI_STATS2), w2 = epi_flags & (TF_EPI_JOIN | TF_EPI_MASK2);
 #pragma unroll
@@ -263,15 +265,18 @@ __global__ void __launch_bounds__(256, MMA == 32 ? 2 : (NS == 1 && BM == 128 ? (
       const bool ok = p < a.M && pc0 < a.ldy;
       const size_t o = (orow(ok ? p : 0) * a.ldy + (ok ? pc0 : 0)) * sizeof(T);
       if constexpr (PF_COLD3) {
-        pf1[ps] = ok ? *reinterpret_cast<const uint4*>(a.aux3 + o) : make_uint4(0, 0, 0, 0);
-        if (pf3_on) pf3[ps] = ok ? *reinterpret_cast<const uint4*>(a.aux + o) : make_uint4(0, 0, 0, 0);
-      } else
-      pf1[ps] = (ok && w1) ? *reinterpret_cast<const uint4*>(a.aux + o) : make_uint4(0, 0, 0, 0);
-      // (TF_CONV_DBG=64, WRONG results, timing only: the mask operand collapses to one cached 4 KiB window -- what a bit mask instead of the
-      //  25 MB activation could save at most)
-      pf2[ps] = (ok && w2) ? *reinterpret_cast<const uint4*>(a.aux2 + ((a.dbg & 64) ? (size_t)tid * 16 : o)) : make_uint4(0, 0, 0, 0);
+        const uint4 t1 = *reinterpret_cast<const uint4*>(a.aux3 + o), t2 = *reinterpret_cast<const uint4*>(a.aux2 + o), t3 = *reinterpret_cast<const uint4*>(a.aux + o);
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        pf1[ps] = ok ? t1 : z; pf2[ps] = ok ? t2 : z; pf3[ps] = ok ? t3 : z;
+      } else {
+        pf1[ps] = (ok && w1) ? *reinterpret_cast<const uint4*>(a.aux + o) : make_uint4(0, 0, 0, 0);
+        pf2[ps] = (ok && w2) ? *reinterpret_cast<const uint4*>(a.aux2 + o) : make_uint4(0, 0, 0, 0);
+      }
     }
-  }
+  };
+  const bool pf_early = PF_COLD3 && (a.dbg & 32);    // TF_CONV_DBG=32 (A/B): requests in front of the first DMAs, first stage waited with vmcnt(0)
+  if constexpr (PREF && !PF_COLD3) prefetch();
+  if constexpr (PF_COLD3) { if (pf_early) prefetch(); }
 
   // stage iterator (scalar): stages are issued in order, so (slot, chunk, kw, kh) advance incrementally
   const bool par = KIND == 2 && a.scat == 2;       // parity class: only the taps kh0 + 2i, kw0 + 2j exist for these output pixels
@@ -334,7 +339,7 @@ __global__ void __launch_bounds__(256, MMA == 32 ? 2 : (NS == 1 && BM == 128 ? (
     // (ring-less, 1-4 stages, latency-bound with 4 blocks per CU), so the fix-up rides in time other blocks spend waiting, and the
     // separate bn_relu launch (one per bottleneck on the forward chain) disappears.  Coefficients: bn_fused.hip fwd_table, all Cin <= 256
     // channels per block, in a 2 KiB table behind the staging tile; block 0 publishes scale / shift / mean / invstd + running statistics.
-    constexpr bool FIX = KIND == 1 && sizeof(T) == 2;
+    constexpr bool FIX = KIND == 1 && sizeof(T) == 2 && EPIC < 0;      // (the specialised instantiations are never launched with a prologue)
     constexpr int TAB_AT = (BUF > BM * (BN + 4) * 4 ? BUF : BM * (BN + 4) * 4);
     float* ctab = reinterpret_cast<float*>(smem + TAB_AT);
     if constexpr (FIX) {
@@ -364,8 +369,12 @@ __global__ void __launch_bounds__(256, MMA == 32 ? 2 : (NS == 1 && BM == 128 ? (
     for (int st = 0; st < nst; ++st) {
       if (st) __builtin_amdgcn_s_barrier();         // everyone finished reading the previous stage
       issue();
-      wait_vmcnt<0>();
-      __syncthreads();                              // (r3: also publishes the coefficient table written above)
+      if constexpr (PF_COLD3) {
+        if (st == 0 && !pf_early) { prefetch(); wait_vmcnt<NPF>(); } else wait_vmcnt<0>();
+      } else wait_vmcnt<0>();
+      // (r3: __syncthreads also publishes the coefficient table written above; it implies vmcnt(0), which the specialised instantiations
+      //  -- never launched with a prologue -- must not pay: the raw barrier behind the counted wait is the ring variants' protocol)
+      if constexpr (EPIC >= 0) __builtin_amdgcn_s_barrier(); else __syncthreads();
       if constexpr (FIX) {
         if (a.pro) {
 #pragma unroll
@@ -396,11 +405,13 @@ __global__ void __launch_bounds__(256, MMA == 32 ? 2 : (NS == 1 && BM == 128 ? (
 #pragma unroll
   for (int j = 0; j < NS - 1; ++j)
     if (j < nst && !(a.dbg & 8)) issue();
+  if constexpr (PF_COLD3) { if (!pf_early) prefetch(); }      // (NS == 2: behind the DMAs of stage 0)
   int cs = 0;                                        // ring slot being computed
   for (int st = 0; st < nst; ++st) {
     // stage st has landed once at most min(NS-2, nst-1-st) younger stages are still in flight
     const int younger = nst - 1 - st;
-    if (younger >= NS - 2) wait_vmcnt<L*(NS - 2)>();
+    if (PF_COLD3 && st == 0 && !pf_early) wait_vmcnt<NPF>();
+    else if (younger >= NS - 2) wait_vmcnt<L*(NS - 2)>();
     else if (NS > 3 && younger == 1) wait_vmcnt<L>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();                   // everyone's pieces of stage st landed; ring slot (st-1)%NS is free
@@ -477,8 +488,8 @@ __global__ void __launch_bounds__(256, MMA == 32 ? 2 : (NS == 1 && BM == 128 ? (
       const size_t o = (orow(p) * a.ldy + c0) * sizeof(T);
       float ax[EPS];
       if (epi_flags & (TF_EPI_RES | TF_EPI_MASK | TF_EPI_STATS2)) {
-        if constexpr (PREF && !PF_COLD3) tf::unpack16<T>(pf1[ps], ax);
-        else if (PF_COLD3 && pf3_on) tf::unpack16<T>(pf3[PF_COLD3 ? ps : 0], ax);
+        if constexpr (PF_COLD3) tf::unpack16<T>(pf3[PF_COLD3 ? ps : 0], ax);
+        else if constexpr (PREF) tf::unpack16<T>(pf1[ps], ax);
         else tf::unpack16<T>(*reinterpret_cast<const uint4*>(a.aux + o), ax);
       }
       if (epi_flags & TF_EPI_AFFINE) {
@@ -650,7 +661,7 @@ int launch_kind(const tf_conv_args* A, hipStream_t stream, int pcls = -1) {
     // r4: the three flag sets of a training step get instantiations of their own for the hot pointwise bf16 tiles (EPIC, see the kernel)
     // which (tile, ring, fragment) combinations the executor dispatches (pick_tile, csrc/conv.hip): 64 x 128 / 2-deep / 32x32x16 fragments,
     // the ring-less 128 x 64 tile, 64 x 64 with 1-3 slots -- the other instantiations exist for explicit tile requests only
-    constexpr bool SPEC = sizeof(T) == 2 && ((MMA == 32 && BM == 64 && BN == 128 && NS == 2) || (MMA == 16 && BM == 128 && BN == 64 && NS == 1 && KIND != 2) ||
+    constexpr bool SPEC = sizeof(T) == 2 && ((MMA == 32 && BM == 64 && BN == 128 && NS == 2) || (MMA == 16 && BM == 128 && BN == 64 && NS == 1 && KIND != 2) || (MMA == 16 && BM == 128 && BN == 64 && NS == 2 && KIND == 1) ||
                                              (MMA == 16 && BM == 64 && BN == 64 && NS <= 3));
     constexpr bool TRAIN = std::is_same<T, tf::bf16_t>::value;          // the training flag sets: bf16 only (fp16 is inference only)
     static const bool spec_off = getenv("TINYFACES_EPI_SPEC_OFF") != nullptr;       // A/B knob
@@ -720,6 +731,7 @@ int launch_half(const tf_conv_args* a, int tile, int depth, hipStream_t stream) 
   if (tile == 1) return launch<T, 128, 128, 3>(a, stream);
   if (tile == 2) {
     if (depth == 1) return launch<T, 128, 64, 1>(a, stream);       // tile code 32: ring-less, short K (see pick_tile)
+    if (depth == 2) return launch<T, 128, 64, 2>(a, stream);       // tile code 42 (r4: A/B form of the hand-over data gradient)
     return depth == 4 ? launch<T, 128, 64, 4>(a, stream) : launch<T, 128, 64, 3>(a, stream);
   }
   if (depth == 3) {
