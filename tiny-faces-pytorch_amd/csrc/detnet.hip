@@ -490,7 +490,7 @@ extern "C" size_t tf_detnet_param_region_bytes(int dtype, int nout, int training
 struct tf_detnet_ctx {
   int device = -1;
   hipStream_t side = nullptr, gside = nullptr;
-  hipEvent_t pack_fork = nullptr, pack_join = nullptr;
+  hipEvent_t pack_fork = nullptr, pack_join = nullptr, pack_join0 = nullptr;
   std::vector<hipEvent_t> events;
 };
 namespace {
@@ -531,6 +531,7 @@ extern "C" int tf_detnet_ctx_destroy(tf_detnet_ctx* x) {
   for (hipEvent_t e : x->events) (void)hipEventDestroy(e);
   if (x->pack_fork) (void)hipEventDestroy(x->pack_fork);
   if (x->pack_join) (void)hipEventDestroy(x->pack_join);
+  if (x->pack_join0) (void)hipEventDestroy(x->pack_join0);
   if (x->side) (void)hipStreamDestroy(x->side);
   if (x->gside) (void)hipStreamDestroy(x->gside);
   delete x;
@@ -581,7 +582,8 @@ extern "C" int tf_detnet_forward_ctx(tf_detnet_ctx* xctx, int single_stream, int
   if (pack_side) {
     g_pack_stream = ctx_side(xctx);
     if (g_pack_stream && !xctx->pack_fork && (hipEventCreateWithFlags(&xctx->pack_fork, hipEventDisableTiming) != hipSuccess ||
-                                              hipEventCreateWithFlags(&xctx->pack_join, hipEventDisableTiming) != hipSuccess)) g_pack_stream = nullptr;
+                                              hipEventCreateWithFlags(&xctx->pack_join, hipEventDisableTiming) != hipSuccess ||
+                                              hipEventCreateWithFlags(&xctx->pack_join0, hipEventDisableTiming) != hipSuccess)) g_pack_stream = nullptr;
   }
   if (!g_pack_stream) pack_side = false;
   if (pack_side) {           // everything enqueued so far (the previous step's SGD: the masters) precedes the packing
@@ -595,7 +597,17 @@ extern "C" int tf_detnet_forward_ctx(tf_detnet_ctx* xctx, int single_stream, int
   for (size_t i = 0; i < A.blocks.size(); ++i) {
     const Block& B = A.blocks[i];
     Plan::Blk& b = P.blk[i];
-    if (pack_side && pack_split && (int)i == A.layer_end[1] + 1) c.flush_packs();      // stem + layers 1-2: inline, needed first
+    // stem + layers 1-2 are needed first: inline, behind the im2col.  r4 experiment, NEUTRAL (1277 / 1281 against 1279 / 1275 img/s), opt-in
+    // (TINYFACES_PACK_FIRST_SIDE=1): packed on the second stream as well, first in its order, beside the stem's im2col, the caller's
+    // stream waiting for them in front of the stem conv
+    if (pack_side && pack_split && (int)i == A.layer_end[1] + 1) {
+      static const bool first_inline = getenv("TINYFACES_PACK_FIRST_SIDE") == nullptr;
+      if (first_inline) c.flush_packs();
+      else {
+        c.flush_packs(g_pack_stream);
+        if (hipEventRecord(xctx->pack_join0, g_pack_stream) != hipSuccess || hipStreamWaitEvent(c.stream, xctx->pack_join0, 0) != hipSuccess) c.chk(TF_ERR_LAUNCH);
+      }
+    }
     pack2(c, B.c1, B.planes, b.w1, b.w1t); pack2(c, B.c2, B.planes, b.w2, b.w2t); pack2(c, B.c3, B.planes * 4, b.w3, b.w3t);
     if (B.has_ds) pack2(c, B.ds, B.planes * 4, b.wd, b.wdt);
   }
