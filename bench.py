@@ -182,6 +182,20 @@ def pmc_traffic(kind, path=None):
     return round(sum(r["hbm_bytes"] * r["launches"] for r in rows) / n)
 
 
+def pmc_step_traffic(path=None):
+    """HBM bytes of ONE whole training step: every kernel of the committed PMC passes (bytes per launch x launches), divided by the steps of
+    that run (the fused SGD launches three times per step: the groups with a non-zero learning rate).  None without the file."""
+    path = path or PMC_TRAFFIC_FILE
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        k = json.load(f)["kernels"]
+    sgd = sum(v["launches"] for n, v in k.items() if "sgd_kernel" in n)
+    if not sgd:
+        return None
+    return sum(v["hbm_bytes"] * v["launches"] for v in k.values()) / (sgd / 3.0)
+
+
 ROCPROF_STATS_FILE = os.path.join(ROOT, "profiles", "r04_train_bs12_bf16_kernel_stats.csv")
 
 
@@ -764,6 +778,14 @@ def main():
                                          "(SURVEY.md 8d); executed = the 2*M*N*K of the GEMM the kernel ran (stride-2 data gradients at 4x, padded stem / head channels)",
                            "algorithmic_gb_s": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9, 1),
                            "share_of_timed_region": round(dom["ms"] * PROFILE_EVERY / (dt * 1e3), 3)}
+        stb = pmc_step_traffic() if args.dtype == "bf16" and world == 1 else None
+        if stb:       # the step as a whole against the OTHER roof: a training-mode-BN step at bs = 12 moves every activation several times
+            out["roofline_step"] = {"bound": "hbm", "traffic_gb_per_step": round(stb / 1e9, 2), "achieved": round(stb / (ms_per_step * 1e-3) / 1e9, 1),
+                                    "peak": 8000.0, "unit": "GB/s", "frac": round(stb / (ms_per_step * 1e-3) / 8e12, 4),
+                                    "ms_per_step_at_6300_gb_s": round(stb / 6.3e12 * 1e3, 2),
+                                    "mfma_frac_of_step": round(3 * FWD_GFLOP_PER_IMG * args.batch / ms_per_step / PEAK_TFLOPS["bf16"], 4),
+                                    "note": "all kernels of a step, HBM bytes from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, "
+                                            "profiles/r04_pmc_traffic.json) over this run's step time; the step is nearer to the HBM roof than to the MFMA roof"}
         out["kernels"] = [{"kernel": KIND_NAMES.get(r["kind"], str(r["kind"])), "launches_per_step": round(r["launches"] * PROFILE_EVERY / args.steps, 1),
                            "ms_per_step": round(r["ms"] * PROFILE_EVERY / args.steps, 3),
                            "tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 1), "gb_s": round(r["bytes"] / (r["ms"] * 1e-3) / 1e9, 1)} for r in prof]

@@ -303,6 +303,9 @@ def test_bench_reads_committed_pmc_traffic():
     assert t is not None and 2e7 < t < 3e8
     assert bench.pmc_traffic(14) is not None                     # weight-gradient rows exist too
     assert bench.pmc_traffic(5) is None                          # a kernel kind with no pattern: None, not an exception
+    # the whole step (roofline_step): tens of GB, i.e. several milliseconds of HBM time at bs = 12 -- the step is nearer to that roof
+    step = bench.pmc_step_traffic()
+    assert step is not None and 1.5e10 < step < 6e10
     # a file whose kernel names no longer match the binary must fail loudly, not report a stale number
     import json
     import pytest
