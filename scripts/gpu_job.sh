@@ -86,8 +86,15 @@ print(d['value'], d['ms_per_step'], 'frac', r.get('frac'), 'fwd', r.get('forward
   nms) bash scripts/gpu_nms.sh ;;
   dist-smoke) bash scripts/gpu_dist_smoke.sh ;;
   final)
+    # the profile passes FIRST: bench.py quotes the committed kernel-stats / PMC files, so they are refreshed in the box's copy of profiles/
+    # (and come home through gpurun_out/) before the bench line is taken with the same binary
+    rp=${ROUND:-r04}
+    bash "$0" prof train; cp "$R/gpurun_out/prof/train_kernel_stats.csv" "$R/profiles/${rp}_train_bs12_bf16_kernel_stats.csv"
+    bash "$0" pmc-traffic; cp "$R/gpurun_out/pmc_bench/traffic.json" "$R/profiles/${rp}_pmc_traffic.json"; cp "$R/gpurun_out/pmc_bench/traffic_fp32.json" "$R/profiles/${rp}_pmc_traffic_fp32.json"
+    bash "$0" bench
     bash "$0" tests; cp "$R/gpurun_out/parity_report.txt" "$R/gpurun_out/parity_report_full.txt" 2>/dev/null
-    bash "$0" bench; bash "$0" prof train; bash "$0" pmc-traffic; bash "$0" layer-table; bash "$0" timeline; bash "$0" prof eval; bash "$0" eval-table
+    bash "$0" layer-table; bash "$0" timeline; bash "$0" prof eval; bash "$0" eval-table
+    python scripts/gridbar.py 2>&1 | grep -v amdgpu.ids > "$R/gpurun_out/gridbar.txt"; tail -5 "$R/gpurun_out/gridbar.txt"
     timeout 200 python __graft_entry__.py smoke 2>&1 | tail -2 ;;
   *) sed -n 2,22p "$0" ;;
 esac
