@@ -41,6 +41,23 @@ def test_probe_tr16(hip):
     assert ok, got[:20]
 
 
+@pytest.mark.parametrize("kind", [7, 8])
+def test_grid_barrier_probe_is_coherent(hip, kind):
+    """csrc/probe.hip kinds 7 / 8 (scripts/gridbar.py): 40 device-wide barriers inside one launch of 256 co-resident blocks, every
+    thread writing 16 bytes before and reading another block's 16 bytes after each barrier.  The measurement is only worth quoting if the
+    barrier IS one: no spin gave up, no read saw a value older than the current round, every block arrived at every barrier."""
+    blocks, iters = 256, 40
+    buf = torch.zeros(4096 + blocks * 256 * 16 + 4096, dtype=torch.uint8, device="cuda")
+    rc = hip.lib().tf_debug_probe(kind, blocks, 0, buf.data_ptr(), buf.numel(), iters, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    flags = buf[:16].view(torch.int32).tolist()
+    report(f"grid_barrier_probe[{kind}]", arrivals=flags[0], gave_up=flags[1], stale_reads=flags[2])
+    assert flags[1] == 0 and flags[2] == 0
+    assert flags[0] == (blocks * iters if kind == 7 else 8 * iters)
+    assert hip.lib().tf_debug_probe(kind, 2048, 0, buf.data_ptr(), buf.numel(), 1, torch.cuda.current_stream().cuda_stream) != 0   # more blocks than can be resident: refused
+
+
 @pytest.mark.parametrize("ci", range(5))
 def test_targets_vs_reference_golden(golden, ci):
     from tinyfaces import ops
