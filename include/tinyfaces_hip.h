@@ -260,6 +260,11 @@ int tf_maxpool_fwd(int dtype, const void* x, int N, int H, int W, int C, const f
                    void* y, uint8_t* argmax, void* stream);
 int tf_maxpool_bwd(int dtype, const void* g, const uint8_t* argmax, const void* x, const float* scale, const float* shift,
                    int N, int H, int W, int C, void* gz, void* stream);
+/* r4: tf_maxpool_bwd that also takes the column sums of the stem's BatchNorm backward (autograd of model.py:91-93) in the same pass:
+ * stat_out[rows][2][C] += (sum gz, sum gz * x), rows = *host_rows_out <= tf_get_stat_rows(), zero on entry -- what
+ * tf_colstats(gz, NULL, x) would compute from a second read of both tensors.  TF_ERR_UNSUPPORTED with unfolded rows (tf_set_stat_rows(0)). */
+int tf_maxpool_bwd_stats(int dtype, const void* g, const uint8_t* argmax, const void* x, const float* scale, const float* shift,
+                         int N, int H, int W, int C, void* gz, float* stat_out, int* host_rows_out, void* stream);
 /* per-channel sums over the rows of an [M][ld] matrix, block partials [nblk][nk][C]:
  * k0 = sum g', k1 = sum g'*a, k2 = sum g'*b, g' = g*(y>0) when y != NULL.  nblk = tf_colstats_blocks(). */
 int tf_colstats_blocks(int M, int C, int dtype);

@@ -363,6 +363,19 @@ def test_stem_im2col_and_maxpool(dtype, hip):
     d2 = err(from_nhwc(gz), gref)
     report(f"im2col_maxpool[{dtype}]", pool_maxabs=d[0], pool_bwd_rel=d2[2])
     assert d[0] < (1e-6 if dtype == torch.float32 else 1e-2) and d2[2] < (1e-6 if dtype == torch.float32 else 8e-3)
+    # r4: the same backward with the column sums of the stem's BN backward taken in the same pass: gz bit-equal, sums = those of the stored gz
+    import ctypes as C_
+    gz2 = torch.empty_like(xin)
+    rows = C_.c_int(0)
+    st = torch.zeros(hip.lib().tf_get_stat_rows(), 2, C, device="cuda")
+    assert lib().tf_maxpool_bwd_stats(tf_dtype(dtype), ptr(gpd), ptr(idx), ptr(xin), ptr(scd), ptr(shd), N, OH, OW, C, ptr(gz2), ptr(st), C_.byref(rows), stream()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(gz2, gz) and 1 <= rows.value <= st.shape[0]
+    s = st[:rows.value].sum(0).cpu().double()
+    gzf, xf = gz.double().cpu().reshape(-1, C), xin.double().cpu().reshape(-1, C)
+    e1, e2 = err(s[0], gzf.sum(0)), err(s[1], (gzf * xf).sum(0))
+    report(f"maxpool_bwd_stats[{dtype}]", rows=rows.value, sum_rel=e1[2], sumx_rel=e2[2])
+    assert e1[2] < 1e-5 and e2[2] < 1e-5
 
 
 @pytest.mark.parametrize("dtype", DT)

@@ -36,6 +36,7 @@ extern "C" {
 int tf_stem_im2col(const float*, int, int, int, int, void*, int, void*);
 int tf_maxpool_fwd(int, const void*, int, int, int, int, const float*, const float*, void*, uint8_t*, void*);
 int tf_maxpool_bwd(int, const void*, const uint8_t*, const void*, const float*, const float*, int, int, int, int, void*, void*);
+int tf_maxpool_bwd_stats(int, const void*, const uint8_t*, const void*, const float*, const float*, int, int, int, int, void*, float*, int*, void*);
 int tf_colstats_blocks(int, int, int);
 int tf_colstats(int, const void*, const void*, const void*, const void*, int, int, int, float*, void*);
 int tf_bn_finalize(const float*, int, int, int, float, const float*, const float*, float, float, float*, float*, float*, float*, float*,
@@ -1110,9 +1111,17 @@ extern "C" int tf_detnet_backward_ctx(tf_detnet_ctx* xctx, const tf_detnet_hooks
   // ---- stem
   const int M1 = N * P.H1 * P.W1;
   void* gz = P.T4;                          // main-stream scratch (its last reader, block 0's conv1 dgrad, is ahead on this stream)
-  c.chk(tf_maxpool_bwd(dtype, Gcur, P.pool_idx, P.cstem, P.bn_stem.scale, P.bn_stem.shift, N, P.H1, P.W1, 64, gz, c.stream));
-  const int nb = tf_colstats_blocks(M1, 64, dtype);
-  c.chk(tf_colstats(dtype, gz, nullptr, P.cstem, nullptr, M1, 64, 64, P.partial_b, c.stream));
+  // r4: the statistic sums of the stem's BN backward ride in the max-pool backward (gz and x are in its registers): one pass over two 96 MB
+  // tensors and one launch fewer at the very end of the chain (TINYFACES_POOL_STATS_OFF=1: the two-pass form)
+  static const bool pool_stats_off = getenv("TINYFACES_POOL_STATS_OFF") != nullptr;
+  int nb = 0;
+  if (fused && !pool_stats_off) {
+    c.chk(tf_maxpool_bwd_stats(dtype, Gcur, P.pool_idx, P.cstem, P.bn_stem.scale, P.bn_stem.shift, N, P.H1, P.W1, 64, gz, P.partial_b, &nb, c.stream));
+  } else {
+    c.chk(tf_maxpool_bwd(dtype, Gcur, P.pool_idx, P.cstem, P.bn_stem.scale, P.bn_stem.shift, N, P.H1, P.W1, 64, gz, c.stream));
+    nb = tf_colstats_blocks(M1, 64, dtype);
+    c.chk(tf_colstats(dtype, gz, nullptr, P.cstem, nullptr, M1, 64, 64, P.partial_b, c.stream));
+  }
   bn_backward_coefs(c, A.stem, 64, P.bn_stem, P.partial_b, nb, 2, 1, 64, (float)M1);
   c.chk(tf_bn_bwd_apply(dtype, gz, nullptr, P.cstem, P.bn_stem.cA, P.bn_stem.cB, P.bn_stem.cD, M1, 64, gz, c.stream));
   // P.col still holds the im2col matrix of this forward (nothing else is carved from that range)

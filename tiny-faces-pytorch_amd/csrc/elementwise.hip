@@ -209,12 +209,19 @@ __global__ void __launch_bounds__(256) maxpool_fwd_kernel(const T* __restrict__ 
 }
 
 // gz[n,ih,iw,c] = (relu mask of BN(x)) * sum over windows whose arg-max is this position of g[window]
-template <typename T>
+template <typename T, bool STATS>
 __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const T* __restrict__ g, const uint8_t* __restrict__ idx, const T* __restrict__ x,
                                                           const float* __restrict__ sc, const float* __restrict__ sh, int N, int H, int W,
-                                                          int C, int OH, int OW, T* __restrict__ gz) {
+                                                          int C, int OH, int OW, T* __restrict__ gz, float* __restrict__ stat_out, int srows) {
   constexpr int EPS = tf::Elem<T>::kPer16B;
   const int spr = C / EPS;
+  // STATS (r4): the column sums  sum gz, sum gz * x  of the stem's BatchNorm backward (what tf_colstats(gz, NULL, x) computes in a second
+  // pass over both tensors) are taken here, where both values are in registers: a thread keeps its channel chunk over the grid stride
+  // (gridDim.x * 256 is a multiple of C / EPS), lanes of a wave with the same chunk are summed by shuffles, the four waves through LDS,
+  // and the block folds its row into stat_out[blockIdx % srows][2][C] like the colstats kernel does
+  float s1[EPS], s2[EPS];
+#pragma unroll
+  for (int j = 0; j < EPS; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
   const size_t total = (size_t)N * H * W * spr;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int s = (int)(i % spr);
@@ -253,7 +260,33 @@ __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const T* __restrict__ 
     tf::unpack16<T>(xv, xf);
 #pragma unroll
     for (int j = 0; j < EPS; ++j) if (!(xf[j] * sc[s * EPS + j] + sh[s * EPS + j] > 0.f)) acc[j] = 0.f;
-    *reinterpret_cast<uint4*>(reinterpret_cast<char*>(gz) + i * 16) = tf::pack16<T>(acc);
+    const uint4 outv = tf::pack16<T>(acc);
+    *reinterpret_cast<uint4*>(reinterpret_cast<char*>(gz) + i * 16) = outv;
+    if constexpr (STATS) {
+      float r[EPS];
+      tf::unpack16<T>(outv, r);               // the ROUNDED gradient: what the separate pass would read back
+#pragma unroll
+      for (int j = 0; j < EPS; ++j) { s1[j] += r[j]; s2[j] += r[j] * xf[j]; }
+    }
+  }
+  if constexpr (STATS) {
+    __shared__ float red[4][2][256];           // C <= 256
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, s = threadIdx.x % spr;
+#pragma unroll
+    for (int j = 0; j < EPS; ++j) {
+      for (int o = spr; o < 64; o <<= 1) { s1[j] += __shfl_xor(s1[j], o, 64); s2[j] += __shfl_xor(s2[j], o, 64); }
+    }
+    if (lane < spr) {
+#pragma unroll
+      for (int j = 0; j < EPS; ++j) { red[wave][0][s * EPS + j] = s1[j]; red[wave][1][s * EPS + j] = s2[j]; }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * C; e += 256) {
+      const int k = e / C, c = e - k * C;
+      const float t = red[0][k][c] + red[1][k][c] + red[2][k][c] + red[3][k][c];
+      if ((int)gridDim.x <= srows) stat_out[(size_t)blockIdx.x * 2 * C + e] = t;
+      else atomicAdd(&stat_out[(size_t)(blockIdx.x % srows) * 2 * C + e], t);          // rows are zero on entry (the finalize clears them)
+    }
   }
 }
 
@@ -709,8 +742,26 @@ extern "C" int tf_maxpool_bwd(int dtype, const void* g, const uint8_t* argmax, c
   if (!g || !argmax || !x || !scale || !shift || !gz || C % 8) return TF_ERR_ARG;
   const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
   const size_t total = (size_t)N * H * W * (C / (dtype == TF_F32 ? 4 : 8));
-  DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const T*)g, argmax,
-                                       (const T*)x, scale, shift, N, H, W, C, OH, OW, (T*)gz));
+  DISPATCH_T(dtype, hipLaunchKernelGGL((maxpool_bwd_kernel<T, false>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const T*)g, argmax,
+                                       (const T*)x, scale, shift, N, H, W, C, OH, OW, (T*)gz, (float*)nullptr, 0));
+  TF_CHECK_LAUNCH();
+  return TF_OK;
+}
+
+// tf_maxpool_bwd + tf_colstats(gz, NULL, x) in one pass (r4): also folds  sum gz, sum gz * x  per channel into stat_out[rows][2][C]
+// (rows = *rows_out <= tf_get_stat_rows(), zero on entry like every folded statistic region); C <= 256 and 256 % (C / elements per 16 bytes) == 0
+extern "C" int tf_maxpool_bwd_stats(int dtype, const void* g, const uint8_t* argmax, const void* x, const float* scale, const float* shift, int N,
+                                    int H, int W, int C, void* gz, float* stat_out, int* rows_out, void* stream) {
+  const int eps = dtype == TF_F32 ? 4 : 8;
+  if (!g || !argmax || !x || !scale || !shift || !gz || !stat_out || !rows_out || C % 8 || C > 256 || 256 % (C / eps)) return TF_ERR_ARG;
+  const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+  const size_t total = (size_t)N * H * W * (C / eps);
+  const unsigned grid = grid_for(total);
+  const int srows = tf_get_stat_rows();
+  if ((int)grid > srows && srows > TF_STAT_ROWS) return TF_ERR_UNSUPPORTED;       // unfolded (bit-reproducible) rows: the two-pass form
+  *rows_out = (int)grid <= srows ? (int)grid : srows;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((maxpool_bwd_kernel<T, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)g, argmax,
+                                       (const T*)x, scale, shift, N, H, W, C, OH, OW, (T*)gz, stat_out, srows));
   TF_CHECK_LAUNCH();
   return TF_OK;
 }

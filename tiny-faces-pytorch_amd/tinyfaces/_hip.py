@@ -110,6 +110,7 @@ _SIGNATURES = {
     "tf_stem_im2col": (i32, [vp, i32, i32, i32, i32, vp, i32, vp]),
     "tf_maxpool_fwd": (i32, [i32, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
     "tf_maxpool_bwd": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
+    "tf_maxpool_bwd_stats": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, C.POINTER(i32), vp]),
     "tf_colstats_blocks": (i32, [i32, i32, i32]),
     "tf_colstats": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, vp, vp]),
     "tf_bn_finalize": (i32, [vp, i32, i32, i32, f32, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, i32, vp]),
