@@ -254,6 +254,13 @@ int tf_unpack_dw(const float* packed, int Cout, int Cin, int taps, float* dw_oih
 /* conv1 (7x7 s2 p3, 3->64; model.py:90): x NCHW fp32 -> im2col [N*OH*OW][ldc], k = c*49+kh*7+kw
  * (the OIHW order of conv1.weight), zero padded to ldc (>= 147, multiple of 8). */
 int tf_stem_im2col(const float* x_nchw, int N, int H, int W, int dtype, void* col, int ldc, void* stream);
+/* r4: conv1 straight from the NCHW fp32 image, no im2col matrix (dtype TF_BF16 | TF_F16; TF_F32 keeps tf_stem_im2col + tf_conv2d):
+ * y [N*OH*OW][64] = conv(x, W) with w_packed = conv1.weight as tf_pack_weight* writes it for the im2col GEMM ([>= 64 rows][ldw],
+ * k = c*49 + kh*7 + kw, ldw >= 160 and a multiple of 8).  epi: 0 | TF_EPI_STATS (stat_out[rows][2][64] += per-channel sum and sum of
+ * squares of the fp32 results, rows = *host_rows_out <= tf_get_stat_rows(), zero on entry; TF_ERR_UNSUPPORTED with unfolded rows) |
+ * TF_EPI_AFFINE|TF_EPI_RELU (y = relu(conv * scale + shift): the folded BatchNorm of the evaluation graph). */
+int tf_stem_conv(int dtype, const float* x_nchw, int N, int H, int W, const void* w_packed, int ldw, void* y, int epi,
+                 const float* scale, const float* shift, float* stat_out, int* host_rows_out, void* stream);
 /* nn.MaxPool2d(3,2,1) (model.py:93) with the stem's BN+ReLU fused in front when scale/shift are
  * given (training: the un-normalised conv output is read once).  argmax (u8, optional) feeds _bwd. */
 int tf_maxpool_fwd(int dtype, const void* x, int N, int H, int W, int C, const float* scale, const float* shift,

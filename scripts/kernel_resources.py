@@ -3,7 +3,7 @@ needed): file | kernel | VGPRs | AGPRs | scratch B/lane | VGPR spills | occupanc
 import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "tiny-faces-pytorch_amd", "csrc")
-FILES = sys.argv[1:] or ["conv_dma_bf16.hip", "conv_dma_f16.hip", "conv_dma.hip", "conv3x3h.hip", "wgrad_group.hip", "wgrad_dma.hip", "wgrad3x3.hip", "wgrad.hip", "conv.hip", "nms.hip"]
+FILES = sys.argv[1:] or ["conv_dma_bf16.hip", "conv_dma_f16.hip", "conv_dma.hip", "conv3x3h.hip", "wgrad_group.hip", "wgrad_dma.hip", "wgrad3x3.hip", "wgrad.hip", "conv.hip", "stem_conv.hip", "nms.hip"]
 print("# compiler resource report (hipcc -Rpass-analysis=kernel-resource-usage, gfx950) of the MFMA kernels and the NMS kernels")
 print("# file | kernel | VGPRs | AGPRs | scratch B/lane | VGPR spills | occupancy waves/SIMD")
 for f in FILES:

@@ -378,6 +378,42 @@ def test_stem_im2col_and_maxpool(dtype, hip):
     assert e1[2] < 1e-5 and e2[2] < 1e-5
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(2, 37, 45), (1, 130, 71), (3, 64, 64)])
+def test_stem_conv_direct_equals_im2col_gemm_and_torch(dtype, shape):
+    """tf_stem_conv (r4, csrc/stem_conv.hip): conv1 straight from the NCHW fp32 image -- against torch's conv on the rounded operands, against
+    the im2col + GEMM path it replaces (same products, another summation order), its batch statistics against the sums of the fp32 result,
+    and the folded-BN + ReLU epilogue of the evaluation graph; image sizes with partial tiles on every border, several tiles per block."""
+    from tinyfaces import _hip, ops
+    from tinyfaces._hip import lib, ptr, stream, tf_dtype
+    g = _g(31)
+    N, H, W = shape
+    x = torch.randn(N, 3, H, W, generator=g)
+    w = torch.randn(64, 3, 7, 7, generator=g) / 147 ** 0.5
+    ref = F.conv2d(q(x, dtype), q(w, dtype), stride=2, padding=3)                      # fp32 accumulation of the rounded operands
+    y, st = ops.stem_conv(x.cuda(), w.cuda(), dtype, epi=_hip.EPI_STATS)
+    d = err(from_nhwc(y), q(ref, dtype))
+    s = st.sum(0).cpu().double()
+    d1, d2 = err(s[0], ref.double().sum(dim=(0, 2, 3))), err(s[1], (ref.double() ** 2).sum(dim=(0, 2, 3)))
+    # the path of rounds 1-3
+    OH, OW = ref.shape[2:]
+    col = torch.empty(N * OH * OW, 192, dtype=dtype, device="cuda")
+    xd = x.cuda()
+    assert lib().tf_stem_im2col(ptr(xd), N, H, W, tf_dtype(dtype), ptr(col), 192, stream()) == 0
+    wp = ops.pack_weight(w.cuda().reshape(64, 147, 1, 1), dtype, cols_pad=192)
+    y_old = ops.conv2d_nhwc(col.view(1, 1, N * OH * OW, 192), wp, 64, 1, 1, 1, 0)
+    d_old = err(y.float().cpu().reshape(-1, 64), y_old.float().cpu().reshape(-1, 64))
+    # evaluation epilogue
+    sc, sh = (torch.rand(64, generator=g) + 0.5), torch.randn(64, generator=g) * 0.2
+    y2 = ops.stem_conv(x.cuda(), w.cuda(), dtype, epi=_hip.EPI_AFFINE | _hip.EPI_RELU, scale=sc.cuda(), shift=sh.cuda())
+    d3 = err(from_nhwc(y2), q(torch.relu(ref * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)), dtype))
+    y0 = ops.stem_conv(x.cuda(), w.cuda(), dtype)
+    report(f"stem_conv[{dtype},{shape}]", rel=d[2], vs_im2col=d_old[2], sum_rel=d1[2], sumsq_rel=d2[2], eval_rel=d3[2])
+    assert torch.equal(y0, y)
+    tol = {torch.bfloat16: 6e-3, torch.float16: 1e-3}[dtype]
+    assert d[2] < tol and d_old[2] < tol and d3[2] < tol and d1[2] < 1e-4 and d2[2] < 1e-4
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_bn_train_forward_backward_chain(dtype):
     """colstats -> bn_finalize -> bn_add_relu forward; colstats(masked) -> bn_bwd_finalize -> bn_bwd_apply backward,

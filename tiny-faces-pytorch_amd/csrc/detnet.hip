@@ -34,6 +34,7 @@
 
 extern "C" {
 int tf_stem_im2col(const float*, int, int, int, int, void*, int, void*);
+int tf_stem_conv(int, const float*, int, int, int, const void*, int, void*, int, const float*, const float*, float*, int*, void*);
 int tf_maxpool_fwd(int, const void*, int, int, int, int, const float*, const float*, void*, uint8_t*, void*);
 int tf_maxpool_bwd(int, const void*, const uint8_t*, const void*, const float*, const float*, int, int, int, int, void*, void*);
 int tf_maxpool_bwd_stats(int, const void*, const uint8_t*, const void*, const float*, const float*, int, int, int, int, void*, float*, int*, void*);
@@ -57,6 +58,13 @@ int tf_conv2d_wgrad_group(const tf_wgrad_args*, int, void*);
 namespace {
 
 constexpr int kStemK = 192;     // 147 taps*channels padded to 3 x 64
+// r4: conv1 straight from the image (csrc/stem_conv.hip) for the 2-byte operand types: no 288 MB im2col matrix on the forward chain.  The
+// weight gradient still reduces over that matrix: a training step builds it on the second stream at the top of the backward pass, where
+// that stream is idle.  fp32 and the unfolded-statistics mode keep im2col + GEMM.  TINYFACES_STEM_DIRECT_OFF=1: A/B knob.
+bool stem_direct_mode(int dtype, bool training, bool fused) {
+  static const bool off = getenv("TINYFACES_STEM_DIRECT_OFF") != nullptr;
+  return !off && dtype != TF_F32 && (!training || fused);
+}
 constexpr int kHeadLd = 128;    // 125 outputs padded
 
 struct ConvUnit {               // one conv + (optional) BN, with indices into the parameter table
@@ -587,10 +595,15 @@ extern "C" int tf_detnet_forward_ctx(tf_detnet_ctx* xctx, int single_stream, int
                                               hipEventCreateWithFlags(&xctx->pack_join0, hipEventDisableTiming) != hipSuccess)) g_pack_stream = nullptr;
   }
   if (!g_pack_stream) pack_side = false;
-  if (pack_side) {           // everything enqueued so far (the previous step's SGD: the masters) precedes the packing
+  const bool stem_direct = stem_direct_mode(dtype, tr, fused);
+  // r4 experiment, NEGATIVE, opt-in (TINYFACES_PACK_FORK_LATE=1): the layer-3 packing forked BEHIND the stem conv instead of at the top of the
+  // step (beside it the conv takes 99 instead of 56 us): 1273.0 / 1274.2 against 1276.1 / 1276.1 img/s -- the packing then overlaps layer 1
+  static const bool fork_late_env = getenv("TINYFACES_PACK_FORK_LATE") != nullptr;
+  const bool pack_late = pack_side && pack_split && stem_direct && fork_late_env;
+  if (pack_side && !pack_late) {           // everything enqueued so far (the previous step's SGD: the masters) precedes the packing
     if (hipEventRecord(xctx->pack_fork, c.stream) != hipSuccess || hipStreamWaitEvent(g_pack_stream, xctx->pack_fork, 0) != hipSuccess) c.chk(TF_ERR_LAUNCH);
   }
-  c.chk(tf_stem_im2col(x, N, H, W, dtype, P.col, kStemK, c.stream));
+  if (!stem_direct) c.chk(tf_stem_im2col(x, N, H, W, dtype, P.col, kStemK, c.stream));
   // ---- every weight of the pass re-packed from the fp32 master copy in two launches
   if (!ready) {
   // every operand of the pass (and, in training, of the backward pass) from ONE read of the fp32 masters
@@ -620,21 +633,41 @@ extern "C" int tf_detnet_forward_ctx(tf_detnet_ctx* xctx, int single_stream, int
     j.src = c.P(A.head4.w); j.dst = P.w_h4; j.dst_t = P.w_h4t; j.cin = 1024; j.cols_pad = 1024; j.rows_pad_t = 1024;
     c.jobs2.push_back(j);
   }
-  c.flush_packs(pack_side ? g_pack_stream : nullptr);
-  if (pack_side) {
+  if (!pack_late) {
+    c.flush_packs(pack_side ? g_pack_stream : nullptr);
+    if (pack_side) {
+      if (hipEventRecord(xctx->pack_join, g_pack_stream) != hipSuccess) c.chk(TF_ERR_LAUNCH);
+      if (!pack_split && hipStreamWaitEvent(c.stream, xctx->pack_join, 0) != hipSuccess) c.chk(TF_ERR_LAUNCH);
+    }
+  }
+  }
+  if (stem_direct) {
+    if (tr) {
+      int rows = 0;
+      c.chk(tf_stem_conv(dtype, x, N, H, W, P.wstem, kStemK, P.cstem, TF_EPI_STATS, nullptr, nullptr, P.partial, &rows, c.stream));
+      c.chk(tf_bn_finalize(P.partial, rows, 64, 64, (float)M1, c.P(A.stem.gamma), c.P(A.stem.beta), eps, mom, P.bn_stem.scale, P.bn_stem.shift,
+                           P.bn_stem.mean, P.bn_stem.invstd, (float*)c.params[A.stem.rmean], (float*)c.params[A.stem.rvar], 1, c.stream));
+    } else {
+      bn_forward(c, A.stem, 64, P.bn_stem, false, nullptr, nullptr, 0, eps, mom);
+      c.chk(tf_stem_conv(dtype, x, N, H, W, P.wstem, kStemK, P.cstem, TF_EPI_AFFINE | TF_EPI_RELU, P.bn_stem.scale, P.bn_stem.shift, nullptr, nullptr,
+                         c.stream));
+    }
+  } else {
+    conv_fill(a, dtype, 0, 1, 1, M1, kStemK, 1, M1, 64, 1, 1, 0, 64, P.col, P.wstem, P.cstem);
+    a.alg_k = 147;                                  // 7 x 7 x 3 taps*channels, zero-padded to kStemK for the 64-deep K stages
+    if (tr) { a.epi = TF_EPI_STATS; a.stat_out = P.partial; }
+    else {
+      bn_forward(c, A.stem, 64, P.bn_stem, false, nullptr, nullptr, 0, eps, mom);
+      a.epi = TF_EPI_AFFINE | TF_EPI_RELU; a.epi_scale = P.bn_stem.scale; a.epi_shift = P.bn_stem.shift;
+    }
+    c.chk(tf_conv2d(&a, c.stream));
+    if (tr) bn_forward(c, A.stem, 64, P.bn_stem, true, &a, P.partial, (float)M1, eps, mom);
+  }
+  if (pack_late && !ready) {               // the layer-3 + head packing: forked behind the stem conv, joined in front of layer 3
+    if (hipEventRecord(xctx->pack_fork, c.stream) != hipSuccess || hipStreamWaitEvent(g_pack_stream, xctx->pack_fork, 0) != hipSuccess) c.chk(TF_ERR_LAUNCH);
+    c.flush_packs(g_pack_stream);
     if (hipEventRecord(xctx->pack_join, g_pack_stream) != hipSuccess) c.chk(TF_ERR_LAUNCH);
-    if (!pack_split && hipStreamWaitEvent(c.stream, xctx->pack_join, 0) != hipSuccess) c.chk(TF_ERR_LAUNCH);
   }
-  }
-  conv_fill(a, dtype, 0, 1, 1, M1, kStemK, 1, M1, 64, 1, 1, 0, 64, P.col, P.wstem, P.cstem);
-  a.alg_k = 147;                                  // 7 x 7 x 3 taps*channels, zero-padded to kStemK for the 64-deep K stages
-  if (tr) { a.epi = TF_EPI_STATS; a.stat_out = P.partial; }
-  else {
-    bn_forward(c, A.stem, 64, P.bn_stem, false, nullptr, nullptr, 0, eps, mom);
-    a.epi = TF_EPI_AFFINE | TF_EPI_RELU; a.epi_scale = P.bn_stem.scale; a.epi_shift = P.bn_stem.shift;
-  }
-  c.chk(tf_conv2d(&a, c.stream));
-  if (tr) bn_forward(c, A.stem, 64, P.bn_stem, true, &a, P.partial, (float)M1, eps, mom);
   c.chk(tf_maxpool_fwd(dtype, P.cstem, N, P.H1, P.W1, 64, tr ? P.bn_stem.scale : nullptr, tr ? P.bn_stem.shift : nullptr, P.pool,
                        tr ? P.pool_idx : nullptr, c.stream));
 
@@ -850,6 +883,10 @@ extern "C" int tf_detnet_backward_ctx(tf_detnet_ctx* xctx, const tf_detnet_hooks
   const bool fused = srows <= TF_STAT_ROWS && !g_unfused_env;   // see tf_detnet_forward
   // statistic rows start at zero: the per-BN backward regions + the head of this pass's partial buffer right behind them, ONE memset
   if (hipMemsetAsync(P.stat_bwd, 0, (size_t)((char*)P.partial_b - (char*)P.stat_bwd) + (size_t)TF_STAT_ROWS * 3 * 1024 * 4, c.stream) != hipSuccess) c.chk(TF_ERR_LAUNCH);
+  if (stem_direct_mode(dtype, true, fused)) {            // the forward pass took conv1 straight from the image: the weight gradient's im2col
+    if (c.side) { c.fork(); c.chk(tf_stem_im2col(x, N, H, W, dtype, P.col, kStemK, c.side)); }     // matrix, beside the head's backward
+    else c.chk(tf_stem_im2col(x, N, H, W, dtype, P.col, kStemK, c.stream));
+  }
   const bool group_on = wgrad_group_mode(dtype, 1) && fused;
   const int first_id = A.layer_end[1] + 2, last_id = A.layer_end[2];           // the identity bottlenecks of layer 3: blocks 8 .. 29
   if (grad_flat && grad_flat_bytes) {                     // one memset for every weight gradient (atomics accumulate into them) ...

@@ -332,6 +332,23 @@ def pack_weight(w_oihw, dtype, transpose=False, cols_pad=None):
     return out
 
 
+def stem_conv(x_nchw, w_oihw, dtype, epi=0, scale=None, shift=None):
+    """conv1 of the trunk (7x7 / stride 2 / pad 3, 3 -> 64; model.py:90) straight from the NCHW fp32 image (tf_stem_conv, r4): returns
+    y (N, OH, OW, 64) of `dtype` (bf16 | fp16) [, statistic rows (rows, 2, 64) with epi = EPI_STATS].  `w_oihw` (64, 3, 7, 7) fp32."""
+    require_gpu(x_nchw, "stem_conv")
+    x = x_nchw.float().contiguous()
+    N, _, H, W = x.shape
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    wp = pack_weight(w_oihw.reshape(64, 147, 1, 1), dtype, cols_pad=192)
+    tfd = _hip.tf_dtype(dtype)
+    y = torch.empty(N, OH, OW, 64, dtype=dtype, device=x.device)
+    st = torch.zeros(lib().tf_get_stat_rows(), 2, 64, device=x.device) if epi == _hip.EPI_STATS else None
+    rows = C.c_int(0)
+    check(lib().tf_stem_conv(tfd, ptr(x), N, H, W, ptr(wp), 192, ptr(y), int(epi), ptr(scale) if scale is not None else None,
+                             ptr(shift) if shift is not None else None, ptr(st) if st is not None else None, C.byref(rows), stream()), "tf_stem_conv")
+    return (y, st[:rows.value]) if st is not None else y
+
+
 def conv2d_nhwc(x, w_packed, Cout, KH, KW, stride, pad, mode=0, out_hw=None, ldy=None, pro=None, epi=0, epi_scale=None,
                 epi_shift=None, aux=None, aux2=None, aux3=None, mask=None, want_stats=False, tile=0):
     """x (N,H,W,Cin) dtype bf16|f32 contiguous; returns y (N,OH,OW,ldy) [, stat partials (mtiles,2,ldy)]."""
