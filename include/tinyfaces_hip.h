@@ -261,6 +261,13 @@ int tf_stem_im2col(const float* x_nchw, int N, int H, int W, int dtype, void* co
  * TF_EPI_AFFINE|TF_EPI_RELU (y = relu(conv * scale + shift): the folded BatchNorm of the evaluation graph). */
 int tf_stem_conv(int dtype, const float* x_nchw, int N, int H, int W, const void* w_packed, int ldw, void* y, int epi,
                  const float* scale, const float* shift, float* stat_out, int* host_rows_out, void* stream);
+/* r4: weight gradient of conv1 straight from the image (autograd of model.py:90; dtype TF_BF16 | TF_F16): dw_oihw[64][147] (fp32, the OIHW
+ * order of conv1.weight) += sum over output pixels of g[px][co] * patch[px][k]; g [N*OH*OW][64] of `dtype`; dw holds zeros (or what is to be
+ * accumulated into) on entry.  Replaces tf_stem_im2col + tf_conv2d_wgrad over the 147-column matrix.  x_conv != NULL (with cA, cB, cD: 64
+ * floats each): the gradient operand is  cA * g + cB * x_conv + cD  per channel, rounded to `dtype` -- tf_bn_bwd_apply of the stem's BatchNorm
+ * (x_conv = the conv output the statistics were taken of) folded into the kernel, whose output has no other reader. */
+int tf_stem_wgrad(int dtype, const float* x_nchw, int N, int H, int W, const void* g, const void* x_conv, const float* cA, const float* cB,
+                  const float* cD, float* dw_oihw, void* stream);
 /* nn.MaxPool2d(3,2,1) (model.py:93) with the stem's BN+ReLU fused in front when scale/shift are
  * given (training: the un-normalised conv output is read once).  argmax (u8, optional) feeds _bwd. */
 int tf_maxpool_fwd(int dtype, const void* x, int N, int H, int W, int C, const float* scale, const float* shift,

@@ -18,5 +18,7 @@ for _ in range(10):
     y, st = ops.stem_conv(x, w, dtype, epi=_hip.EPI_STATS)
     assert lib().tf_stem_im2col(ptr(x), N, H, W, tf_dtype(dtype), ptr(col), 192, stream()) == 0
     y_old = ops.conv2d_nhwc(col.view(1, 1, N * OH * OW, 192), wp, 64, 1, 1, 1, 0, epi=_hip.EPI_STATS, want_stats=True)
+    dw = ops.stem_wgrad(x, y)                          # (the gradient operand: any [N*OH*OW][64] tensor of the operand type)
+    dw_old = ops.conv2d_wgrad(col.view(1, 1, N * OH * OW, 192), y.view(1, 1, N * OH * OW, 64), 192, 64, 1, 1, 1, 0) if hasattr(ops, "conv2d_wgrad") else None
 torch.cuda.synchronize()
 print("ok", float((y.float() - y_old[0].float().reshape(y.shape)).abs().max()))

@@ -414,6 +414,33 @@ def test_stem_conv_direct_equals_im2col_gemm_and_torch(dtype, shape):
     assert d[2] < tol and d_old[2] < tol and d3[2] < tol and d1[2] < 1e-4 and d2[2] < 1e-4
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(2, 37, 45), (1, 130, 71), (3, 64, 64), (2, 250, 250)])
+def test_stem_wgrad_direct_equals_autograd(dtype, shape):
+    """tf_stem_wgrad (r4): the weight gradient of conv1 straight from the image against torch's autograd on the rounded operands (fp32
+    accumulation), partial tiles on every border, blocks that walk several tiles, more tiles than blocks (250x250)."""
+    from tinyfaces import ops
+    g = _g(37)
+    N, H, W = shape
+    x = torch.randn(N, 3, H, W, generator=g)
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    gy = torch.randn(N, 64, OH, OW, generator=g)
+    w = torch.zeros(64, 3, 7, 7, requires_grad=True)
+    F.conv2d(q(x, dtype), w, stride=2, padding=3).backward(q(gy, dtype))
+    dw = ops.stem_wgrad(x.cuda(), to_nhwc(gy, dtype))
+    d = err(dw.cpu(), w.grad)
+    # ... and with the stem's BN-backward apply folded into the gradient operand: cA * g + cB * x_conv + cD, rounded to the operand type
+    xc = torch.randn(N, 64, OH, OW, generator=g)
+    cA, cB, cD = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1, torch.randn(64, generator=g) * 0.05
+    ga = q(cA.view(1, -1, 1, 1) * q(gy, dtype) + cB.view(1, -1, 1, 1) * q(xc, dtype) + cD.view(1, -1, 1, 1), dtype)
+    w2 = torch.zeros(64, 3, 7, 7, requires_grad=True)
+    F.conv2d(q(x, dtype), w2, stride=2, padding=3).backward(ga)
+    dw2 = ops.stem_wgrad(x.cuda(), to_nhwc(gy, dtype), to_nhwc(xc, dtype), cA.cuda(), cB.cuda(), cD.cuda())
+    d2 = err(dw2.cpu(), w2.grad)
+    report(f"stem_wgrad[{dtype},{shape}]", rel=d[2], max_ref=d[1], applied_rel=d2[2])
+    assert d[2] < 2e-4 and d2[2] < 2e-3          # (the applied operand is re-rounded: one ulp of the operand type where the fp32 orders differ)
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_bn_train_forward_backward_chain(dtype):
     """colstats -> bn_finalize -> bn_add_relu forward; colstats(masked) -> bn_bwd_finalize -> bn_bwd_apply backward,

@@ -10,7 +10,7 @@ static const char* const kSymbols[] = {
     "tf_criterion_workspace_bytes", "tf_criterion_fwd_bwd",
     "tf_sgd_step", "tf_image_prepare",
     "tf_conv_mtiles", "tf_conv2d", "tf_pack_weight", "tf_pack_weights_batched", "tf_pack_weights_tiled", "tf_conv2d_wgrad", "tf_conv2d_wgrad_group", "tf_wgrad_workspace_bytes", "tf_unpack_dw",
-    "tf_stem_im2col", "tf_stem_conv", "tf_maxpool_fwd", "tf_maxpool_bwd", "tf_maxpool_bwd_stats", "tf_colstats_blocks", "tf_colstats",
+    "tf_stem_im2col", "tf_stem_conv", "tf_stem_wgrad", "tf_maxpool_fwd", "tf_maxpool_bwd", "tf_maxpool_bwd_stats", "tf_colstats_blocks", "tf_colstats",
     "tf_bn_finalize", "tf_bn_fold", "tf_bn_bwd_finalize", "tf_bn_bwd_apply", "tf_bn_relu", "tf_bn_add_relu",
     "tf_bn_relu_fused", "tf_bn_add_relu_fused", "tf_bn_bwd_apply_fused", "tf_conv2d_bnbwd",
     "tf_upsample_add_crop", "tf_upsample_add_crop_bwd", "tf_reduce_partials",

@@ -35,6 +35,7 @@
 extern "C" {
 int tf_stem_im2col(const float*, int, int, int, int, void*, int, void*);
 int tf_stem_conv(int, const float*, int, int, int, const void*, int, void*, int, const float*, const float*, float*, int*, void*);
+int tf_stem_wgrad(int, const float*, int, int, int, const void*, const void*, const float*, const float*, const float*, float*, void*);
 int tf_maxpool_fwd(int, const void*, int, int, int, int, const float*, const float*, void*, uint8_t*, void*);
 int tf_maxpool_bwd(int, const void*, const uint8_t*, const void*, const float*, const float*, int, int, int, int, void*, void*);
 int tf_maxpool_bwd_stats(int, const void*, const uint8_t*, const void*, const float*, const float*, int, int, int, int, void*, float*, int*, void*);
@@ -883,8 +884,12 @@ extern "C" int tf_detnet_backward_ctx(tf_detnet_ctx* xctx, const tf_detnet_hooks
   const bool fused = srows <= TF_STAT_ROWS && !g_unfused_env;   // see tf_detnet_forward
   // statistic rows start at zero: the per-BN backward regions + the head of this pass's partial buffer right behind them, ONE memset
   if (hipMemsetAsync(P.stat_bwd, 0, (size_t)((char*)P.partial_b - (char*)P.stat_bwd) + (size_t)TF_STAT_ROWS * 3 * 1024 * 4, c.stream) != hipSuccess) c.chk(TF_ERR_LAUNCH);
-  if (stem_direct_mode(dtype, true, fused)) {            // the forward pass took conv1 straight from the image: the weight gradient's im2col
-    if (c.side) { c.fork(); c.chk(tf_stem_im2col(x, N, H, W, dtype, P.col, kStemK, c.side)); }     // matrix, beside the head's backward
+  // the forward pass took conv1 straight from the image.  Its weight gradient does too (tf_stem_wgrad); with TINYFACES_STEM_WGRAD_IM2COL=1 it
+  // reduces over the im2col matrix as in rounds 1-3, built here on the second stream (beside the head's backward)
+  static const bool stem_wgrad_im2col = getenv("TINYFACES_STEM_WGRAD_IM2COL") != nullptr;
+  const bool stem_direct = stem_direct_mode(dtype, true, fused);
+  if (stem_direct && stem_wgrad_im2col) {
+    if (c.side) { c.fork(); c.chk(tf_stem_im2col(x, N, H, W, dtype, P.col, kStemK, c.side)); }
     else c.chk(tf_stem_im2col(x, N, H, W, dtype, P.col, kStemK, c.stream));
   }
   const bool group_on = wgrad_group_mode(dtype, 1) && fused;
@@ -1160,12 +1165,19 @@ extern "C" int tf_detnet_backward_ctx(tf_detnet_ctx* xctx, const tf_detnet_hooks
     c.chk(tf_colstats(dtype, gz, nullptr, P.cstem, nullptr, M1, 64, 64, P.partial_b, c.stream));
   }
   bn_backward_coefs(c, A.stem, 64, P.bn_stem, P.partial_b, nb, 2, 1, 64, (float)M1);
-  c.chk(tf_bn_bwd_apply(dtype, gz, nullptr, P.cstem, P.bn_stem.cA, P.bn_stem.cB, P.bn_stem.cD, M1, 64, gz, c.stream));
+  // (r4: with the direct weight gradient the apply rides in that kernel's staging -- its output has no other reader)
+  const bool stem_wgrad_direct = stem_direct && !stem_wgrad_im2col;
+  static const bool stem_apply_off = getenv("TINYFACES_STEM_APPLY_SEPARATE") != nullptr;
+  const bool stem_apply_fused = stem_wgrad_direct && !stem_apply_off;
+  if (!stem_apply_fused) c.chk(tf_bn_bwd_apply(dtype, gz, nullptr, P.cstem, P.bn_stem.cA, P.bn_stem.cB, P.bn_stem.cD, M1, 64, gz, c.stream));
   // P.col still holds the im2col matrix of this forward (nothing else is carved from that range)
   {
     ConvUnit s = A.stem; s.stride = 1; s.pad = 0;
     c.fork();
-    wgrad(c, s, 64, 1, 1, M1, 1, M1, P.col, kStemK, gz, 64, nullptr, 147, 1, 147);
+    if (stem_wgrad_direct) {
+      if (!c.grads_zeroed && hipMemsetAsync(c.G(A.stem.w), 0, (size_t)64 * 147 * 4, c.wstream()) != hipSuccess) c.chk(TF_ERR_LAUNCH);
+      c.chk(tf_stem_wgrad(dtype, x, N, H, W, gz, stem_apply_fused ? P.cstem : nullptr, P.bn_stem.cA, P.bn_stem.cB, P.bn_stem.cD, c.G(A.stem.w), c.wstream()));
+    } else wgrad(c, s, 64, 1, 1, M1, 1, M1, P.col, kStemK, gz, 64, nullptr, 147, 1, 147);
   }
   c.wait_on_main(c.mark_side());           // join: the caller's stream sees every weight gradient
   if (c.gside) c.wait_on_main(c.mark(c.gside));

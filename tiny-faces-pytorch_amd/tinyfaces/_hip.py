@@ -108,6 +108,7 @@ _SIGNATURES = {
     "tf_wgrad_workspace_bytes": (sz, [C.POINTER(WgradArgs)]),
     "tf_unpack_dw": (i32, [vp, i32, i32, i32, vp, vp]),
     "tf_stem_im2col": (i32, [vp, i32, i32, i32, i32, vp, i32, vp]),
+    "tf_stem_wgrad": (i32, [i32, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
     "tf_stem_conv": (i32, [i32, vp, i32, i32, i32, vp, i32, vp, i32, vp, vp, vp, C.POINTER(i32), vp]),
     "tf_maxpool_fwd": (i32, [i32, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
     "tf_maxpool_bwd": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),

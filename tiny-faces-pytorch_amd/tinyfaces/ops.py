@@ -349,6 +349,19 @@ def stem_conv(x_nchw, w_oihw, dtype, epi=0, scale=None, shift=None):
     return (y, st[:rows.value]) if st is not None else y
 
 
+def stem_wgrad(x_nchw, g_nhwc, x_conv=None, cA=None, cB=None, cD=None):
+    """Weight gradient of conv1 straight from the image (tf_stem_wgrad, r4): x (N,3,H,W) fp32, g (N,OH,OW,64) bf16 | fp16 -> (64,3,7,7) fp32.
+    With x_conv (N,OH,OW,64) and cA / cB / cD (64,) fp32 the gradient operand is cA * g + cB * x_conv + cD (the stem's BN-backward apply)."""
+    require_gpu(x_nchw, "stem_wgrad")
+    x = x_nchw.float().contiguous()
+    N, _, H, W = x.shape
+    g = g_nhwc.contiguous()
+    dw = torch.zeros(64, 3, 7, 7, dtype=torch.float32, device=x.device)
+    opt = [ptr(t.contiguous()) if t is not None else None for t in (x_conv, cA, cB, cD)]
+    check(lib().tf_stem_wgrad(_hip.tf_dtype(g.dtype), ptr(x), N, H, W, ptr(g), *opt, ptr(dw), stream()), "tf_stem_wgrad")
+    return dw
+
+
 def conv2d_nhwc(x, w_packed, Cout, KH, KW, stride, pad, mode=0, out_hw=None, ldy=None, pro=None, epi=0, epi_scale=None,
                 epi_shift=None, aux=None, aux2=None, aux3=None, mask=None, want_stats=False, tile=0):
     """x (N,H,W,Cin) dtype bf16|f32 contiguous; returns y (N,OH,OW,ldy) [, stat partials (mtiles,2,ldy)]."""
