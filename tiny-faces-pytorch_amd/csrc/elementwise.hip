@@ -4,6 +4,7 @@
 // Each replaces the torch op cited in tinyfaces_hip.h (tinyfaces/models/model.py:90-126).
 #include <algorithm>
 
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -756,7 +757,11 @@ extern "C" int tf_maxpool_bwd_stats(int dtype, const void* g, const uint8_t* arg
   if (!g || !argmax || !x || !scale || !shift || !gz || !stat_out || !rows_out || C % 8 || C > 256 || 256 % (C / eps)) return TF_ERR_ARG;
   const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
   const size_t total = (size_t)N * H * W * (C / eps);
-  const unsigned grid = grid_for(total);
+  // (every block folds 2 * C sums into the rows with atomics: 1024 blocks, not the 8192 of the plain kernel -- 1 M same-address atomics
+  //  cost more than the longer grid-stride loops; TINYFACES_POOL_STATS_BLOCKS)
+  static const unsigned cap = [] { const char* e = getenv("TINYFACES_POOL_STATS_BLOCKS"); return e ? (unsigned)atoi(e) : 1024u; }();
+  unsigned grid = grid_for(total);
+  if (grid > cap && cap >= 1) grid = cap;
   const int srows = tf_get_stat_rows();
   if ((int)grid > srows && srows > TF_STAT_ROWS) return TF_ERR_UNSUPPORTED;       // unfolded (bit-reproducible) rows: the two-pass form
   *rows_out = (int)grid <= srows ? (int)grid : srows;
