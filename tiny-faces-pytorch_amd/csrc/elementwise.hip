@@ -162,54 +162,49 @@ __global__ void __launch_bounds__(256) stem_im2col_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------- max-pool 3x3 s2 p1 (+ fused BN/ReLU of the stem)
-// r4: a block walks output ROWS (n, oh) and its threads the (column, 16-byte channel chunk) pairs of a row -- the flat-index form of rounds 1-3
-// spent three 64-bit divisions per chunk on (n, oh, ow), more instructions than the nine window loads they addressed (52 us for 132 MB)
 template <typename T>
 __global__ void __launch_bounds__(256) maxpool_fwd_kernel(const T* __restrict__ x, int N, int H, int W, int C, const float* __restrict__ sc,
                                                           const float* __restrict__ sh, T* __restrict__ y, uint8_t* __restrict__ idx,
                                                           int OH, int OW) {
   constexpr int EPS = tf::Elem<T>::kPer16B;
   const int spr = C / EPS;
-  const bool reg = (256 % spr) == 0;               // a thread keeps its channel chunk over the row loop
-  const int per_row = OW * spr;
-  for (int row = blockIdx.x; row < N * OH; row += gridDim.x) {
-    const int n = row / OH, oh = row - n * OH;
-    for (int e = threadIdx.x; e < per_row; e += 256) {
-      const int ow = e / spr, s = reg ? (int)(threadIdx.x % spr) : e - ow * spr;
-      const size_t i = (size_t)row * per_row + e;
-      float best[EPS]; int bi[EPS];
+  const size_t total = (size_t)N * OH * OW * spr;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int s = (int)(i % spr);
+    const size_t p = i / spr;
+    const int ow = (int)(p % OW), oh = (int)((p / OW) % OH), n = (int)(p / ((size_t)OW * OH));
+    float best[EPS]; int bi[EPS];
 #pragma unroll
-      for (int j = 0; j < EPS; ++j) { best[j] = -INFINITY; bi[j] = 0; }
-      float fs[EPS], fh[EPS];
-      if (sc) {
+    for (int j = 0; j < EPS; ++j) { best[j] = -INFINITY; bi[j] = 0; }
+    float fs[EPS], fh[EPS];
+    if (sc) {
 #pragma unroll
-        for (int j = 0; j < EPS; ++j) { fs[j] = sc[s * EPS + j]; fh[j] = sh[s * EPS + j]; }
-      }
+      for (int j = 0; j < EPS; ++j) { fs[j] = sc[s * EPS + j]; fh[j] = sh[s * EPS + j]; }
+    }
 #pragma unroll
-      for (int kh = 0; kh < 3; ++kh)
+    for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-          const int ih = oh * 2 - 1 + kh, iw = ow * 2 - 1 + kw;
-          if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
-            const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(x) + ((((size_t)n * H + ih) * W + iw) * spr + s) * 16);
-            float f[EPS];
-            tf::unpack16<T>(v, f);
+      for (int kw = 0; kw < 3; ++kw) {
+        const int ih = oh * 2 - 1 + kh, iw = ow * 2 - 1 + kw;
+        if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
+          const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(x) + ((((size_t)n * H + ih) * W + iw) * spr + s) * 16);
+          float f[EPS];
+          tf::unpack16<T>(v, f);
 #pragma unroll
-            for (int j = 0; j < EPS; ++j) {
-              float t = f[j];
-              if (sc) t = fmaxf(t * fs[j] + fh[j], 0.f);
-              if (t > best[j]) { best[j] = t; bi[j] = kh * 3 + kw; }     // first max wins (torch CPU max_pool2d)
-            }
+          for (int j = 0; j < EPS; ++j) {
+            float t = f[j];
+            if (sc) t = fmaxf(t * fs[j] + fh[j], 0.f);
+            if (t > best[j]) { best[j] = t; bi[j] = kh * 3 + kw; }     // first max wins (torch CPU max_pool2d)
           }
         }
-      *reinterpret_cast<uint4*>(reinterpret_cast<char*>(y) + i * 16) = tf::pack16<T>(best);
-      if (idx) {                                     // one EPS-byte store per chunk
-        uint8_t ib[EPS];
-#pragma unroll
-        for (int j = 0; j < EPS; ++j) ib[j] = (uint8_t)bi[j];
-        if constexpr (EPS == 8) { uint2 q; __builtin_memcpy(&q, ib, 8); *reinterpret_cast<uint2*>(idx + i * EPS) = q; }
-        else { uint32_t q; __builtin_memcpy(&q, ib, 4); *reinterpret_cast<uint32_t*>(idx + i * EPS) = q; }
       }
+    *reinterpret_cast<uint4*>(reinterpret_cast<char*>(y) + i * 16) = tf::pack16<T>(best);
+    if (idx) {                                     // one EPS-byte store per chunk
+      uint8_t ib[EPS];
+#pragma unroll
+      for (int j = 0; j < EPS; ++j) ib[j] = (uint8_t)bi[j];
+      if constexpr (EPS == 8) { uint2 q; __builtin_memcpy(&q, ib, 8); *reinterpret_cast<uint2*>(idx + i * EPS) = q; }
+      else { uint32_t q; __builtin_memcpy(&q, ib, 4); *reinterpret_cast<uint32_t*>(idx + i * EPS) = q; }
     }
   }
 }
@@ -223,18 +218,16 @@ __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const T* __restrict__ 
   const int spr = C / EPS;
   // STATS (r4): the column sums  sum gz, sum gz * x  of the stem's BatchNorm backward (what tf_colstats(gz, NULL, x) computes in a second
   // pass over both tensors) are taken here, where both values are in registers: a thread keeps its channel chunk over the grid stride
-  // (256 is a multiple of C / EPS, so e % (C / EPS) is the same in every pass), lanes of a wave with the same chunk are summed by shuffles, the four waves through LDS,
+  // (gridDim.x * 256 is a multiple of C / EPS), lanes of a wave with the same chunk are summed by shuffles, the four waves through LDS,
   // and the block folds its row into stat_out[blockIdx % srows][2][C] like the colstats kernel does
   float s1[EPS], s2[EPS];
 #pragma unroll
   for (int j = 0; j < EPS; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
-  // (r4: rows (n, ih) per block, (column, chunk) pairs per thread: no 64-bit divisions per chunk -- see maxpool_fwd_kernel)
-  const int per_row = W * spr;
-  for (int row = blockIdx.x; row < N * H; row += gridDim.x) {
-   const int n = row / H, ih = row - n * H;
-   for (int e = threadIdx.x; e < per_row; e += 256) {
-    const int iw = e / spr, s = e - iw * spr;
-    const size_t i = (size_t)row * per_row + e;
+  const size_t total = (size_t)N * H * W * spr;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int s = (int)(i % spr);
+    const size_t p = i / spr;
+    const int iw = (int)(p % W), ih = (int)((p / W) % H), n = (int)(p / ((size_t)W * H));
     float acc[EPS];
 #pragma unroll
     for (int j = 0; j < EPS; ++j) acc[j] = 0.f;
@@ -276,7 +269,6 @@ __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const T* __restrict__ 
 #pragma unroll
       for (int j = 0; j < EPS; ++j) { s1[j] += r[j]; s2[j] += r[j] * xf[j]; }
     }
-   }
   }
   if constexpr (STATS) {
     __shared__ float red[4][2][256];           // C <= 256
@@ -656,7 +648,6 @@ __global__ void __launch_bounds__(kFinCh* kFinLanes) reduce_partials_kernel(floa
   if (threadIdx.x < kFinCh && c < C) out[c] = (float)sums[0][threadIdx.x];
 }
 
-inline unsigned rows_grid(size_t rows) { return (unsigned)(rows < 1 ? 1 : (rows > 8192 ? 8192 : rows)); }     // one block per raster row, capped
 inline unsigned grid_for(size_t total) {
   size_t b = (total + 255) / 256;
   if (b > 8192) b = 8192;
@@ -740,7 +731,8 @@ extern "C" int tf_maxpool_fwd(int dtype, const void* x, int N, int H, int W, int
                               uint8_t* argmax, void* stream) {
   if (!x || !y || C % 8) return TF_ERR_ARG;
   const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
-  DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3(rows_grid((size_t)N * OH)), dim3(256), 0, (hipStream_t)stream, (const T*)x, N, H, W, C,
+  const size_t total = (size_t)N * OH * OW * (C / (dtype == TF_F32 ? 4 : 8));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const T*)x, N, H, W, C,
                                        scale, shift, (T*)y, argmax, OH, OW));
   TF_CHECK_LAUNCH();
   return TF_OK;
@@ -750,7 +742,8 @@ extern "C" int tf_maxpool_bwd(int dtype, const void* g, const uint8_t* argmax, c
                               int H, int W, int C, void* gz, void* stream) {
   if (!g || !argmax || !x || !scale || !shift || !gz || C % 8) return TF_ERR_ARG;
   const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
-  DISPATCH_T(dtype, hipLaunchKernelGGL((maxpool_bwd_kernel<T, false>), dim3(rows_grid((size_t)N * H)), dim3(256), 0, (hipStream_t)stream, (const T*)g, argmax,
+  const size_t total = (size_t)N * H * W * (C / (dtype == TF_F32 ? 4 : 8));
+  DISPATCH_T(dtype, hipLaunchKernelGGL((maxpool_bwd_kernel<T, false>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const T*)g, argmax,
                                        (const T*)x, scale, shift, N, H, W, C, OH, OW, (T*)gz, (float*)nullptr, 0));
   TF_CHECK_LAUNCH();
   return TF_OK;
@@ -763,10 +756,11 @@ extern "C" int tf_maxpool_bwd_stats(int dtype, const void* g, const uint8_t* arg
   const int eps = dtype == TF_F32 ? 4 : 8;
   if (!g || !argmax || !x || !scale || !shift || !gz || !stat_out || !rows_out || C % 8 || C > 256 || 256 % (C / eps)) return TF_ERR_ARG;
   const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+  const size_t total = (size_t)N * H * W * (C / eps);
   // (every block folds 2 * C sums into the rows with atomics: 1024 blocks, not the 8192 of the plain kernel -- 1 M same-address atomics
   //  cost more than the longer grid-stride loops; TINYFACES_POOL_STATS_BLOCKS)
   static const unsigned cap = [] { const char* e = getenv("TINYFACES_POOL_STATS_BLOCKS"); return e ? (unsigned)atoi(e) : 1024u; }();
-  unsigned grid = rows_grid((size_t)N * H);
+  unsigned grid = grid_for(total);
   if (grid > cap && cap >= 1) grid = cap;
   const int srows = tf_get_stat_rows();
   if ((int)grid > srows && srows > TF_STAT_ROWS) return TF_ERR_UNSUPPORTED;       // unfolded (bit-reproducible) rows: the two-pass form
