@@ -541,6 +541,19 @@ __global__ void __launch_bounds__(256) bn_relu_kernel(const T* __restrict__ x, c
 }
 
 // ---------------------------------------------------------------- head: bilinear ConvTranspose2d(k4,s2,p1) + crop + add
+// four consecutive elements (ldc % 4 == 0, 4-element groups: 8- / 16-byte aligned) in one load
+template <typename T> __device__ __forceinline__ void load4(const T* p, float* f) {
+  if constexpr (sizeof(T) == 4) {
+    const float4 q = *reinterpret_cast<const float4*>(p);
+    f[0] = q.x; f[1] = q.y; f[2] = q.z; f[3] = q.w;
+  } else {
+    const uint2 q = *reinterpret_cast<const uint2*>(p);
+    float g[8];
+    tf::unpack16<T>(make_uint4(q.x, q.y, 0u, 0u), g);
+    f[0] = g[0]; f[1] = g[1]; f[2] = g[2]; f[3] = g[3];
+  }
+}
+
 // out NCHW fp32 [B][C][H3][W3] = s3[(b,y,x)][c] + sum_{ky,kx} s4[(b,i,j)][c] * wup[c][ky][kx],  y = 2i-1+ky, x = 2j-1+kx
 // (model.py:104-126; only the channel diagonal of score4_upsample.weight is non-zero, model.py:61-65)
 template <typename T>
@@ -558,11 +571,7 @@ __global__ void __launch_bounds__(256) upsample_add_kernel(const T* __restrict__
     if (p >= hw) continue;
     const int y = p / W3, x = p - y * W3;
     float v[4], t[4];
-    {
-      const T* src = s3 + ((size_t)b * hw + p) * ldc + c4;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = tf::Elem<T>::load(src + j);
-    }
+    load4(s3 + ((size_t)b * hw + p) * ldc + c4, v);          // (r4: one 8- / 16-byte load per 4-channel group instead of four element loads)
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
       const int ky = ((y + 1) & 1) + 2 * a, ty = y + 1 - ky;
@@ -575,9 +584,7 @@ __global__ void __launch_bounds__(256) upsample_add_kernel(const T* __restrict__
         if (tx < 0) continue;
         const int jx = tx >> 1;
         if (jx >= W4) continue;
-        const T* src = s4 + (((size_t)b * H4 + i) * W4 + jx) * ldc + c4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) t[j] = tf::Elem<T>::load(src + j);
+        load4(s4 + (((size_t)b * H4 + i) * W4 + jx) * ldc + c4, t);
 #pragma unroll
         for (int j = 0; j < 4; ++j) if (c4 + j < C) v[j] += t[j] * wup[(c4 + j) * 16 + ky * 4 + kx];
       }
