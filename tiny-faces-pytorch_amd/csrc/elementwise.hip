@@ -613,19 +613,34 @@ __global__ void __launch_bounds__(256) upsample_add_bwd_kernel(const float* __re
   const int cc = blockIdx.x % chunks, i = (blockIdx.x / chunks) % H4, b = blockIdx.x / (chunks * H4);
   const int c0 = cc * kUpC;
   (void)B;
-  for (int e = threadIdx.x; e < 4 * kUpC * W3; e += 256) {
-    const int x = e % W3, cl = (e / W3) % kUpC, r = e / (W3 * kUpC);
-    const int y = 2 * i - 1 + r, c = c0 + cl;
-    float v = 0.f;
-    if ((unsigned)y < (unsigned)H3 && c < C) v = g[(((size_t)b * C + c) * H3 + y) * W3 + x];
-    slab[(r * kUpC + cl) * pitch + x] = v;
+  // r4: a wave per (slab row, channel) line of W3 floats, eight lines per pass -- the flat-index loop of rounds 1-3 issued ONE load per
+  // iteration (31 dependent round trips per thread, two runtime divisions each): 80 us for 48 MB
+  {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int x0 = 0; x0 < W3; x0 += 64) {
+      const int x = x0 + lane;
+#pragma unroll 8
+      for (int rc = wave; rc < 4 * kUpC; rc += 4) {
+        const int r = rc / kUpC, cl = rc % kUpC;
+        const int y = 2 * i - 1 + r, c = c0 + cl;
+        float v = 0.f;
+        if (x < W3 && (unsigned)y < (unsigned)H3 && c < C) v = g[(((size_t)b * C + c) * H3 + y) * W3 + x];
+        if (x < W3) slab[(r * kUpC + cl) * pitch + x] = v;
+      }
+    }
   }
   __syncthreads();
-  // g3 rows 2i, 2i+1 (slab rows 1, 2)
-  for (int e = threadIdx.x; e < 2 * W3 * kUpC; e += 256) {
-    const int cl = e % kUpC, x = (e / kUpC) % W3, rr = e / (kUpC * W3);
-    const int y = 2 * i + rr;
-    if (y < H3) tf::Elem<T>::store(g3 + (((size_t)b * H3 + y) * W3 + x) * ldc + c0 + cl, slab[((1 + rr) * kUpC + cl) * pitch + x]);
+  // g3 rows 2i, 2i+1 (slab rows 1, 2): thread -> channel threadIdx % 32, columns threadIdx / 32 + 8 k
+  {
+    const int cl = threadIdx.x % kUpC;
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int y = 2 * i + rr;
+      if (y >= H3) continue;
+#pragma unroll 4
+      for (int x = threadIdx.x / kUpC; x < W3; x += 256 / kUpC)
+        tf::Elem<T>::store(g3 + (((size_t)b * H3 + y) * W3 + x) * ldc + c0 + cl, slab[((1 + rr) * kUpC + cl) * pitch + x]);
+    }
   }
   // g4 row i
   for (int e = threadIdx.x; e < W4 * kUpC; e += 256) {
