@@ -20,7 +20,11 @@
 //   backward: dgrad epilogues apply the ReLU mask and fold the BN-backward sums; the last data
 //          gradient of a block hands the previous block g*(y>0) AND its BN3-backward sums
 //          (RES|MASK2|STATS3); bn_bwd_apply_fused finalizes in-kernel; weight gradients run on
-//          a second stream against parity buffers.
+//          the context's second stream against per-block operand buffers (r4) -- per launch for
+//          layers 1-2, deferred and grouped (tf_conv2d_wgrad_group: 8 + 7 + 7 blocks) for the
+//          identity bottlenecks of layer 3.
+//   stem (r4): conv1 and its weight gradient straight from the NCHW image (stem_conv.hip), the
+//          BN-backward sums inside the max-pool backward, the apply inside the weight gradient.
 //   tf_set_stat_rows(0) (unfolded, bit-reproducible statistics) falls back to the separate
 //   finalize kernels and the unmasked gradient flow: the A/B and race-screen path.
 #include <cstdio>
@@ -59,9 +63,10 @@ int tf_conv2d_wgrad_group(const tf_wgrad_args*, int, void*);
 namespace {
 
 constexpr int kStemK = 192;     // 147 taps*channels padded to 3 x 64
-// r4: conv1 straight from the image (csrc/stem_conv.hip) for the 2-byte operand types: no 288 MB im2col matrix on the forward chain.  The
-// weight gradient still reduces over that matrix: a training step builds it on the second stream at the top of the backward pass, where
-// that stream is idle.  fp32 and the unfolded-statistics mode keep im2col + GEMM.  TINYFACES_STEM_DIRECT_OFF=1: A/B knob.
+// r4: conv1 AND its weight gradient straight from the image (csrc/stem_conv.hip: tf_stem_conv, tf_stem_wgrad) for the 2-byte operand types:
+// no 288 MB im2col matrix in a training step or an evaluation forward.  fp32 and the unfolded-statistics mode keep im2col + GEMM.
+// TINYFACES_STEM_DIRECT_OFF=1: the path of rounds 1-3; TINYFACES_STEM_WGRAD_IM2COL=1: only the weight gradient over the im2col matrix (built on
+// the second stream at the top of the backward pass).
 bool stem_direct_mode(int dtype, bool training, bool fused) {
   static const bool off = getenv("TINYFACES_STEM_DIRECT_OFF") != nullptr;
   return !off && dtype != TF_F32 && (!training || fused);
@@ -574,7 +579,7 @@ extern "C" int tf_detnet_forward_ctx(tf_detnet_ctx* xctx, int single_stream, int
   const bool fused = tr && srows <= TF_STAT_ROWS && !g_unfused_env;
   // statistic rows start at zero: the per-BN regions and, right behind them in the arena, the head of the shared partial buffer -- ONE memset
   if (tr && hipMemsetAsync(P.stat_fwd, 0, (size_t)((char*)P.partial - (char*)P.stat_fwd) + (size_t)TF_STAT_ROWS * 3 * 1024 * 4, c.stream) != hipSuccess) c.chk(TF_ERR_LAUNCH);
-  // ---- stem: im2col + GEMM (+BN+ReLU) + maxpool
+  // ---- stem: conv1 (direct, or im2col + GEMM) (+BN+ReLU) + maxpool
   const int M1 = N * P.H1 * P.W1;
   // r3 experiment, NEGATIVE, kept behind TINYFACES_PACK_SIDE=1: the weight re-packing of a training step (three launches, ~170 us: 111 MB
   // of masters read, 2 x 55 MB written) on a second stream BESIDE the stem's im2col (~130 us) -- both are HBM-bound, side by side they
