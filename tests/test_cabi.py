@@ -147,3 +147,31 @@ def test_conv_pwx_inline_asm_loads_are_untouched_until_their_wait(tmp_path):
                 j += 1
             checked += 1
     assert checked >= 12          # prologue + steady-state loads of the four instantiations
+
+
+def test_round4_entry_points_refuse_bad_arguments_without_launching(hip):
+    """The entry points added in round 4 check their arguments on the host before anything is enqueued: a NULL operand or an operand type a
+    kernel does not exist for comes back as TF_ERR_ARG / TF_ERR_UNSUPPORTED (the reference-side binding maps these to exceptions), never
+    as a launch.  Runs without a GPU."""
+    import ctypes as C
+    l = hip.lib()
+    ERR_ARG, ERR_UNSUPPORTED = -1, -3
+    one = C.c_int(0)
+    buf = (C.c_float * 64)()
+    p = C.cast(buf, C.c_void_p)
+    # conv1 straight from the image: 2-byte operand types only, every operand required, the statistic epilogue needs its outputs
+    assert l.tf_stem_conv(0, p, 1, 8, 8, p, 192, p, 0, None, None, None, None, None) == ERR_UNSUPPORTED          # TF_F32
+    assert l.tf_stem_conv(1, None, 1, 8, 8, p, 192, p, 0, None, None, None, None, None) == ERR_ARG
+    assert l.tf_stem_conv(1, p, 1, 8, 8, p, 100, p, 0, None, None, None, None, None) == ERR_ARG                    # ldw < 160
+    assert l.tf_stem_conv(1, p, 1, 8, 8, p, 192, p, 8, None, None, None, C.byref(one), None) == ERR_ARG            # TF_EPI_STATS without rows
+    assert l.tf_stem_conv(1, p, 1, 8, 8, p, 192, p, 5, None, None, None, None, None) == ERR_ARG                    # folded BN without vectors
+    assert l.tf_stem_conv(1, p, 1, 8, 8, p, 192, p, 2, None, None, None, None, None) == ERR_UNSUPPORTED            # an epilogue it does not have
+    assert l.tf_stem_wgrad(0, p, 1, 8, 8, p, None, None, None, None, p, None) == ERR_UNSUPPORTED
+    assert l.tf_stem_wgrad(1, p, 1, 8, 8, None, None, None, None, None, p, None) == ERR_ARG
+    assert l.tf_stem_wgrad(1, p, 1, 8, 8, p, p, None, None, None, p, None) == ERR_ARG                               # apply without coefficients
+    assert l.tf_maxpool_bwd_stats(1, p, p, p, p, p, 1, 8, 8, 64, p, None, C.byref(one), None) == ERR_ARG
+    assert l.tf_maxpool_bwd_stats(1, p, p, p, p, p, 1, 8, 8, 60, p, p, C.byref(one), None) == ERR_ARG                # C % 8
+    assert l.tf_conv2d_wgrad_group(None, 1, None) == ERR_ARG
+    # the executor context and the communicator: NULL handles are refused, not dereferenced
+    assert l.tf_comm_rank(None) == -1 and l.tf_comm_world(None) == 0          # "no communicator": rank -1 of a world of 0
+    assert l.tf_allreduce_bucket(None, p, 4, None) == ERR_ARG
