@@ -623,3 +623,30 @@ def test_wider_parser_names_the_malformed_record(tmp_path):
     with pytest.raises(ValueError, match="record 1 of 'a/1.jpg'"):
         parse_annotations(str(f), "train")
 
+
+def test_frozen_parameter_tables_skip_the_walk_until_the_module_moves():
+    """DetectionModel._sync_tables (r4): an owner that pins the storages (TrainEngine after flatten_parameters) freezes the pointer tables, so a
+    step does not walk the 571 tensors; anything that can move a storage (`_apply`: .to() / .float() / .cuda(), or flatten_parameters itself)
+    unfreezes and rebuilds them."""
+    import torch
+    from tinyfaces.models.model import DetectionModel
+    m = DetectionModel(num_templates=25)
+    dev = torch.device("cpu")
+    m._sync_tables(dev)                                   # builds the tables (host-side only: pointers and shapes)
+    key = m._table_key
+    assert key is not None and len(m._names) == 475
+    walks = []
+    orig = m._named_tensors
+    m._named_tensors = lambda: (walks.append(1), orig())[1]
+    m._sync_tables(dev)
+    assert len(walks) == 1 and m._table_key == key        # not frozen: the identity walk runs (and finds nothing changed)
+    m._tables_frozen = True
+    m._sync_tables(dev); m._sync_tables(dev)
+    assert len(walks) == 1                                # frozen: no walk
+    m.float()                                             # nn.Module._apply: storages may move
+    assert m._tables_frozen is False and m._table_key is None
+    m._sync_tables(dev)
+    assert len(walks) == 2 and m._table_key is not None
+    m._tables_frozen = True
+    flat = m.flatten_parameters()                         # re-points every parameter: must rebuild even when frozen
+    assert len(walks) >= 3 and m._table_key != key and flat.numel() > 27_000_000
