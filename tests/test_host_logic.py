@@ -650,3 +650,43 @@ def test_frozen_parameter_tables_skip_the_walk_until_the_module_moves():
     m._tables_frozen = True
     flat = m.flatten_parameters()                         # re-points every parameter: must rebuild even when frozen
     assert len(walks) >= 3 and m._table_key != key and flat.numel() > 27_000_000
+
+
+def test_stem_wgrad_patch_copies_address_the_right_input_pixels():
+    """csrc/stem_conv.hip (r4), the operand layout of the direct conv1 weight gradient, restated in numpy: the input patch of a 4 x 32-pixel tile
+    is staged split by column parity q and in four copies shifted by s elements, copy(s, q)[row][i] = patch[row][2 (i + s) + q]; a lane that owns
+    k = (c, kh, kw) reads, for tile row ph and pixel quad pw0 (a multiple of 4), the four CONSECUTIVE elements i = pw0 .. pw0 + 3 of row
+    (c, 2 ph + kh) of copy (kw >> 1, kw & 1) -- and must get the input pixels (2 ph + kh, 2 pw + kw) of output pixels pw = pw0 .. pw0 + 3,
+    i.e. what im2col column k holds for them.  Also: every element a fragment can touch is written by the staging (12-column segments)."""
+    TH, TW, PR, PCOLS, PC, SEG = 4, 32, 13, 69, 72, 12
+    rng = np.random.RandomState(0)
+    patch = np.zeros((3 * PR, PC), np.float64)
+    patch[:, :PCOLS] = rng.rand(3 * PR, PCOLS) + 1.0          # > 0: an unwritten copy element (0) is detectable
+    copies = np.zeros((4, 2, 3 * PR, TW), np.float64)
+    written = np.zeros_like(copies, dtype=bool)
+    for prow in range(3 * PR):                                # the kernel's staging: thread -> (row, 12-column segment)
+        for pseg in range(PC // SEG):
+            for qq in range(SEG):
+                par, h = qq & 1, pseg * (SEG // 2) + (qq >> 1)
+                for sft in range(4):
+                    i = h - sft
+                    if 0 <= i < TW:
+                        copies[sft, par, prow, i] = patch[prow, pseg * SEG + qq]
+                        written[sft, par, prow, i] = True
+    assert written.all()
+    for k in range(147):
+        c, kh, kw = k // 49, (k % 49) // 7, k % 7
+        for ph in range(TH):
+            row = c * PR + 2 * ph + kh
+            for pw0 in range(0, TW, 4):
+                got = copies[kw >> 1, kw & 1, row, pw0:pw0 + 4]
+                want = patch[row, [2 * pw + kw for pw in range(pw0, pw0 + 4)]]
+                assert np.array_equal(got, want), (k, ph, pw0)
+    # the forward kernel's gather table: offset of k inside the (c, row, column) patch raster, output pixel (ph, pw) at base 2 ph PC + 2 pw
+    flat = patch.reshape(-1)
+    for k in (0, 6, 7, 48, 49, 100, 146):
+        c, kh, kw = k // 49, (k % 49) // 7, k % 7
+        off = (c * PR + kh) * PC + kw
+        for ph, pw in ((0, 0), (3, 31), (2, 17)):
+            assert flat[off + 2 * ph * PC + 2 * pw] == patch[c * PR + 2 * ph + kh, 2 * pw + kw]
+    assert 2 * (TH - 1) * PC + 2 * (TW - 1) < 512             # ZPAD: the zero region behind the patch covers every pixel base offset
