@@ -35,6 +35,17 @@ def test_library_exports_every_declared_symbol(built, hip):
     assert hip.lib().tf_version() >= 100
 
 
+def test_library_exports_only_the_c_abi(built):
+    """csrc/exports.map: nothing but tf_* (the ABI + the four debug probes of csrc/debug_api.h) is a dynamic symbol of the library --
+    no C++-mangled launcher leaks out."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", built], capture_output=True, text=True, check=True).stdout
+    names = [ln.split()[-1] for ln in out.splitlines() if ln.strip()]
+    assert names and not [n for n in names if n.startswith("_Z")], [n for n in names if n.startswith("_Z")][:5]
+    dbg = set(re.findall(r"\b(tf_[a-z0-9_]+)\s*\(", open(os.path.join(ROOT, "tiny-faces-pytorch_amd", "csrc", "debug_api.h")).read()))
+    assert set(names) == set(_declared()) | dbg
+
+
 def test_binding_signatures_cover_the_abi(hip):
     assert set(hip._SIGNATURES) == set(hip.symbols())
 

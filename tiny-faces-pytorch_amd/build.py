@@ -14,6 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "tinyfaces", "libtinyfaces_hip.so")
+EXPORTS = os.path.join(CSRC, "exports.map")   # only tf_* leaves the library
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # files whose float64 arithmetic must round exactly like numpy's: no FMA contraction
@@ -23,6 +24,7 @@ EXACT = {"targets.hip", "nms.hip", "decode.hip", "augment.hip"}
 def _deps_mtime():
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     hdrs.append(os.path.join(os.path.dirname(HERE), "include", "tinyfaces_hip.h"))
+    hdrs.append(EXPORTS)
     return max(os.path.getmtime(h) for h in hdrs)
 
 
@@ -52,7 +54,7 @@ def build(force=False, verbose=True):
                 print(out)
     objs = [os.path.join(OBJ, f[:-4] + ".o") for f in srcs]
     if force or jobs or not os.path.exists(LIB):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", f"-Wl,--version-script={EXPORTS}", "-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stdout + r.stderr)
