@@ -383,8 +383,8 @@ def bench_fp32_path(device, rank, batch, steps=20, warmup=3):
     if prof:
         dom = max(prof, key=lambda r: r["ms"])
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-        out["roofline"] = {"kernel": KIND_NAMES.get(dom["kind"], str(dom["kind"])), "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS["fp32"],
-                           "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS["fp32"], 4), "traffic": pmc_traffic(dom["kind"], PMC_TRAFFIC_FILE_FP32),
+        out["roofline"] = {"kernel": KIND_NAMES.get(dom["kind"], str(dom["kind"])), **roof_of(dom["flops"], dom["bytes"], dom["ms"] * 1e-3, PEAK_TFLOPS["fp32"]),
+                           "achieved_tflops": round(ach, 2), "traffic": pmc_traffic(dom["kind"], PMC_TRAFFIC_FILE_FP32),
                            "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes of `bench.py --dtype fp32` (profiles/r04_pmc_traffic_fp32.json); "
                                            "algorithmic bytes per launch = %d" % round(dom["bytes"] / dom["launches"]),
                            "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2), "launches_sampled": dom["launches"],
@@ -494,6 +494,42 @@ def _arena_gb(model, H, W):
     return _hip.lib().tf_detnet_workspace_bytes(_hip.TF_F16, 1, H, W, model.num_out, 0) / 2**30
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher around it (no WORLD_SIZE / RANK in the environment): start the N ranks ourselves --
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free port> bench.py <same
+    arguments>`, one process per GPU over RCCL; rank 0's JSON line passes through on stdout, the exit code is the job's."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    share = os.environ.get("TINYFACES_BENCH_SHARE_GPU") == "1"
+    if have == 0:
+        sys.stderr.write(f"bench.py --gpus {n}: no GPU is visible to this process (the HIP path has no CPU fallback)\n")
+        return 3
+    if have < n and not share:
+        sys.stderr.write(f"bench.py --gpus {n}: only {have} GPU(s) visible; one process per GPU needs {n} "
+                         "(TINYFACES_BENCH_SHARE_GPU=1 runs the ranks over gloo on shared devices: functional test only)\n")
+        return 3
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "8"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def roof_of(flops, nbytes, seconds, peak_tflops):
+    """Which roof binds a launch: the one whose minimum time is larger -- t_mfma = flops / peak, t_hbm = bytes / 8 TB/s,
+    both from the ALGORITHMIC work of the launch.  Returns the roofline fields expressed against THAT roof plus both fractions."""
+    t_m, t_h = flops / (peak_tflops * 1e12), nbytes / (PEAK_HBM_GBS * 1e9)
+    frac_m, frac_h = t_m / seconds, t_h / seconds
+    if t_h >= t_m:
+        return {"bound": "hbm", "achieved": round(nbytes / seconds / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(frac_h, 4),
+                "frac_mfma": round(frac_m, 4), "frac_hbm": round(frac_h, 4)}
+    return {"bound": "mfma", "achieved": round(flops / seconds / 1e12, 2), "peak": peak_tflops, "unit": "TFLOP/s", "frac": round(frac_m, 4),
+            "frac_mfma": round(frac_m, 4), "frac_hbm": round(frac_h, 4)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -515,6 +551,8 @@ def main():
     ap.add_argument("--no-eval-hard", action="store_true", help="skip the configs[4] leg (5000-px fp16 pyramid + batched NMS)")
     ap.add_argument("--cpu-full", action="store_true", help="CPU baseline with the full BASELINE.md protocol (3 + 5 training steps, 3 + 20 images) instead of the bounded sample")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(self_launch(args.gpus))      # `python bench.py --gpus N`: this process becomes the launcher of N ranks
 
     from tinyfaces import _hip, ops, parallel
     from tinyfaces.datasets.templates import load_templates
@@ -761,15 +799,20 @@ def main():
         dom = max(prof, key=lambda r: r["ms"])
         peak = PEAK_TFLOPS["bf16" if dom["kind"] in BF16_KINDS else "fp32"]
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-        out["roofline"] = {"kernel": KIND_NAMES.get(dom["kind"], str(dom["kind"])), "bound": "mfma", "achieved": round(ach, 2), "peak": peak,
-                           "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": pmc_traffic(dom["kind"]),
+        roof = roof_of(dom["flops"], dom["bytes"], dom["ms"] * 1e-3, peak)
+        out["roofline"] = {"kernel": KIND_NAMES.get(dom["kind"], str(dom["kind"])), **roof,
+                           "bound_note": "bound = argmax(algorithmic flops / MFMA peak, algorithmic bytes / 8 TB/s) of the kernel's launches in the timed region; "
+                                         "achieved / peak / frac are stated against that roof, frac_mfma and frac_hbm against both",
+                           "achieved_tflops": round(ach, 2), "peak_tflops": peak,
+                           "arithmetic_intensity_flop_per_byte": round(dom["flops"] / max(dom["bytes"], 1.0), 1), "machine_balance_flop_per_byte": round(peak * 1e12 / (PEAK_HBM_GBS * 1e9), 1),
+                           "traffic": pmc_traffic(dom["kind"]),
                            "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes of this command (profiles/r04_pmc_traffic.json); "
                                            "algorithmic bytes per launch = %d" % round(dom["bytes"] / dom["launches"]),
                            "launches_sampled": dom["launches"], "launches_per_step": round(dom["launches"] * PROFILE_EVERY / args.steps, 1),
                            "sampling": f"HIP events around 1 launch in {PROFILE_EVERY} over the timed region (weight gradients run concurrently on a second stream)",
                            "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
                            "rocprof_avg_launch_us": rocprof_avg_us(dom["kind"]),
-                           "frac_rocprof_clock": (lambda us: round(dom["flops"] / dom["launches"] / (us * 1e-6) / 1e12 / peak, 4) if us else None)(rocprof_avg_us(dom["kind"])),
+                           "frac_rocprof_clock": (lambda us: roof_of(dom["flops"] / dom["launches"], dom["bytes"] / dom["launches"], us * 1e-6, peak)["frac"] if us else None)(rocprof_avg_us(dom["kind"])),
                            "rocprof_note": "true kernel duration in the committed rocprofv3 --kernel-trace --stats summary of this command "
                                            "(profiles/r04_train_bs12_bf16_kernel_stats.csv); the HIP-event bracket adds the queue's inter-packet latency (~5-6 us)",
                            "algorithmic_gflop_per_launch": round(dom["flops"] / dom["launches"] / 1e9, 3),
@@ -788,7 +831,9 @@ def main():
                                             "profiles/r04_pmc_traffic.json) over this run's step time; the step is nearer to the HBM roof than to the MFMA roof"}
         out["kernels"] = [{"kernel": KIND_NAMES.get(r["kind"], str(r["kind"])), "launches_per_step": round(r["launches"] * PROFILE_EVERY / args.steps, 1),
                            "ms_per_step": round(r["ms"] * PROFILE_EVERY / args.steps, 3),
-                           "tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 1), "gb_s": round(r["bytes"] / (r["ms"] * 1e-3) / 1e9, 1)} for r in prof]
+                           "tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 1), "gb_s": round(r["bytes"] / (r["ms"] * 1e-3) / 1e9, 1),
+                           **{k: v for k, v in roof_of(r["flops"], r["bytes"], r["ms"] * 1e-3, PEAK_TFLOPS["bf16" if r["kind"] in BF16_KINDS else "fp32"]).items()
+                              if k in ("bound", "frac_mfma", "frac_hbm")}} for r in prof]
         fw = [r for r in shapes if r["mode"] == 0 and r["kind"] == dom["kind"]]
         if fw:          # the forward convs of the same kernel (no second stream is active during the forward pass)
             f_ms, f_fl = sum(r["ms"] for r in fw), sum(r["flops"] for r in fw)

@@ -217,3 +217,24 @@ def test_evaluate_model_two_ranks_write_what_one_process_writes(tmp_path):
     assert sorted(os.listdir(one)) == sorted(os.listdir(two)) == ["img_0.txt", "img_1.txt", "img_2.txt"]
     for f in os.listdir(one):
         assert open(one / f).read() == open(two / f).read(), f
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` (the form the driver uses, no launcher around it) starts its N ranks itself.  On the
+    1-GPU lease the two ranks share cuda:0 over gloo (TINYFACES_BENCH_SHARE_GPU=1; two RCCL ranks on one device are refused by RCCL):
+    rc 0, ONE JSON line on stdout, n_gpus == 2, a whole-job value of two ranks' images and the exchange block of the N > 1 path."""
+    import json
+    env = dict(os.environ, TINYFACES_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"], capture_output=True, text=True,
+                       timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["config"]["global_batch"] == 24 and out["config"]["parallelism"] == "dp2"
+    assert out["scaling"] == "weak" and out["value"] > 0 and abs(out["value"] - 24 / (out["ms_per_step"] * 1e-3)) < 0.02 * out["value"]
+    assert out["allreduce"].get("ranks") == 2, out["allreduce"]
+    assert out["roofline"]["bound"] in ("hbm", "mfma") and 0 < out["roofline"]["frac"] < 1
+    report("bench_self_launch", img_s=out["value"], ms_per_step=out["ms_per_step"], exposed_ms=out["allreduce"].get("exposed_ms_per_step"))

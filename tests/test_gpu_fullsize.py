@@ -243,3 +243,73 @@ def test_get_detections_960x1280_bf16_overlap(pyramid_case):
     report("fullsize_detections[bf16]", kept=dets.shape[0], ref_kept=ref.shape[0], found=found, survivor_logit_spread=spread, map_maxabs=dmap[0], map_maxref=dmap[1])
     assert dmap[0] < 1.8e-2                                                                               # bf16 maps at 960 x 1280 vs the oracle
     assert found >= 0.88 * ref.shape[0] and abs(dets.shape[0] - ref.shape[0]) <= 0.1 * ref.shape[0]
+
+
+def test_single_image_eval_forward_500x500_fp32_vs_oracle():
+    """BASELINE.json configs[0]: ONE 500x500 random image, 25 templates, eval-mode forward through DetectionModel (the reference's
+    CPU-runnable plumbing case).  It is served here by the fp32 GPU path (a CPU tensor raises): per-anchor cls / reg maps within the
+    1e-3 of north_star against the torch-CPU oracle, same (1, 125, 63, 63) surface."""
+    from oracle.model import OracleDetectionModel, tame_init_
+    from tinyfaces.models.model import DetectionModel
+    om = tame_init_(OracleDetectionModel(num_templates=25), 0).eval()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 3, SIDE, SIDE, generator=g)
+    with torch.no_grad():
+        want = om(x)
+    m = DetectionModel(num_templates=25)
+    m.load_state_dict(om.state_dict(), strict=True)
+    m = m.cuda().set_compute_dtype(torch.float32).eval()
+    with torch.no_grad():
+        got = m(x.cuda())
+    assert tuple(got.shape) == tuple(want.shape) == (1, 125, 63, 63)
+    d = err(got.cpu().numpy(), want.numpy())
+    report("configs0_single_image_eval_fp32", maxabs=d[0], rel=d[2], span=float(want.abs().max()))
+    assert d[0] < 1e-3, d
+    with pytest.raises(Exception):
+        m(x)                                   # the CPU tensor: no fallback
+
+
+def test_bf16_trains_like_fp32():
+    """the headline number stands on the bf16 path, whose single-step gradients are held by direction only.  This test
+    shows that it TRAINS like the fp32 path: 150 fused-engine steps (targets -> forward -> criterion with OHEM + balanced sampling ->
+    backward -> SGD, tinyfaces/trainer.py:72-87 semantics) on ONE fixed 4-image batch, from the same initial weights and the same sampling
+    seeds, once with fp32 and once with bf16 MFMA operands.  Both losses must fall by the stated factor, and the bf16 trajectory (mean of
+    10-step windows) must stay within the stated band of the fp32 one."""
+    from oracle.model import OracleDetectionModel, tame_init_
+    from tinyfaces import ops
+    from tinyfaces.datasets.synthetic import random_boxes
+    from tinyfaces.datasets.templates import load_templates
+    from tinyfaces.engine import TrainEngine
+    from tinyfaces.models.loss import DetectionCriterion
+    from tinyfaces.models.model import DetectionModel
+    B, S, STEPS = 4, 500, 150
+    templates = load_templates()
+    sd0 = tame_init_(OracleDetectionModel(num_templates=25), 0).state_dict()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, 3, S, S, generator=g).cuda()
+    rng = np.random.RandomState(3)
+    boxes = [random_boxes(rng) for _ in range(B)]
+    noise = [np.random.RandomState(200 + i).rand(63, 63, 25, b.shape[0]) for i, b in enumerate(boxes)]
+    cm, rm = ops.dense_overlap_targets(boxes, templates, paste_boxes=[[0, 0, S, S]] * B, noise=noise, device="cuda")
+    curves = {}
+    for name, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        m = DetectionModel(num_templates=25)
+        m.load_state_dict({k: v.clone() for k, v in sd0.items()}, strict=True)
+        m.set_compute_dtype(dt)
+        eng = TrainEngine(m, DetectionCriterion(25, seed=7), lr=1e-3, momentum=0.9, weight_decay=5e-4, device="cuda")
+        losses = []
+        for _ in range(STEPS):
+            losses.append(eng.step(x, cm.clone(), rm))
+        torch.cuda.synchronize()
+        curves[name] = np.array([float(l.sum()) / B for l in losses])
+        eng.close()
+        del eng, m
+    w = lambda c: c.reshape(-1, 10).mean(1)                      # 15 windows of 10 steps (the sampling draws make single steps noisy)
+    f, b = w(curves["fp32"]), w(curves["bf16"])
+    band = float(np.abs(b - f).max() / f[0])
+    rel = float(np.abs(b / f - 1).max())
+    report("bf16_trains_like_fp32", fp32_first=f[0], fp32_last=f[-1], bf16_first=b[0], bf16_last=b[-1], fall_fp32=f[0] / f[-1], fall_bf16=b[0] / b[-1],
+           band_of_first=band, max_rel_window=rel)
+    assert np.isfinite(curves["fp32"]).all() and np.isfinite(curves["bf16"]).all()
+    assert f[0] / f[-1] >= 2.0 and b[0] / b[-1] >= 2.0, (f, b)
+    assert band < 0.10 and rel < 0.25, (band, rel, f, b)

@@ -550,3 +550,57 @@ def test_grad_ready_callback_is_called_per_bucket_with_the_carrying_stream():
     m._run_backward(x, torch.ones_like(out), persistent=True)
     torch.cuda.synchronize()
     assert calls == []
+
+
+_REFUSED_GROUP_SCRIPT = r'''
+import sys, numpy as np, torch
+sys.path[:0] = [ROOT, ROOT + "/tiny-faces-pytorch_amd"]
+from oracle.model import OracleDetectionModel, tame_init_
+from tinyfaces.engine import TrainEngine
+from tinyfaces.models.loss import DetectionCriterion
+from tinyfaces.models.model import DetectionModel
+g = np.load(ROOT + "/tests/golden/trainer.npz")
+img, cm, rm = (torch.from_numpy(g["b0_img"]).cuda(), torch.from_numpy(g["b0_cm"].astype(np.float32)).cuda(), torch.from_numpy(g["b0_rm"]).float().cuda())
+m = DetectionModel(num_templates=25)
+m.load_state_dict(tame_init_(OracleDetectionModel(num_templates=25), 0).state_dict())
+m.set_compute_dtype(torch.bfloat16)
+c = DetectionCriterion(25)
+keep = torch.ones(2, 25 * 16 * 16, dtype=torch.uint8); keep[:, 128:] = 0
+c.inject_sampling(keep, keep)
+eng = TrainEngine(m, c, lr=0.0, momentum=0.0, weight_decay=0.0, device="cuda")     # lr 0: both steps differentiate the SAME function
+out = []
+for _ in range(2):
+    eng.step(img, cm.clone(), rm)
+    torch.cuda.synchronize()
+    out.append(m._grad_flat_persistent.detach().float().cpu().numpy().copy())
+o, n = m._segments["model.layer3.5.conv2.weight"]
+np.savez(sys.argv[1], g1=out[0], g2=out[1], lo=o, n=n)
+'''
+
+
+@pytest.mark.parametrize("refuse", [0, 1])
+def test_refused_wgrad_group_falls_back_into_zeroed_gradients(tmp_path, refuse):
+    """ADVICE r4 (medium): when tf_conv2d_wgrad_group refuses a group (layer-3 width the all-taps plan does not take), the per-problem
+    fallback accumulates with fp32 atomics -- into tensors the split flat-gradient memset skipped.  On the engine's PERSISTENT gradient the
+    second step would then carry step one's values on top.  TINYFACES_DBG_GROUP_REFUSE=1 forces the refusal at any size (the knob is read
+    once per process, hence the subprocess): with lr = 0 the two steps' gradients must agree, and must equal the grouped kernels'."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / f"g{refuse}.npz")
+    env = dict(os.environ)
+    env.pop("TINYFACES_DBG_GROUP_REFUSE", None)
+    if refuse:
+        env["TINYFACES_DBG_GROUP_REFUSE"] = "1"
+    r = subprocess.run([sys.executable, "-c", f"ROOT = {root!r}\n" + _REFUSED_GROUP_SCRIPT, out], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    z = np.load(out)
+    g1, g2, lo, n = z["g1"], z["g2"], int(z["lo"]), int(z["n"])
+    a, b = g1[lo:lo + n], g2[lo:lo + n]
+    assert np.abs(a).max() > 0
+    cos = float(np.dot(a, b) / (np.linalg.norm(a) * np.linalg.norm(b)))
+    ratio = float(np.linalg.norm(b) / np.linalg.norm(a))
+    cos_all = float(np.dot(g1, g2) / (np.linalg.norm(g1) * np.linalg.norm(g2)))
+    report(f"refused_group[refuse={refuse}]", cos_layer3_conv2=cos, norm_ratio=ratio, cos_flat=cos_all)
+    # the same function twice: equal up to the run-to-run order of the fp32 atomics (BN statistic rows, split-K sums)
+    assert 0.98 < ratio < 1.02 and cos > 0.999, (ratio, cos)
+    assert cos_all > 0.999

@@ -997,11 +997,22 @@ extern "C" int tf_detnet_backward_ctx(tf_detnet_ctx* xctx, const tf_detnet_hooks
     if (!skip) {
       // the 3x3 group first: 16 tiles per problem = half a machine for a group of eight; the pointwise launch behind it fills the CUs its
       // tail leaves (both are enqueued behind the same fork)
-      int rc = tf_conv2d_wgrad_group(pend_c3.data(), (int)pend_c3.size(), c.gstream());
-      if (rc == TF_ERR_UNSUPPORTED) for (const tf_wgrad_args& w : pend_c3) c.chk(tf_conv2d_wgrad(&w, c.gstream()));      // (atomics into the zeroed gradient)
+      // A refused group (e.g. a layer-3 width the all-taps plan does not take: inputs wider than ~2000 px) falls back to the per-problem
+      // split-K kernels, which ACCUMULATE with fp32 atomics -- and the split memset above skipped exactly these tensors, so on a
+      // persistent flat gradient they would be added onto the previous step's (all-reduced) values: zero each one here, on the stream
+      // the fallback launches run on (tests/test_gpu_model.py::test_refused_wgrad_group_falls_back_into_zeroed_gradients)
+      auto fallback = [&](const std::vector<tf_wgrad_args>& v) {
+        for (const tf_wgrad_args& w : v) {
+          if (hipMemsetAsync(w.dw_oihw, 0, (size_t)w.Cout * w.dw_ld * 4, c.gstream()) != hipSuccess) c.chk(TF_ERR_LAUNCH);
+          c.chk(tf_conv2d_wgrad(&w, c.gstream()));
+        }
+      };
+      static const bool force_refuse = getenv("TINYFACES_DBG_GROUP_REFUSE") != nullptr;      // test knob: exercise the fallback at any size
+      int rc = force_refuse ? TF_ERR_UNSUPPORTED : tf_conv2d_wgrad_group(pend_c3.data(), (int)pend_c3.size(), c.gstream());
+      if (rc == TF_ERR_UNSUPPORTED) fallback(pend_c3);
       else c.chk(rc);
-      rc = tf_conv2d_wgrad_group(pend_pw.data(), (int)pend_pw.size(), c.gstream());
-      if (rc == TF_ERR_UNSUPPORTED) for (const tf_wgrad_args& w : pend_pw) c.chk(tf_conv2d_wgrad(&w, c.gstream()));
+      rc = force_refuse ? TF_ERR_UNSUPPORTED : tf_conv2d_wgrad_group(pend_pw.data(), (int)pend_pw.size(), c.gstream());
+      if (rc == TF_ERR_UNSUPPORTED) fallback(pend_pw);
       else c.chk(rc);
     }
     // a gradient-ready event of a grouped block promises "every gradient of the blocks >= it, and of the heads": the heads and layer3.x

@@ -169,9 +169,25 @@ class TrainEngine:
         except BaseException as e:       # an exception must not unwind through the C frames of the executor
             self._cb_error = e
 
+    def _drain_exchange(self):
+        """Error path of step(): whatever the gradient hooks issued before the backward call failed is waited for, so that neither the
+        communicator's stream nor torch's work objects outlive the step (a peer that did NOT fail is released by the group's timeout)."""
+        try:
+            if self._native is not None:
+                with torch.cuda.device(self.device):
+                    lib().tf_comm_join(self._native["comm"], torch.cuda.current_stream(self.device).cuda_stream)
+                self._native["plan"].issued, self._native["plan"].rc = 0, 0
+            works, self._works = getattr(self, "_works", []), []
+            for w in works:
+                w.wait()
+        except Exception:
+            pass
+
     def close(self):
         """Detach the gradient-ready events from the model (they are owned by this engine: the executor must not record
-        handles that are about to be destroyed)."""
+        handles that are about to be destroyed) and hand the pointer tables back to the per-call identity walk."""
+        if getattr(self, "model", None) is not None:
+            self.model._tables_frozen = False
         if self._overlap is not None:
             if getattr(self.model, "_grad_events", None) is not None and self.model._grad_events[0] is self._overlap["keep"][0]:
                 self.model._grad_events = None
@@ -345,7 +361,13 @@ class TrainEngine:
                                                c.max_neg, c._pos_keep, c._neg_keep, c._next_seed())
         if self._native is not None:         # (bench.py measures a step without the exchange: the C hook is simply not installed for it)
             m._grad_callback = None if self.skip_allreduce else C.cast(lib().tf_comm_allreduce_hook, C.c_void_p)
-        gflat = m._run_backward(x, grad, persistent=True)
+            self._native["plan"].issued, self._native["plan"].rc = 0, 0       # a step that raised half-way must not poison the next one
+        self._works, self._cb_error = [], None
+        try:
+            gflat = m._run_backward(x, grad, persistent=True)
+        except BaseException:
+            self._drain_exchange()               # collectives already queued by the hooks are joined before the error travels on
+            raise
         scale = 1.0
         reduce = parallel.is_distributed() and not self.skip_allreduce
         if reduce:

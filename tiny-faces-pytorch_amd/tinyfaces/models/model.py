@@ -120,6 +120,8 @@ class DetectionModel(nn.Module):
         self._session_depth = 0          # constant_weights() nesting
         self._ready_key = None           # (workspace ptr, dtype, table key) whose packed eval weights sit in the workspace
         self._lanes = []                 # forward_levels: extra (workspace, HIP stream, ready key) triples beside the model's own
+        # load_state_dict(assign=True) re-points parameters without _apply: the pointer tables are rebuilt on the next call
+        self.register_load_state_dict_post_hook(lambda module, incompatible: setattr(module, "_table_key", None))
         if isinstance(pretrained_weights, (str, os.PathLike)):           # no network here: a local file only
             sd = torch.load(pretrained_weights, map_location="cpu", weights_only=True)
             sd = sd.get("model", sd)
@@ -264,7 +266,12 @@ class DetectionModel(nn.Module):
         (~0.4 ms of Python): an owner that pins the storages (TrainEngine after flatten_parameters) sets `_tables_frozen` and the walk is
         skipped until something moves the module (`_apply`, flatten_parameters)."""
         if getattr(self, "_tables_frozen", False) and self._table_key is not None:
-            return
+            # frozen: three sentinels (first / a middle / the last tensor of the table) instead of the walk -- replacing a Parameter, a BN
+            # buffer or `.data` without going through _apply still moves at least the storage it touched; load_state_dict(assign=True)
+            # is caught by the post-hook registered in __init__ (ADVICE r4)
+            sent = self._sentinels
+            if all(t.data_ptr() == self._table_key[i] for i, t in sent()):
+                return
         named = self._named_tensors()
         n = lib().tf_detnet_num_params()
         names = self._names if getattr(self, "_names", None) and len(self._names) == n else [lib().tf_detnet_param_name(i).decode() for i in range(n)]
@@ -295,6 +302,14 @@ class DetectionModel(nn.Module):
         self._grad_numels = [pd[k].numel() for k in self._grad_names]
         self._bn_modules = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
         self._table_key = key
+        picks = (0, n // 2, n - 1)
+        self._sentinels = lambda names=names, picks=picks: [(i, self._named_tensor(names[i])) for i in picks]
+
+    def _named_tensor(self, dotted):
+        obj = self
+        for part in dotted.split("."):
+            obj = getattr(obj, part)
+        return obj
 
     def flatten_parameters(self):
         """Re-point every parameter the executor trains into ONE flat fp32 buffer (executor order, each

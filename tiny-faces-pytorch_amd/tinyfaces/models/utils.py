@@ -79,10 +79,9 @@ def balance_sampling(label_cls, pos_fraction, sample_size=256):
     """utils.py:103-139: at most sample_size * pos_fraction positive and the matching number of negative labels survive, the rest become 0
     ("ignore").  Mutates and returns `label_cls` (numpy array of {-1, 0, 1}, any shape)."""
     pos_keep, neg_keep = balance_sampling_keep(label_cls, pos_fraction, sample_size)
-    flat = label_cls.reshape(-1)
-    if flat.base is None and flat is not label_cls:
-        raise ValueError("balance_sampling: label_cls must be C-contiguous (it is edited in place)")
+    flat = label_cls.reshape(-1)             # logical C order (a copy for a non-contiguous array: only READ here)
     pos_at, neg_at = np.flatnonzero(flat == 1), np.flatnonzero(flat == -1)
-    flat[pos_at[pos_keep == 0]] = 0
-    flat[neg_at[neg_keep == 0]] = 0
+    # index-based assignment like the reference (utils.py:126-137): edits `label_cls` itself whatever its memory layout
+    label_cls[np.unravel_index(pos_at[pos_keep == 0], label_cls.shape)] = 0
+    label_cls[np.unravel_index(neg_at[neg_keep == 0], label_cls.shape)] = 0
     return label_cls
