@@ -307,9 +307,13 @@ def test_bf16_trains_like_fp32():
     w = lambda c: c.reshape(-1, 10).mean(1)                      # 15 windows of 10 steps (the sampling draws make single steps noisy)
     f, b = w(curves["fp32"]), w(curves["bf16"])
     band = float(np.abs(b - f).max() / f[0])
-    rel = float(np.abs(b / f - 1).max())
-    report("bf16_trains_like_fp32", fp32_first=f[0], fp32_last=f[-1], bf16_first=b[0], bf16_last=b[-1], fall_fp32=f[0] / f[-1], fall_bf16=b[0] / b[-1],
-           band_of_first=band, max_rel_window=rel)
+    live = f > 0.12 * f[0]                                       # the descent proper.  Below ~10 % of the start the run is a chaotic tail on 4 images
+    rel = float(np.abs(b[live] / f[live] - 1).max())             # (lr 1e-3, momentum 0.9, fresh sampling draws every step) until the OHEM threshold of
+                                                                 # loss.py:62 switches every converged example off and both reach 0.0: measured windows
+                                                                 # fp32 517 112 70 58 47 17 1.1 .04 .02 0 ...   bf16 520 110 68 52 69 31 3.6 1.4 .24 .004 .04 0 ...
+    fall_f, fall_b = f[0] / max(f[-1], 1e-9), b[0] / max(b[-1], 1e-9)
+    report("bf16_trains_like_fp32", fp32_windows=[round(float(v), 3) for v in f], bf16_windows=[round(float(v), 3) for v in b], fall_fp32=min(fall_f, 1e9),
+           fall_bf16=min(fall_b, 1e9), band_of_first=band, live_windows=int(live.sum()), max_rel_live_window=rel)
     assert np.isfinite(curves["fp32"]).all() and np.isfinite(curves["bf16"]).all()
-    assert f[0] / f[-1] >= 2.0 and b[0] / b[-1] >= 2.0, (f, b)
-    assert band < 0.10 and rel < 0.25, (band, rel, f, b)
+    assert fall_f >= 20.0 and fall_b >= 20.0, (f, b)
+    assert band < 0.08 and rel < 0.15, (band, rel, f, b)        # measured 0.044 / 0.033

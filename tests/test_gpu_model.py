@@ -601,6 +601,8 @@ def test_refused_wgrad_group_falls_back_into_zeroed_gradients(tmp_path, refuse):
     ratio = float(np.linalg.norm(b) / np.linalg.norm(a))
     cos_all = float(np.dot(g1, g2) / (np.linalg.norm(g1) * np.linalg.norm(g2)))
     report(f"refused_group[refuse={refuse}]", cos_layer3_conv2=cos, norm_ratio=ratio, cos_flat=cos_all)
-    # the same function twice: equal up to the run-to-run order of the fp32 atomics (BN statistic rows, split-K sums)
-    assert 0.98 < ratio < 1.02 and cos > 0.999, (ratio, cos)
+    # the same function twice.  Not bit-equal: the fp32 atomics of the BN statistic rows land in another order, and on this 2-image
+    # fixture (batch statistics over <= 512 pixels) that flips bf16 roundings all the way up -- a layer-3 3x3 gradient repeats itself to
+    # cosine 0.978 with or without the refusal.  A gradient accumulated onto the previous step's would have norm ratio 2.
+    assert 0.97 < ratio < 1.03 and cos > 0.95, (ratio, cos)
     assert cos_all > 0.999
