@@ -335,6 +335,14 @@ int tf_bn_bwd_apply_fused(int dtype, const void* g, const void* y /* NULL: no Re
  * under autograd, tinyfaces/trainer.py:86).  bf16, 1x1 / stride 1, Cin a multiple of 64 in [128, 1024], Cout a multiple of 128 with
  * ldy == Cout; TF_ERR_UNSUPPORTED otherwise (run the two calls). */
 int tf_conv2d_bnbwd(const tf_conv_args* a, const tf_bn_bwd_desc* bn, const void* x2, void* applied_out, int rows, float count, void* stream);
+/* r5: tf_bn_add_relu_fused + the pointwise tf_conv2d that consumes its output, in ONE launch (csrc/conv_pwx.hip): the conv's pixel operand
+ * is y = relu(bn(a->x) + (bn_res(res) | res)) -- a->x = the raw output of the previous bottleneck's conv3, `bn` its bn3 (batch statistics
+ * finalized in-kernel: scale / shift / mean / invstd published, running statistics updated, exactly like tf_bn_add_relu_fused), res = the
+ * residual (bn_res != NULL: the raw downsample conv output and its BatchNorm) -- and y is also written to y_out [M][Cin]: the block output.
+ * Replaces bn3 -> += identity -> relu of a torchvision Bottleneck followed by conv1 of the NEXT one (tinyfaces/models/model.py:90-101).
+ * Same shape limits and error codes as tf_conv2d_bnbwd. */
+int tf_conv2d_bnfwd(const tf_conv_args* a, const tf_bn_fwd_desc* bn, const void* res, const tf_bn_fwd_desc* bn_res, void* y_out, int rows, float count,
+                    float eps, float momentum, void* stream);
 /* score4_upsample (frozen bilinear ConvTranspose2d k4 s2 p1, model.py:34-40,107) + crop (:110-124)
  * + add (:126); wup_diag [C][4][4] = the channel diagonal of the (C,C,4,4) weight; output NCHW fp32. */
 int tf_upsample_add_crop(int dtype, const void* s3, const void* s4, const float* wup_diag, int B, int C, int ldc,

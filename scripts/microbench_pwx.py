@@ -46,3 +46,26 @@ for name, (N, H, W, K, Co) in (("layer3", (12, 32, 32, 1024, 256)), ("layer2", (
     plain13 = lambda: lib().tf_conv2d(C.byref(a0), stream())
     plain60 = lambda: lib().tf_conv2d(C.byref(a2), stream())
     print(f"{name} M={M} K={K} N={Co}: apply+dgrad {timeit(pair):6.1f} us | conv_pwx fused {timeit(fused):6.1f} us | dgrad alone conv_dma {timeit(plain13):6.1f} | conv_pwx plain {timeit(plain60):6.1f}", flush=True)
+    # r5: the forward pair  tf_bn_add_relu_fused + conv1 (conv_dma)  against tf_conv2d_bnfwd (same shapes: K = 4 planes -> planes)
+    fstat = torch.randn(rows * 2 + 1, K, device="cuda").abs() * 100
+    vec = [torch.zeros(K, device="cuda") for _ in range(4)] + [torch.zeros(K, device="cuda"), torch.ones(K, device="cuda")]
+    fd = _hip.BnFwdDesc()
+    fd.stat, fd.gamma, fd.beta = ptr(fstat), ptr(gamma), ptr(mean)
+    fd.scale, fd.shift, fd.mean, fd.invstd, fd.running_mean, fd.running_var = [ptr(v) for v in vec]
+    wf = ops.pack_weight(torch.randn(Co, K, 1, 1, device="cuda") / K ** 0.5, dt)
+    yact = torch.empty_like(gz)
+    def fargs(x, tile=0):
+        a = _hip.ConvArgs()
+        a.dtype, a.mode = _hip.TF_BF16, 0
+        a.N, a.H, a.W, a.Cin, a.OH, a.OW, a.Cout, a.KH, a.KW, a.stride, a.pad = N, H, W, K, H, W, Co, 1, 1, 1, 0
+        a.ldy, a.epi, a.tile = Co, _hip.EPI_STATS, tile
+        st = torch.zeros(16, 2, Co, device="cuda")
+        a.x, a.w, a.y, a.stat_out = ptr(x), ptr(wf), ptr(y), ptr(st)
+        a._keep = st
+        return a
+    f0, f1 = fargs(yact), fargs(gz)
+    def fpair():
+        lib().tf_bn_add_relu_fused(_hip.TF_BF16, ptr(gz), C.byref(fd), ptr(x2), None, rows, M, K, float(M), 1e-5, 0.1, ptr(yact), stream())
+        lib().tf_conv2d(C.byref(f0), stream())
+    ffused = lambda: lib().tf_conv2d_bnfwd(C.byref(f1), C.byref(fd), ptr(x2), None, ptr(yact), rows, float(M), 1e-5, 0.1, stream())
+    print(f"{name} forward: bn_add_relu+conv1 {timeit(fpair):6.1f} us | tf_conv2d_bnfwd {timeit(ffused):6.1f} us | conv1 alone {timeit(lambda: lib().tf_conv2d(C.byref(f0), stream())):6.1f}", flush=True)

@@ -1161,3 +1161,91 @@ def test_conv_bn_relu_forward_prologue_in_lds(case):
     d = _hip.BnFwdDesc()
     a.x, a.w, a.y, a.bnf = ptr(xx), ptr(ww), ptr(yy), C.addressof(d)
     assert lib().tf_conv2d(C.byref(a), stream()) == -3                # TF_ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("case", [(2, 9, 11, 256, 128, False, True), (1, 16, 16, 512, 256, True, False), (3, 7, 13, 1024, 256, False, True),
+                                  (2, 8, 8, 128, 128, True, True), (12, 32, 32, 1024, 256, False, True)])
+def test_conv_pwx_bn_forward_prologue(case):
+    """r5, csrc/conv_pwx.hip: tf_conv2d_bnfwd == tf_bn_add_relu_fused followed by the pointwise conv (conv_dma) on its output, in ONE launch:
+    the side output y = relu(bn(x) + (bn_res(res) | res)) (bf16), the conv output with its statistic rows (STATS, with and without the
+    shift row), and everything tf_bn_add_relu_fused publishes for BOTH BatchNorms (scale / shift / mean / invstd, running statistics).
+    K = 128 has fewer stages (2) than the pixel ring is deep; M is not a multiple of the 64-pixel tile in three cases; the last case is
+    the layer-3 shape of the bs = 12 step (192 blocks, 16 stages)."""
+    import ctypes as C
+    from tinyfaces import _hip, ops
+    from tinyfaces._hip import lib, ptr, stream
+    N, H, W, K, Co, ds, shifted = case
+    M = N * H * W
+    g = _g(sum(case[:5]) + 3)
+    dt = torch.bfloat16
+    x = (torch.randn(N, H, W, K, generator=g) * 1.3 + 0.4).to(dt).cuda()
+    res = (torch.randn(N, H, W, K, generator=g) * 0.9 - 0.2).to(dt).cuda()
+    w0 = torch.randn(Co, K, 1, 1, generator=g) / K ** 0.5
+    w = ops.pack_weight(w0.cuda(), dt)
+    rows = lib().tf_get_stat_rows()
+
+    def stat_of(t, sh):
+        st = torch.zeros(rows * 2 + 1, K, device="cuda")
+        ts = t.float().view(M, K)
+        for r in range(rows):
+            part = ts[r::rows] - sh
+            st[2 * r], st[2 * r + 1] = part.sum(0), (part * part).sum(0)
+        st[rows * 2] = sh
+        return st
+    sh1 = (torch.randn(K, generator=g) * 0.2 + 0.4).cuda() if shifted else torch.zeros(K, device="cuda")
+    sh2 = (torch.randn(K, generator=g) * 0.2 - 0.2).cuda() if shifted else torch.zeros(K, device="cuda")
+    stat1, stat2 = stat_of(x, sh1), stat_of(res, sh2)
+    gam = [(torch.rand(K, generator=g) + 0.5).cuda() for _ in range(2)]
+    bet = [(torch.randn(K, generator=g) * 0.3).cuda() for _ in range(2)]
+    oshift = (torch.randn(Co, generator=g) * 0.1).cuda()            # the shift of the conv's OWN statistic sums (its BN's running mean)
+
+    def run(fused):
+        vecs = [[torch.zeros(K, device="cuda") for _ in range(4)] + [torch.full((K,), 0.25, device="cuda"), torch.full((K,), 2.0, device="cuda")] for _ in range(2)]
+        descs = []
+        for i, (st, vec) in enumerate(zip((stat1, stat2), vecs)):
+            d = _hip.BnFwdDesc()
+            d.stat, d.gamma, d.beta = ptr(st), ptr(gam[i]), ptr(bet[i])
+            d.scale, d.shift, d.mean, d.invstd, d.running_mean, d.running_var = [ptr(v) for v in vec]
+            if shifted:
+                d.stat_shift = st[rows * 2].data_ptr()
+            descs.append(d)
+        yact = torch.zeros(N, H, W, K, dtype=dt, device="cuda")
+        y = torch.zeros(N, H, W, Co, dtype=dt, device="cuda")
+        a = _hip.ConvArgs()
+        a.dtype, a.mode = _hip.TF_BF16, 0
+        a.N, a.H, a.W, a.Cin, a.OH, a.OW, a.Cout, a.KH, a.KW, a.stride, a.pad = N, H, W, K, H, W, Co, 1, 1, 1, 0
+        a.ldy, a.epi, a.tile = Co, _hip.EPI_STATS, (0 if fused else 13)
+        srows = min(rows, (M + 63) // 64) if fused else lib().tf_conv_mtiles(C.byref(a))
+        so = torch.zeros(srows, 2, Co, device="cuda")
+        so_shift = torch.zeros(Co, device="cuda")
+        a.w, a.y, a.stat_out = ptr(w), ptr(y), ptr(so)
+        if shifted:
+            a.stat_shift, a.stat_shift_out = ptr(oshift), ptr(so_shift)
+        bn_r = C.byref(descs[1]) if ds else None
+        if fused:
+            a.x = ptr(x)
+            assert lib().tf_conv2d_bnfwd(C.byref(a), C.byref(descs[0]), ptr(res), bn_r, ptr(yact), rows, float(M), 1e-5, 0.1, stream()) == 0
+        else:
+            assert lib().tf_bn_add_relu_fused(_hip.TF_BF16, ptr(x), C.byref(descs[0]), ptr(res), bn_r, rows, M, K, float(M), 1e-5, 0.1, ptr(yact), stream()) == 0
+            a.x = ptr(yact)
+            assert lib().tf_conv2d(C.byref(a), stream()) == 0
+        torch.cuda.synchronize()
+        return yact, y, so.sum(0), so_shift, vecs[0], (vecs[1] if ds else [])
+
+    two, one = run(False), run(True)
+    d_act = err(one[0].float().cpu(), two[0].float().cpu())
+    d_y = err(one[1].float().cpu(), two[1].float().cpu())
+    d_s = float((one[2] - two[2]).abs().max() / (two[2].abs().max() + 1e-30))
+    report(f"conv_pwx_bnfwd[{case}]", act_rel=d_act[2], y_rel=d_y[2], stat_rel=d_s)
+    assert d_act[2] < 8e-3                       # at most one bf16 rounding apart (the two kernels may contract the FMAs differently)
+    assert float((one[0] != two[0]).float().mean()) < 2e-2
+    assert d_y[2] < 2e-2 and d_s < 2e-2
+    assert torch.equal(one[3], two[3])
+    for nm, p, q in zip(["scale", "shift", "mean", "invstd", "running_mean", "running_var"] * 2, two[4] + two[5], one[4] + one[5]):
+        assert torch.equal(p, q), (nm, float((p - q).abs().max()))
+    # independent check: the activation against torch's BatchNorm arithmetic, the conv against the kernel's own activation
+    xs, rs = x.float().view(M, K), res.float().view(M, K)
+    bn = lambda t, i: (t - t.mean(0)) / torch.sqrt(t.var(0, unbiased=False) + 1e-5) * gam[i] + bet[i]
+    ref = torch.relu(bn(xs, 0) + (bn(rs, 1) if ds else rs))
+    assert err(one[0].float().view(M, K).cpu(), ref.cpu())[0] < 4e-2
+    assert err(one[1].float().view(M, Co).cpu(), one[0].float().view(M, K).cpu() @ q(w0, dt)[:, :, 0, 0].t())[2] < 6e-3

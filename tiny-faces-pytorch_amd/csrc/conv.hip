@@ -2,7 +2,7 @@
 // Replaces the nn.Conv2d / BatchNorm2d / ReLU / residual-add chain of tinyfaces/models/model.py:90-106 and the torchvision Bottleneck
 // (see tinyfaces_hip.h).  GEMM view:  D[channel][pixel] = sum_k W[channel][k] * X[pixel][k],  k = (tap, cin).
 // The kernels: conv_dma_impl.h (LDS-DMA implicit GEMM: every conv but ...), conv3x3h.hip (... the 3x3 / stride 1 convs with >= 256 input
-// channels), conv_pwx.hip (BN-backward apply fused into a pointwise data gradient).  r4: the register-staged kernel of round 1
+// channels), conv_pwx.hip (a BatchNorm pass fused into the operand path of the pointwise conv / data gradient that consumes it).  r4: the register-staged kernel of round 1
 // (conv_igemm, tile codes 1-3, the only one with a producer-BN prologue) was dead on the executor's path since round 1's LDS-DMA
 // kernel and was removed: tf_conv2d returns TF_ERR_UNSUPPORTED for tile codes < 10 and for pro_scale (tf_conv2d_wgrad keeps its prologue).
 #include <cstdlib>
@@ -16,6 +16,8 @@ int tf_conv3x3h_launch(const tf_conv_args* a, hipStream_t stream);
 bool tf_conv_pwx_applicable(const tf_conv_args* a);                                            // conv_pwx.hip
 int tf_conv_pwx_mtiles(const tf_conv_args* a);
 int tf_conv_pwx_launch(const tf_conv_args* a, const tf_bn_bwd_desc* pro, const void* pro_x2, void* pro_out, int pro_rows, float pro_count, hipStream_t stream);
+int tf_conv_pwx_launch_fwd(const tf_conv_args* a, const tf_bn_fwd_desc* bn, const void* res, const tf_bn_fwd_desc* bn_res, void* y_out, int rows, float count,
+                           float eps, float momentum, hipStream_t stream);
 
 namespace {
 
@@ -112,4 +114,23 @@ extern "C" int tf_conv2d_bnbwd(const tf_conv_args* a, const tf_bn_bwd_desc* bn, 
   if ((a->epi & TF_EPI_STATS3) && !a->aux3) return TF_ERR_ARG;
   if (rows < 1 || rows > TF_STAT_ROWS) return TF_ERR_ARG;
   return tf_conv_pwx_launch(a, bn, x2, applied_out, rows, count, (hipStream_t)stream_);
+}
+
+// r5: tf_bn_add_relu_fused + the pointwise tf_conv2d that consumes its output (conv1 of the NEXT bottleneck), in ONE launch: the conv's pixel
+// operand is y = relu(bn(a->x) + (bn_res(res) | res)) with the batch statistics finalized in-kernel; y also goes to y_out (the block output:
+// residual of the next block, operand of conv1's weight gradient, ReLU mask of the backward pass).  conv_pwx.hip; TF_ERR_UNSUPPORTED for
+// shapes it does not take (the caller runs the two kernels).
+extern "C" int tf_conv2d_bnfwd(const tf_conv_args* a, const tf_bn_fwd_desc* bn, const void* res, const tf_bn_fwd_desc* bn_res, void* y_out, int rows,
+                               float count, float eps, float momentum, void* stream_) {
+  if (!a || !a->x || !a->w || !a->y || !bn || !res || !y_out) return TF_ERR_ARG;
+  if (!bn->stat || !bn->gamma || !bn->beta || !bn->scale || !bn->shift || !bn->mean || !bn->invstd) return TF_ERR_ARG;
+  if (bn_res && (!bn_res->stat || !bn_res->gamma || !bn_res->beta || !bn_res->scale || !bn_res->shift || !bn_res->mean || !bn_res->invstd)) return TF_ERR_ARG;
+  if ((a->epi & (TF_EPI_STATS | TF_EPI_STATS2 | TF_EPI_STATS3)) && !a->stat_out) return TF_ERR_ARG;
+  if ((a->epi & (TF_EPI_RES | TF_EPI_MASK | TF_EPI_STATS2)) && !a->aux) return TF_ERR_ARG;
+  if ((a->epi & TF_EPI_AFFINE) && (!a->epi_scale || !a->epi_shift)) return TF_ERR_ARG;
+  if ((a->epi & TF_EPI_MASK) && (!a->mask_scale || !a->mask_shift)) return TF_ERR_ARG;
+  if ((a->epi & (TF_EPI_MASK2 | TF_EPI_JOIN)) && !a->aux2) return TF_ERR_ARG;
+  if ((a->epi & (TF_EPI_STATS3 | TF_EPI_JOIN)) && !a->aux3) return TF_ERR_ARG;
+  if (rows < 1 || rows > TF_STAT_ROWS) return TF_ERR_ARG;
+  return tf_conv_pwx_launch_fwd(a, bn, res, bn_res, y_out, rows, count, eps, momentum, (hipStream_t)stream_);
 }

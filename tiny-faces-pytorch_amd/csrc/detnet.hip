@@ -57,6 +57,7 @@ int tf_upsample_add_crop(int, const void*, const void*, const float*, int, int, 
 int tf_upsample_add_crop_bwd(int, const float*, const float*, int, int, int, int, int, int, int, void*, void*, void*);
 int tf_reduce_partials(const float*, int, int, int, int, int, float*, int, void*);
 int tf_conv2d_bnbwd(const tf_conv_args*, const tf_bn_bwd_desc*, const void*, void*, int, float, void*);
+int tf_conv2d_bnfwd(const tf_conv_args*, const tf_bn_fwd_desc*, const void*, const tf_bn_fwd_desc*, void*, int, float, float, float, void*);
 int tf_conv2d_wgrad_group(const tf_wgrad_args*, int, void*);
 }
 
@@ -679,6 +680,7 @@ extern "C" int tf_detnet_forward_ctx(tf_detnet_ctx* xctx, int single_stream, int
 
   // ---- bottlenecks
   const void* yin = P.pool;
+  bool tail_deferred = false;             // the previous bottleneck left c3 raw: this one's conv1 produces y on its way in
   for (size_t i = 0; i < A.blocks.size(); ++i) {
     const Block& B = A.blocks[i];
     Plan::Blk& b = P.blk[i];
@@ -689,7 +691,17 @@ extern "C" int tf_detnet_forward_ctx(tf_detnet_ctx* xctx, int single_stream, int
     conv_fill(a, dtype, 0, N, b.Hin, b.Win, B.cin, b.Hin, b.Win, pl, 1, 1, 0, pl, yin, b.w1, b.c1);
     if (tr) { a.epi = TF_EPI_STATS; a.stat_out = fused ? b.b1.fst : P.partial; stat_shift(a, c, B.c1, b.b1, fused); }
     else { bn_forward(c, B.c1, pl, b.b1, false, nullptr, nullptr, 0, eps, mom); a.epi = TF_EPI_AFFINE | TF_EPI_RELU; a.epi_scale = b.b1.scale; a.epi_shift = b.b1.shift; }
-    c.chk(tf_conv2d(&a, c.stream));
+    if (tail_deferred) {
+      // r5: the PREVIOUS bottleneck's  y = relu(bn3(c3) + residual)  rides on this conv's operand path (tf_conv2d_bnfwd, conv_pwx.hip): the
+      // pixel stages are transformed once in LDS on their way to the MFMAs and y (= yin: three more readers) is the launch's side output
+      const Block& Bp = A.blocks[i - 1];
+      Plan::Blk& bp = P.blk[i - 1];
+      const tf_bn_fwd_desc d3 = fwd_desc(c, Bp.c3, bp.b3);
+      tf_bn_fwd_desc dd; if (Bp.has_ds) dd = fwd_desc(c, Bp.ds, bp.bd);
+      a.x = bp.c3;
+      c.chk(tf_conv2d_bnfwd(&a, &d3, Bp.has_ds ? bp.d : (i >= 2 ? P.blk[i - 2].y : P.pool), Bp.has_ds ? &dd : nullptr, bp.y, srows, (float)Min, eps, mom, c.stream));
+      tail_deferred = false;
+    } else c.chk(tf_conv2d(&a, c.stream));
     // a1 = relu(bn1(c1)), materialised on purpose: every consumer (conv2, its weight gradient) uses the LDS-DMA pipeline
     if (fused) {
       const tf_bn_fwd_desc d = fwd_desc(c, B.c1, b.b1);
@@ -735,7 +747,16 @@ extern "C" int tf_detnet_forward_ctx(tf_detnet_ctx* xctx, int single_stream, int
       a.epi = TF_EPI_AFFINE | TF_EPI_RES | TF_EPI_RELU; a.epi_scale = b.b3.scale; a.epi_shift = b.b3.shift; a.aux = B.has_ds ? b.d : yin;
     }
     c.chk(tf_conv2d(&a, c.stream));
-    if (fused) {
+    // r5: the block's tail (bn3 + residual + ReLU) is NOT launched when the next bottleneck's conv1 can apply it on its operand path
+    // (bf16 training, conv1 with 128 / 256 output channels and 128 ... 1024 input channels: layers 2 and 3; TINYFACES_PWX_FWD_OFF=1: never)
+    static const bool pwx_fwd_off = getenv("TINYFACES_PWX_FWD_OFF") != nullptr;
+    if (fused && !pwx_fwd_off && dtype == TF_BF16 && i + 1 < A.blocks.size()) {
+      const Block& Bn = A.blocks[i + 1];
+      tail_deferred = Bn.cin == c4 && Bn.planes % 128 == 0 && Bn.cin % 64 == 0 && Bn.cin >= 128 && Bn.cin <= 1024;
+    }
+    if (tail_deferred) {
+      // nothing here
+    } else if (fused) {
       const tf_bn_fwd_desc d3 = fwd_desc(c, B.c3, b.b3);
       tf_bn_fwd_desc dd; if (B.has_ds) dd = fwd_desc(c, B.ds, b.bd);
       c.chk(tf_bn_add_relu_fused(dtype, b.c3, &d3, B.has_ds ? b.d : yin, B.has_ds ? &dd : nullptr, srows, Mout, c4, (float)Mout, eps, mom, b.y,
@@ -1045,7 +1066,9 @@ extern "C" int tf_detnet_backward_ctx(tf_detnet_ctx* xctx, const tf_detnet_hooks
     //     K = 1024 -> 256) 31.6 against 29.8 -- 192 one-per-CU blocks pay the coefficient table and the register-staged operand where the
     //     elementwise kernel has thousands of threads in flight.  So: the identity bottlenecks of layer 2 only (TINYFACES_PWX_ALL=1: every
     //     eligible one, TINYFACES_PWX_OFF=1: none; the step is the same within noise either way, 1160 img/s).
-    static const bool pwx_off = getenv("TINYFACES_PWX_OFF") != nullptr, pwx_all = getenv("TINYFACES_PWX_ALL") != nullptr;
+    // r5: with the deep pixel ring of the rewritten kernel the fused form is used for EVERY identity bottleneck of layers 2 and 3
+    // (TINYFACES_PWX_L2ONLY=1: the round-4 choice, layer 2 only).
+    static const bool pwx_off = getenv("TINYFACES_PWX_OFF") != nullptr, pwx_all = getenv("TINYFACES_PWX_L2ONLY") == nullptr;
     bool fused24 = false;
     if (fused && !pwx_off && dtype == TF_BF16 && !B.has_ds && pl % 128 == 0 && (pl == 128 || pwx_all)) {
       const tf_bn_bwd_desc d = bwd_desc(c, B.c3, b.b3, b.b3.bst, nk, 1);

@@ -125,6 +125,7 @@ _SIGNATURES = {
     "tf_bn_add_relu_fused": (i32, [i32, vp, C.POINTER(BnFwdDesc), vp, C.POINTER(BnFwdDesc), i32, i64, i32, f32, f32, f32, vp, vp]),
     "tf_bn_bwd_apply_fused": (i32, [i32, vp, vp, vp, C.POINTER(BnBwdDesc), i32, i64, i32, f32, vp, vp]),
     "tf_conv2d_bnbwd": (i32, [C.POINTER(ConvArgs), C.POINTER(BnBwdDesc), vp, vp, i32, f32, vp]),
+    "tf_conv2d_bnfwd": (i32, [C.POINTER(ConvArgs), C.POINTER(BnFwdDesc), vp, C.POINTER(BnFwdDesc), vp, i32, f32, f32, f32, vp]),
     "tf_upsample_add_crop": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
     "tf_upsample_add_crop_bwd": (i32, [i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
     "tf_reduce_partials": (i32, [vp, i32, i32, i32, i32, i32, vp, i32, vp]),
