@@ -68,3 +68,8 @@ for q, rs in byq.items():
 print("blit dispatches of the step (main queue?, kind, grid, previous kernel, next kernel): count")
 for k, v in sorted(blit.items(), key=lambda kv: -kv[1])[:40]:
     print(f"    {str(k[0]):5s} {k[1]:18s} grid={k[2]:6d} {k[3]:34s} -> {k[4]:34s} x{v}")
+# r5: the whole step, kernel by kernel (queue, start, duration, grid, workgroup, name): the single-launch outliers live here
+print("sequence (queue | start us | dur us | grid x wg | kernel):")
+for r in step:
+    full = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"]).split("(")[0].replace("void ", "")[:90]
+    print(f"  {'M' if r['q'] == mainq else 's'} {(r['s']-t0)/1e3:8.1f} {(r['e']-r['s'])/1e3:7.1f} {int(r.get('Grid_Size_X', r.get('Grid_Size', 0)) or 0):8d}x{int(r.get('Workgroup_Size_X', r.get('Workgroup_Size', 0)) or 0):4d} {full}")

@@ -1241,8 +1241,8 @@ def test_conv_pwx_bn_forward_prologue(case):
     assert float((one[0] != two[0]).float().mean()) < 2e-2
     assert d_y[2] < 2e-2 and d_s < 2e-2
     assert torch.equal(one[3], two[3])
-    for nm, p, q in zip(["scale", "shift", "mean", "invstd", "running_mean", "running_var"] * 2, two[4] + two[5], one[4] + one[5]):
-        assert torch.equal(p, q), (nm, float((p - q).abs().max()))
+    for nm, pa, pb in zip(["scale", "shift", "mean", "invstd", "running_mean", "running_var"] * 2, two[4] + two[5], one[4] + one[5]):
+        assert torch.equal(pa, pb), (nm, float((pa - pb).abs().max()))
     # independent check: the activation against torch's BatchNorm arithmetic, the conv against the kernel's own activation
     xs, rs = x.float().view(M, K), res.float().view(M, K)
     bn = lambda t, i: (t - t.mean(0)) / torch.sqrt(t.var(0, unbiased=False) + 1e-5) * gam[i] + bet[i]

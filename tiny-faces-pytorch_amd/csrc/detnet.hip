@@ -748,8 +748,10 @@ extern "C" int tf_detnet_forward_ctx(tf_detnet_ctx* xctx, int single_stream, int
     }
     c.chk(tf_conv2d(&a, c.stream));
     // r5: the block's tail (bn3 + residual + ReLU) is NOT launched when the next bottleneck's conv1 can apply it on its operand path
-    // (bf16 training, conv1 with 128 / 256 output channels and 128 ... 1024 input channels: layers 2 and 3; TINYFACES_PWX_FWD_OFF=1: never)
-    static const bool pwx_fwd_off = getenv("TINYFACES_PWX_FWD_OFF") != nullptr;
+    // (bf16 training, conv1 with 128 / 256 output channels and 128 ... 1024 input channels: layers 2 and 3).  OPT-IN (TINYFACES_PWX_FWD=1): measured
+    // r5, it LOSES -- alone 37.4 us against 29.1 for the two launches at layer 3, 45.5 against 40.7 at layer 2 (profiles/r05_conv_pwx.txt); in the
+    // step 1238-1240 img/s against 1277-1279 without it (same box).  DESIGN.md 7.
+    static const bool pwx_fwd_off = getenv("TINYFACES_PWX_FWD") == nullptr;
     if (fused && !pwx_fwd_off && dtype == TF_BF16 && i + 1 < A.blocks.size()) {
       const Block& Bn = A.blocks[i + 1];
       tail_deferred = Bn.cin == c4 && Bn.planes % 128 == 0 && Bn.cin % 64 == 0 && Bn.cin >= 128 && Bn.cin <= 1024;
@@ -1066,9 +1068,11 @@ extern "C" int tf_detnet_backward_ctx(tf_detnet_ctx* xctx, const tf_detnet_hooks
     //     K = 1024 -> 256) 31.6 against 29.8 -- 192 one-per-CU blocks pay the coefficient table and the register-staged operand where the
     //     elementwise kernel has thousands of threads in flight.  So: the identity bottlenecks of layer 2 only (TINYFACES_PWX_ALL=1: every
     //     eligible one, TINYFACES_PWX_OFF=1: none; the step is the same within noise either way, 1160 img/s).
-    // r5: with the deep pixel ring of the rewritten kernel the fused form is used for EVERY identity bottleneck of layers 2 and 3
-    // (TINYFACES_PWX_L2ONLY=1: the round-4 choice, layer 2 only).
-    static const bool pwx_off = getenv("TINYFACES_PWX_OFF") != nullptr, pwx_all = getenv("TINYFACES_PWX_L2ONLY") == nullptr;
+    // Measured r5 (profiles/r05_conv_pwx.txt): alone 27.8 us against 29.9 for the two launches at layer 3 but 46.8 against 40.9 at layer 2 (one block
+    // per CU with the deep rings); in the step: off 1287-1294, layer 2 only 1280-1287, layers 2 + 3 1277-1279 img/s.  So the fused form is
+    // OPT-IN now: TINYFACES_PWX_BWD=1 (layer 2) / TINYFACES_PWX_ALL=1 (layers 2 and 3).
+    static const bool pwx_all = getenv("TINYFACES_PWX_ALL") != nullptr;
+    static const bool pwx_off = getenv("TINYFACES_PWX_OFF") != nullptr || (getenv("TINYFACES_PWX_BWD") == nullptr && !pwx_all);
     bool fused24 = false;
     if (fused && !pwx_off && dtype == TF_BF16 && !B.has_ds && pl % 128 == 0 && (pl == 128 || pwx_all)) {
       const tf_bn_bwd_desc d = bwd_desc(c, B.c3, b.b3, b.b3.bst, nk, 1);

@@ -134,6 +134,39 @@ __global__ void __launch_bounds__(256) probe_kernel(char* buf, size_t window, in
   }
 }
 
+// kind 9 (r5): how fast can a block of a pixel-stationary GEMM STREAM its operand?  Every block owns 64 rows of a [rows][2048 B] matrix
+// (M x 1024 bf16: the layer-3 activations) and moves them into LDS by LDS-DMA in 8 KiB stages with DEPTH stages in flight; `seg` is the
+// run of contiguous bytes a stage takes from one row: 128 = the GEMM pattern (64 rows x one 64-deep k step), 512 / 2048 = fewer rows,
+// longer runs (2048: four whole rows per stage).  Same bytes, same requests per stage -- only their addresses differ.
+template <int DEPTH>
+__global__ void __launch_bounds__(256) stream_probe_kernel(const char* buf, int seg, float* sink) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int RB = 2048, ROWS = 64, STAGE = 8192, NST = ROWS * RB / STAGE;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const char* base = buf + (size_t)blockIdx.x * ROWS * RB;
+  const int ppr = seg / 16, rps = STAGE / seg, cgs = RB / seg;        // pieces per row run, rows per stage, column groups
+  auto issue = [&](int t) {
+    const int rg = t % (ROWS / rps), cg = t / (ROWS / rps);
+    char* dst = smem + (t % (DEPTH + 1)) * STAGE + wave * 1024;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int p = tid + 256 * u, r = p / ppr, c = p - r * ppr;
+      typedef __attribute__((address_space(3))) void lds_void;
+      typedef __attribute__((address_space(1))) const void glb_void;
+      __builtin_amdgcn_global_load_lds((glb_void*)(base + (size_t)(rg * rps + r) * RB + (size_t)(cg % cgs) * seg + c * 16), (lds_void*)(dst + u * 4096), 16, 0, 0);
+    }
+  };
+#pragma unroll
+  for (int t = 0; t < DEPTH; ++t) issue(t);
+  for (int t = 0; t < NST; ++t) {
+    if (t + DEPTH < NST) issue(t + DEPTH);
+    else { issue(0); }                                                  // keep the count uniform (re-reads a cached stage)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DEPTH) : "memory");
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (seg < 0) sink[0] = smem[tid];
+}
+
 template <int KIND>
 int launch(int blocks, int lds, char* buf, size_t window, int iters, hipStream_t s) {
   static bool attr = false;
@@ -160,6 +193,16 @@ extern "C" int tf_debug_probe(int kind, int blocks, int lds_bytes, void* buf, si
     case 4: return launch<4>(blocks, lds_bytes, b, window_bytes, iters, s);
     case 5: return launch<5>(blocks, lds_bytes, b, window_bytes, iters, s);
     case 6: return launch<6>(blocks, lds_bytes, b, 4096, iters, s);
+    case 9: {                                               // iters = seg | depth << 16; window >= blocks * 64 * 2048
+      const int seg = iters & 0xffff, depth = iters >> 16;
+      if ((seg != 128 && seg != 256 && seg != 512 && seg != 1024 && seg != 2048) || window_bytes < (size_t)blocks * 64 * 2048) return TF_ERR_ARG;
+      const size_t l = (size_t)(depth + 1) * 8192;
+      if (depth == 2) hipLaunchKernelGGL(stream_probe_kernel<2>, dim3(blocks), dim3(256), l, s, b, seg, reinterpret_cast<float*>(b));
+      else if (depth == 4) hipLaunchKernelGGL(stream_probe_kernel<4>, dim3(blocks), dim3(256), l, s, b, seg, reinterpret_cast<float*>(b));
+      else if (depth == 8) hipLaunchKernelGGL(stream_probe_kernel<8>, dim3(blocks), dim3(256), l, s, b, seg, reinterpret_cast<float*>(b));
+      else return TF_ERR_ARG;
+      return hipGetLastError() == hipSuccess ? TF_OK : TF_ERR_LAUNCH;
+    }
     case 7: case 8:
       if (blocks > 1024 || blocks % 8) return TF_ERR_ARG;   // every block must be resident at once (256 CUs x 4)
       if (hipMemsetAsync(b, 0, 4096, s) != hipSuccess) return TF_ERR_LAUNCH;
