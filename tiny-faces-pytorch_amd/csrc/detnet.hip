@@ -1034,8 +1034,15 @@ extern "C" int tf_detnet_backward_ctx(tf_detnet_ctx* xctx, const tf_detnet_hooks
       int rc = force_refuse ? TF_ERR_UNSUPPORTED : tf_conv2d_wgrad_group(pend_c3.data(), (int)pend_c3.size(), c.gstream());
       if (rc == TF_ERR_UNSUPPORTED) fallback(pend_c3);
       else c.chk(rc);
-      rc = force_refuse ? TF_ERR_UNSUPPORTED : tf_conv2d_wgrad_group(pend_pw.data(), (int)pend_pw.size(), c.gstream());
-      if (rc == TF_ERR_UNSUPPORTED) fallback(pend_pw);
+      // r5: the pointwise group in `pw_split` launches (default 1).  A group of eight bottlenecks is 256 tiles = one block on EVERY CU for
+      // ~150 us, and beside it the chain's kernels crawl (profiles/r05_step_timeline.txt: the data gradient that normally takes 22 us
+      // takes 118-130 us while the group runs); split, each launch leaves CUs to the chain.  TINYFACES_WGRADG_SPLIT=n.
+      static const int pw_split = [] { const char* e = getenv("TINYFACES_WGRADG_SPLIT"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : v; }();
+      const int npw = (int)pend_pw.size(), per = (npw + pw_split - 1) / pw_split;
+      rc = TF_OK;
+      for (int at = 0; at < npw && rc == TF_OK; at += per)
+        rc = force_refuse ? TF_ERR_UNSUPPORTED : tf_conv2d_wgrad_group(pend_pw.data() + at, npw - at < per ? npw - at : per, c.gstream());
+      if (rc == TF_ERR_UNSUPPORTED) fallback(pend_pw);        // (the first launch already refuses: all problems of a group have the same kind of shape)
       else c.chk(rc);
     }
     // a gradient-ready event of a grouped block promises "every gradient of the blocks >= it, and of the heads": the heads and layer3.x
@@ -1222,6 +1229,8 @@ extern "C" int tf_detnet_backward_ctx(tf_detnet_ctx* xctx, const tf_detnet_hooks
       c.chk(tf_stem_wgrad(dtype, x, N, H, W, gz, stem_apply_fused ? P.cstem : nullptr, P.bn_stem.cA, P.bn_stem.cB, P.bn_stem.cD, c.G(A.stem.w), c.wstream()));
     } else wgrad(c, s, 64, 1, 1, M1, 1, M1, P.col, kStemK, gz, 64, nullptr, 147, 1, 147);
   }
+  // (r5, measured and removed: returning WITHOUT joining this last kernel and running the SGD update of every other parameter beside it --
+  //  1282.2 / 1284.0 against 1282.1 / 1281.2 img/s joined: both are HBM-bound, side by side they take as long as back to back)
   c.wait_on_main(c.mark_side());           // join: the caller's stream sees every weight gradient
   if (c.gside) c.wait_on_main(c.mark(c.gside));
   record_grad_events(hooks, -1, c.stream, c.rc);
