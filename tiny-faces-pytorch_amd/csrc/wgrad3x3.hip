@@ -12,7 +12,7 @@
 //     16 KiB of LDS-DMA per 9 x 262 144 MACs instead of per 262 144;
 //   * X lives in a 512-row circular LDS image (64 KiB): a stage adds 64 new rows, the (W+2)+1 rows of halo on either side are
 //     already there, and every tap reads its fragments with ds_read_b64_tr_b16 from rows shifted by its constant;
-//   * 8 waves per block (r5: 4 ci groups x the 2 k-steps of a stage, every wave all 64 co; r2-r4: 2 x 4 over the tile), two per SIMD, so that one wave's fragment
+//   * 8 waves per block (2 x 4 over the 64 x 64 output tile: 32 co x 16 ci each), two per SIMD, so that one wave's fragment
 //     reads / address arithmetic overlap its partner's MFMAs (the 4-wave first version of this kernel spent 2.5 us per stage,
 //     5x its MFMA time: profiles/r02_wgrad3x3.txt); per stage a wave issues 36 MFMAs behind ONE barrier against 22 fragment reads;
 //   * nine accumulator sets (72 registers per wave) and ONE epilogue instead of nine.
@@ -152,37 +152,35 @@ __device__ __forceinline__ void wgrad3x3_body(const W3K& a, const char* const gx
     ++xc;
   };
 
-  // r5: wave = (ci group of 16, k-step of the stage) and ALL 64 output channels -- 4 x 2 waves.  Rounds 2-4 gave a wave 32 co x 16 ci over
-  // both k-steps: 44 transposing fragment reads per 36 MFMAs (the nine shifted X fragments are re-read by both co halves), and the SQ pass
-  // of r4 shows the LDS port as the bound: 2 cycles per ds_read_b64_tr_b16, matrix pipes 46 % busy on the SIMDs the kernel occupies
-  // (profiles/r04_wgrad_group.txt).  With the stage's two k-steps split between the two waves of a SIMD a wave reads 4 dY + 9 X
-  // fragments = 26 reads for its 36 MFMAs (1.7x fewer LDS bytes per MFMA); the two k-halves of a tile meet in LDS once, in the epilogue.
-  // 36 accumulator quads per wave (144 registers): one block per CU (the 88 KiB of rings never allowed two).
-  f32x4 acc[9][4];
+  f32x4 acc[9][2];
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int n = 0; n < 4; ++n) acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int wave = tid >> 6, wci = wave & 3, kh = wave >> 2;
+    for (int n = 0; n < 2; ++n) acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int wave = tid >> 6, wco = wave & 1, wci = wave >> 1;      // 2 x 4 waves: 32 output channels x 16 input channels each
 
   // fragment offsets (bytes).  Transposing read of 16 channels x 32 pixels: lane (i = l & 15, g = l >> 4) reads rows
   // g*4 + (i >> 2) and +16 of the 32-pixel k-step, 8 bytes at 16-byte slot (c0 >> 3) + ((i & 3) >> 1), half (i & 1)
   const int l = tid & 63, li = l & 15, lg = l >> 4;
   const int frow = lg * 4 + (li >> 2), fhalf = (li & 1) << 3, fs = (li & 3) >> 1;
-  int yoff[4];                                           // [n]: inside a 64-row dY stage tile, k-step kh; the +16-row half is +2048
+  int yoff[2][2];                                        // [k-step][n]: inside a 64-row dY stage tile; the +16-row half is +2048
 #pragma unroll
-  for (int n = 0; n < 4; ++n) {
-    const int row = kh * 32 + frow, slot = n * 2 + fs;
-    yoff[n] = row * 128 + ((slot ^ fsw(row)) << 4) + fhalf;
-  }
-  int xoff[9];                                           // [tap]: inside the 512-row ring, k-step kh of the CURRENT stage
+  for (int k = 0; k < 2; ++k)
 #pragma unroll
-  for (int t = 0; t < 9; ++t) {
-    const int shift = (t / 3 - 1) * a.Wp + (t % 3 - 1);
-    const int row = (PK * a.hb + kh * 32 + shift + frow) & (XROWS - 1);        // stage 0: ring row of padded pixel pb + kh*32 + shift
-    const int slot = wci * 2 + fs;
-    xoff[t] = row * 128 + ((slot ^ fsw(row)) << 4) + fhalf;
-  }
+    for (int n = 0; n < 2; ++n) {
+      const int row = k * 32 + frow, slot = ((wco * 32 + n * 16) >> 3) + fs;
+      yoff[k][n] = row * 128 + ((slot ^ fsw(row)) << 4) + fhalf;
+    }
+  int xoff[9][2];                                        // [tap][k-step]: inside the 512-row ring, for the CURRENT stage
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int shift = (t / 3 - 1) * a.Wp + (t % 3 - 1);
+      const int row = (PK * a.hb + k * 32 + shift + frow) & (XROWS - 1);        // stage 0: ring row of padded pixel pb + k*32 + shift
+      const int slot = ((wci * 16) >> 3) + fs;
+      xoff[t][k] = row * 128 + ((slot ^ fsw(row)) << 4) + fhalf;
+    }
 
   // prologue: the halo chunks 0 .. D-1 first, then the (dY stage, X chunk) pairs of stages 0 and 1.  From then on every loop
   // iteration issues exactly one pair (L = 2 DMA instructions per thread), so vmcnt(L) == "everything but the youngest pair landed"
@@ -196,71 +194,58 @@ __device__ __forceinline__ void wgrad3x3_body(const W3K& a, const char* const gx
     issue_y(); issue_x();                                // pair st + 2 (dY slot (st+2) % 3, X chunk st + D + 2)
     if (!(a.dbg & 1)) {
       const char* ys = yring + cs * YT;
-      // all 26 fragment reads of the wave's k-step are issued before its first MFMA (dY first, then the taps in the order the MFMAs
-      // consume them: the counted lgkmcnt waits hipcc derives let tap t start while the reads of taps > t are still in flight); the other
-      // wave of the SIMD works on the stage's other k-step beside it
-      bf16x8 fy[4], fx[9];
+      // r4: ALL 22 fragment reads of a k-step are issued before its first MFMA, and the reads of the second k-step before the MFMAs of the
+      // first (two fragment sets, 88 registers).  The r2-r3 loop read tap t+1 while the two MFMAs of tap t ran: 32 cycles of cover for an
+      // LDS round trip of > 100 -- every tap of every stage waited (1.3 us per stage against 0.48 us of MFMA time for the two waves of a
+      // SIMD, profiles/r04_wgrad_group.txt).  The full-K grouped form runs 217 stages per block: the loop IS the kernel now.
+      bf16x8 fy0[2], fy1[2], fx0[9], fx1[9];
 #pragma unroll
-      for (int n = 0; n < 4; ++n) fy[n] = read_tr_pair(ys, yoff[n], yoff[n] + 16 * 128);
+      for (int n = 0; n < 2; ++n) fy0[n] = read_tr_pair(ys, yoff[0][n], yoff[0][n] + 16 * 128);
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
-        const int o = xoff[t];
-        fx[t] = read_tr_pair(xring, o, (o + 16 * 128) & (XBYTES - 1));                      // fsw(row + 16) == fsw(row)
-        xoff[t] = (o + PK * 128) & (XBYTES - 1);                                            // next stage: 64 rows further round the ring
+        const int o = xoff[t][0];
+        fx0[t] = read_tr_pair(xring, o, (o + 16 * 128) & (XBYTES - 1));                     // fsw(row + 16) == fsw(row)
+        xoff[t][0] = (o + PK * 128) & (XBYTES - 1);                                         // next stage: 64 rows further round the ring
+      }
+#pragma unroll
+      for (int n = 0; n < 2; ++n) fy1[n] = read_tr_pair(ys, yoff[1][n], yoff[1][n] + 16 * 128);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int o = xoff[t][1];
+        fx1[t] = read_tr_pair(xring, o, (o + 16 * 128) & (XBYTES - 1));
+        xoff[t][1] = (o + PK * 128) & (XBYTES - 1);
       }
       __builtin_amdgcn_sched_barrier(0);                   // (hipcc would sink the reads back in front of their consumers)
 #pragma unroll
       for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[n], fx[t], acc[t][n], 0, 0, 0);
+        for (int n = 0; n < 2; ++n) acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy0[n], fx0[t], acc[t][n], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy1[n], fx1[t], acc[t][n], 0, 0, 0);
     }
     if (++cs == NS) cs = 0;
   }
   wait_vm<0>();                                          // drain the pairs issued past the end before the LDS is released
-  if (a.dbg & 2) return;
 
-  // Epilogue.  The two k-halves of the tile meet in LDS, three taps at a time: the kh = 1 waves park their quads, the kh = 0 waves add them.
-  // With a partial workspace the sums go back into the staging tile and ALL threads store them as float4 ([slice][tile][tap][co 64][ci 64]:
-  // a lane stores 16 contiguous bytes, a wave 1 KiB -- the direct form, 4-byte stores 16 lanes per 64-byte run, was bound by store issue);
-  // otherwise the kh = 0 waves write / atomically add their quads to dW themselves.
-  float* stg = reinterpret_cast<float*>(smem);
-  float* out = a.partial ? a.partial + ((size_t)ks * (a.nco * a.nci) + (size_t)tco * a.nci + tci) * TILE_FLOATS : nullptr;
+  if (a.partial) {
+    // [slice][tile][tap][co 64][ci 64] fp32.  Through LDS, three taps at a time, so that a lane stores 16 contiguous bytes and a
+    // wave 1 KiB: the direct form (72 4-byte stores per lane, 16 lanes per 64-byte run) was bound by store ISSUE
+    // (147 KiB per block at ~7 B/clk: as long as the whole K loop).
+    if (a.dbg & 2) return;
+    float* out = a.partial + ((size_t)ks * (a.nco * a.nci) + (size_t)tco * a.nci + tci) * TILE_FLOATS;
+    float* stg = reinterpret_cast<float*>(smem);
 #pragma unroll
-  for (int t0 = 0; t0 < 9; t0 += 3) {
-    __syncthreads();                                     // rings (first round) / previous round fully read
-    if (kh == 1) {
-#pragma unroll
-      for (int tl = 0; tl < 3; ++tl)
-#pragma unroll
-        for (int n = 0; n < 4; ++n)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) stg[(tl * 64 + n * 16 + lg * 4 + q) * STG_PITCH + wci * 16 + li] = acc[t0 + tl][n][q];
-    }
-    __syncthreads();
-    if (kh == 0) {
-      float other[3][4][4];                              // all 48 reads in flight before the first add (a read-add-write chain per element pays 48 LDS round trips)
+    for (int t0 = 0; t0 < 9; t0 += 3) {
+      __syncthreads();                                   // rings (first round) / previous round fully read
 #pragma unroll
       for (int tl = 0; tl < 3; ++tl)
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
+        for (int n = 0; n < 2; ++n)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) other[tl][n][q] = stg[(tl * 64 + n * 16 + lg * 4 + q) * STG_PITCH + wci * 16 + li];
-#pragma unroll
-      for (int tl = 0; tl < 3; ++tl)
-#pragma unroll
-        for (int n = 0; n < 4; ++n)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) acc[t0 + tl][n][q] += other[tl][n][q];
-      if (out) {
-#pragma unroll
-        for (int tl = 0; tl < 3; ++tl)
-#pragma unroll
-          for (int n = 0; n < 4; ++n)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) stg[(tl * 64 + n * 16 + lg * 4 + q) * STG_PITCH + wci * 16 + li] = acc[t0 + tl][n][q];
-      }
-    }
-    if (out) {
+          for (int q = 0; q < 4; ++q)
+            stg[(tl * 64 + wco * 32 + n * 16 + lg * 4 + q) * STG_PITCH + wci * 16 + li] = acc[t0 + tl][n][q];
       __syncthreads();
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
@@ -270,16 +255,16 @@ __device__ __forceinline__ void wgrad3x3_body(const W3K& a, const char* const gx
         *reinterpret_cast<f32x4v*>(out + (size_t)t0 * 4096 + (size_t)e4 * 4) = v;
       }
     }
+    return;
   }
-  if (out || kh != 0) return;
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int n = 0; n < 4; ++n) {
+    for (int n = 0; n < 2; ++n) {
       const int ci = ci0 + wci * 16 + li;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int co = co0 + n * 16 + lg * 4 + q;
+        const int co = co0 + wco * 32 + n * 16 + lg * 4 + q;
         if (co < a.Cout && ci < a.Cin) {
           float* d = gdw + (size_t)co * a.dw_ld + (size_t)ci * a.ci_stride + (size_t)t * a.tap_stride;
           if (GROUPED || a.direct) *d = acc[t][n][q]; else atomicAdd(d, acc[t][n][q]);
@@ -289,13 +274,13 @@ __device__ __forceinline__ void wgrad3x3_body(const W3K& a, const char* const gx
 }
 
 template <bool SMALL>
-__global__ void __launch_bounds__(NT, 1) wgrad3x3_kernel(const W3K a) {
+__global__ void __launch_bounds__(NT, 2) wgrad3x3_kernel(const W3K a) {
   wgrad3x3_body<SMALL, false>(a, a.x, a.dy, a.dw, blockIdx.x);
 }
 // grouped form: splitk == 1, no partial workspace; the tiles of one problem are consecutive in the XCD-remapped block order (they
 // stream the same dY / X rows: one XCD's L2 serves all 16 of them)
 template <bool SMALL>
-__global__ void __launch_bounds__(NT, 1) wgrad3x3_group_kernel(const W3K a, const W3G g) {
+__global__ void __launch_bounds__(NT, 2) wgrad3x3_group_kernel(const W3K a, const W3G g) {
   const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
   const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   const int per = a.nco * a.nci;
