@@ -31,3 +31,17 @@ for blocks, windows, tag in ((192, 1, "25 MB resident"), (192, 8, "25 MB x 8 win
             us, tbs = run(blocks, seg, depth, windows)
             row.append(f"seg {seg:4d}: {us:6.1f} us {tbs:5.2f} TB/s")
         print(f"{tag:20s} blocks {blocks:4d} depth {depth}: " + " | ".join(row), flush=True)
+# kind 10: the hand-over data gradient's EPILOGUE alone (tile-shaped loads of 1-3 matrices + one tile-shaped store, 1536 blocks at M = 12 288)
+for nin in (1, 2, 3):
+    blocks = 96 * 16
+    mat = 12288 * 2048
+    def once(w=0):
+        rc = l.tf_debug_probe(10, blocks, 0, big.data_ptr() + w * 4 * mat, (nin + 1) * mat, nin, stream()); assert rc == 0, rc
+    for rep, windows in (("same buffers", 1), ("8 rotating windows", 8)):
+        once(); torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for i in range(40): once(i % windows)
+        b.record(); b.synchronize()
+        us = a.elapsed_time(b) / 40 * 1e3
+        print(f"tile epilogue probe: {nin} in + 1 out x 25 MB, 1536 blocks, {rep}: {us:6.1f} us  {(nin + 1) * mat / us / 1e6:5.2f} TB/s", flush=True)

@@ -12,7 +12,7 @@ extern "C" {
 int tf_debug_conv3x3h_trace(void* device_buf);
 /* interference probe of the two-stream contention measurement (csrc/probe.hip, scripts/contention.py): `blocks` workgroups of 256
  * threads that hog ONE CU resource for `iters` rounds -- kind 0 park (LDS capacity + wave slots only), 1 L2 loads, 2 HBM loads,
- * 3 MFMA, 4 LDS-DMA, 5 fp32 atomics, 6 LDS reads, 9 (r5) operand-streaming pattern probe (iters = run bytes | depth << 16), 7 (r4) `iters` device-wide barriers in one launch (blocks <= 1024); `buf` / `window_bytes`: device window of the memory kinds.  Not part of the
+ * 3 MFMA, 4 LDS-DMA, 5 fp32 atomics, 6 LDS reads, 9 (r5) operand-streaming pattern probe (iters = run bytes | depth << 16), 10 (r5) tile-shaped epilogue traffic alone (iters = input matrices), 7 (r4) `iters` device-wide barriers in one launch (blocks <= 1024); `buf` / `window_bytes`: device window of the memory kinds.  Not part of the
  * product path. */
 int tf_debug_probe(int kind, int blocks, int lds_bytes, void* buf, size_t window_bytes, int iters, void* stream);
 int tf_debug_probe_chain(int kind, int blocks, int lds_bytes, void* buf, size_t window_bytes, int iters, int repeat, void* stream);   /* `repeat` launches from one host call */

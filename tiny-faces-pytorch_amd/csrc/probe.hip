@@ -167,6 +167,32 @@ __global__ void __launch_bounds__(256) stream_probe_kernel(const char* buf, int 
   if (seg < 0) sink[0] = smem[tid];
 }
 
+// kind 10 (r5): the EPILOGUE of the hand-over data gradient as a kernel of its own -- no GEMM, no LDS.  A block owns the (128-row x 128-byte)
+// tile (mt, nt) of [M][2048 B] matrices (row stride 2 KiB, 16 tiles across a row), loads it from NIN matrices (16 loads of 16 bytes per
+// thread and matrix, all issued before the first use), combines them and stores the tile of a further matrix: 1536 tiles at M = 12 288.
+// What the memory system gives a kernel with THIS access pattern, free of everything else the conv kernel does.
+template <int NIN>
+__global__ void __launch_bounds__(256) tile_probe_kernel(const char* buf, size_t mat_bytes, int ntiles, int rows_total) {
+  const int mt = blockIdx.x / ntiles, nt = blockIdx.x - mt * ntiles;
+  const int t = threadIdx.x, r0 = t >> 3, pc = t & 7;
+  uint4 v[NIN][4];
+#pragma unroll
+  for (int i = 0; i < NIN; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = mt * 128 + r0 + 32 * j;
+      v[i][j] = row < rows_total ? *reinterpret_cast<const uint4*>(buf + (size_t)i * mat_bytes + (size_t)row * 2048 + nt * 128 + pc * 16) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    uint4 o = v[0][j];
+#pragma unroll
+    for (int i = 1; i < NIN; ++i) { o.x += v[i][j].x; o.y ^= v[i][j].y; o.z += v[i][j].z; o.w ^= v[i][j].w; }
+    const int row = mt * 128 + r0 + 32 * j;
+    if (row < rows_total) *reinterpret_cast<uint4*>(const_cast<char*>(buf) + (size_t)NIN * mat_bytes + (size_t)row * 2048 + nt * 128 + pc * 16) = o;
+  }
+}
+
 template <int KIND>
 int launch(int blocks, int lds, char* buf, size_t window, int iters, hipStream_t s) {
   static bool attr = false;
@@ -201,6 +227,15 @@ extern "C" int tf_debug_probe(int kind, int blocks, int lds_bytes, void* buf, si
       else if (depth == 4) hipLaunchKernelGGL(stream_probe_kernel<4>, dim3(blocks), dim3(256), l, s, b, seg, reinterpret_cast<float*>(b));
       else if (depth == 8) hipLaunchKernelGGL(stream_probe_kernel<8>, dim3(blocks), dim3(256), l, s, b, seg, reinterpret_cast<float*>(b));
       else return TF_ERR_ARG;
+      return hipGetLastError() == hipSuccess ? TF_OK : TF_ERR_LAUNCH;
+    }
+    case 10: {                                              // iters = number of input matrices (1..3); blocks = (rows / 128) * 16; window >= (iters + 1) * rows * 2048
+      const int rows = blocks / 16 * 128;
+      const size_t mat = (size_t)rows * 2048;
+      if (iters < 1 || iters > 3 || blocks % 16 || window_bytes < (size_t)(iters + 1) * mat) return TF_ERR_ARG;
+      if (iters == 1) hipLaunchKernelGGL(tile_probe_kernel<1>, dim3(blocks), dim3(256), 0, s, b, mat, 16, rows);
+      else if (iters == 2) hipLaunchKernelGGL(tile_probe_kernel<2>, dim3(blocks), dim3(256), 0, s, b, mat, 16, rows);
+      else hipLaunchKernelGGL(tile_probe_kernel<3>, dim3(blocks), dim3(256), 0, s, b, mat, 16, rows);
       return hipGetLastError() == hipSuccess ? TF_OK : TF_ERR_LAUNCH;
     }
     case 7: case 8:
