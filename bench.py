@@ -157,8 +157,8 @@ def cpu_baseline(bs=12, warmup=2, steps=5, eval_warmup=1, eval_runs=5, threads=N
             "cpu": _cpu_model(), "host_threads": os.cpu_count(), "torch": torch.__version__}
 
 
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
-PMC_TRAFFIC_FILE_FP32 = os.path.join(ROOT, "profiles", "r04_pmc_traffic_fp32.json")
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")
+PMC_TRAFFIC_FILE_FP32 = os.path.join(ROOT, "profiles", "r05_pmc_traffic_fp32.json")
 PMC_PATTERNS = {6: ("conv3x3h_kernel<tf::bf16_t,",), 7: ("conv3x3h_kernel<tf::f16_t,",), 13: ("conv_dma_kernel<tf::bf16_t,",), 12: ("conv_dma_kernel<float,",), 15: ("conv_dma_kernel<tf::f16_t,",),
                 14: ("wgrad_dma_kernel",), 16: ("wgrad3x3_kernel",), 17: ("conv_pwx_kernel",), 18: ("wgrad_group_kernel", "wgrad_group_fast_kernel"), 20: ("stem_conv_kernel<tf::bf16_t,",), 21: ("stem_conv_kernel<tf::f16_t,",), 19: ("wgrad3x3_group_kernel",)}
 
@@ -196,7 +196,7 @@ def pmc_step_traffic(path=None):
     return sum(v["hbm_bytes"] * v["launches"] for v in k.values()) / (sgd / 3.0)
 
 
-ROCPROF_STATS_FILE = os.path.join(ROOT, "profiles", "r04_train_bs12_bf16_kernel_stats.csv")
+ROCPROF_STATS_FILE = os.path.join(ROOT, "profiles", "r05_train_bs12_bf16_kernel_stats.csv")
 
 
 def rocprof_avg_us(kind):
@@ -385,7 +385,7 @@ def bench_fp32_path(device, rank, batch, steps=20, warmup=3):
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         out["roofline"] = {"kernel": KIND_NAMES.get(dom["kind"], str(dom["kind"])), **roof_of(dom["flops"], dom["bytes"], dom["ms"] * 1e-3, PEAK_TFLOPS["fp32"]),
                            "achieved_tflops": round(ach, 2), "traffic": pmc_traffic(dom["kind"], PMC_TRAFFIC_FILE_FP32),
-                           "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes of `bench.py --dtype fp32` (profiles/r04_pmc_traffic_fp32.json); "
+                           "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes of `bench.py --dtype fp32` (profiles/r05_pmc_traffic_fp32.json); "
                                            "algorithmic bytes per launch = %d" % round(dom["bytes"] / dom["launches"]),
                            "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2), "launches_sampled": dom["launches"],
                            "launches_per_step": round(dom["launches"] * PROFILE_EVERY / steps, 1),
@@ -806,7 +806,7 @@ def main():
                            "achieved_tflops": round(ach, 2), "peak_tflops": peak,
                            "arithmetic_intensity_flop_per_byte": round(dom["flops"] / max(dom["bytes"], 1.0), 1), "machine_balance_flop_per_byte": round(peak * 1e12 / (PEAK_HBM_GBS * 1e9), 1),
                            "traffic": pmc_traffic(dom["kind"]),
-                           "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes of this command (profiles/r04_pmc_traffic.json); "
+                           "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes of this command (profiles/r05_pmc_traffic.json); "
                                            "algorithmic bytes per launch = %d" % round(dom["bytes"] / dom["launches"]),
                            "launches_sampled": dom["launches"], "launches_per_step": round(dom["launches"] * PROFILE_EVERY / args.steps, 1),
                            "sampling": f"HIP events around 1 launch in {PROFILE_EVERY} over the timed region (weight gradients run concurrently on a second stream)",
@@ -814,7 +814,7 @@ def main():
                            "rocprof_avg_launch_us": rocprof_avg_us(dom["kind"]),
                            "frac_rocprof_clock": (lambda us: roof_of(dom["flops"] / dom["launches"], dom["bytes"] / dom["launches"], us * 1e-6, peak)["frac"] if us else None)(rocprof_avg_us(dom["kind"])),
                            "rocprof_note": "true kernel duration in the committed rocprofv3 --kernel-trace --stats summary of this command "
-                                           "(profiles/r04_train_bs12_bf16_kernel_stats.csv); the HIP-event bracket adds the queue's inter-packet latency (~5-6 us)",
+                                           "(profiles/r05_train_bs12_bf16_kernel_stats.csv); the HIP-event bracket adds the queue's inter-packet latency (~5-6 us)",
                            "algorithmic_gflop_per_launch": round(dom["flops"] / dom["launches"] / 1e9, 3),
                            "executed_gflop_per_launch": round(dom["xflops"] / dom["launches"] / 1e9, 3),
                            "flops_note": "achieved / frac count ALGORITHMIC flops: 2 x the MACs of the forward convolution a launch belongs to on unpadded channels "
@@ -828,7 +828,7 @@ def main():
                                     "ms_per_step_at_6300_gb_s": round(stb / 6.3e12 * 1e3, 2),
                                     "mfma_frac_of_step": round(3 * FWD_GFLOP_PER_IMG * args.batch / ms_per_step / PEAK_TFLOPS["bf16"], 4),
                                     "note": "all kernels of a step, HBM bytes from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, "
-                                            "profiles/r04_pmc_traffic.json) over this run's step time; the step is nearer to the HBM roof than to the MFMA roof"}
+                                            "profiles/r05_pmc_traffic.json) over this run's step time; the step is nearer to the HBM roof than to the MFMA roof"}
         out["kernels"] = [{"kernel": KIND_NAMES.get(r["kind"], str(r["kind"])), "launches_per_step": round(r["launches"] * PROFILE_EVERY / args.steps, 1),
                            "ms_per_step": round(r["ms"] * PROFILE_EVERY / args.steps, 3),
                            "tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 1), "gb_s": round(r["bytes"] / (r["ms"] * 1e-3) / 1e9, 1),

@@ -44,7 +44,9 @@ int pick_tile(const tf_conv_args* a) {
     //  profiles/r04_conv_pw8_negative.txt -- removed again)
     // (not with the in-LDS BN prologue `bnf`: only the ring-less 128 x 64 tile implements it -- ADVICE r3)
     if (!t46_off && !a->bnf && a->dtype != TF_F32 && nst <= 4 && M >= 16384 && a->Cout % 128 == 0 && a->Cout >= 256) return 46;
-    if (!t12_off && a->dtype != TF_F32 && nst <= 4) return 32;
+    // (TINYFACES_SHORTK_TILE: A/B knob -- another tile code for these launches, e.g. 42 = the same 128 x 64 tile with a 2-slot ring)
+    static const int shortk_tile = [] { const char* e = getenv("TINYFACES_SHORTK_TILE"); return e ? atoi(e) : 32; }();
+    if (!t12_off && a->dtype != TF_F32 && nst <= 4) return shortk_tile;
     // 32x32x16 fragments (64 pixels x 128 channels per block, 32 x 64 per wave, 2-deep ring) win where a launch still has several
     // blocks per CU AND a long K loop: 3x3 convs / K >= 576 with M >= 16 384 pixels -- layer 2 at bs = 12 (26.3 vs 32.9 us forward,
     // 25.0 vs 30.6 us data gradient) and layers 2-3 of the evaluation pyramid (41.0 vs 50.6, 40.2 vs 44.8, 21.3 vs 23.8 us);
