@@ -606,3 +606,33 @@ def test_refused_wgrad_group_falls_back_into_zeroed_gradients(tmp_path, refuse):
     # cosine 0.978 with or without the refusal.  A gradient accumulated onto the previous step's would have norm ratio 2.
     assert 0.97 < ratio < 1.03 and cos > 0.95, (ratio, cos)
     assert cos_all > 0.999
+
+
+def test_eval_pyramid_is_bit_reproducible(templates):
+    """r5: `get_detections` on ONE image, thirty times, each call with its own constant-weights session and its three pyramid levels side by
+    side on the model's lanes -- the candidate list (every box and score of every level, before NMS) and the kept indices must be the same
+    arrays every time.  Before the conv3x3h fix (csrc/conv3x3h.hip wait_vmcnt: reads of a ring slot in flight across the barrier that
+    frees it) about one run in four differed in the last few candidates of the largest level: the 3x3 convolution of a layer-3 bottleneck
+    returned a few different values when three forwards shared the GPU (scripts/diag_race6.py finds the first differing tensor)."""
+    from oracle.targets import RF
+    from tinyfaces import transforms
+    from tinyfaces.evaluation import get_detections
+    from tinyfaces.models.model import DetectionModel
+    m = DetectionModel(num_templates=25)
+    _load_oracle_weights(m)
+    m = m.cuda().eval().set_compute_dtype(torch.bfloat16)
+    tf = transforms.Compose([transforms.ToTensor(), transforms.Normalize([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])])
+    g = torch.Generator().manual_seed(4)
+    img = torch.rand(3, 700, 933, generator=g)
+    with torch.no_grad():
+        y = m(torch.randn(1, 3, 700, 933, generator=g).cuda()).cpu()
+    thr = float(torch.quantile(torch.sigmoid(y[0, :25]).flatten()[:2000000], 0.999))
+    kw = dict(prob_thresh=thr, nms_thresh=0.3, scales=(-1, 0, 1), device="cuda", pyramid_on_gpu=True, return_candidates=True)
+    r0, c0, k0 = get_detections(m, img, templates, RF, tf, **kw)
+    assert c0.shape[0] > 500
+    differing = 0
+    for _ in range(30):
+        r, c, k = get_detections(m, img, templates, RF, tf, **kw)
+        differing += int(c.shape != c0.shape or not np.array_equal(c, c0) or not np.array_equal(k, k0))
+    report("eval_pyramid_reproducible", candidates=int(c0.shape[0]), kept=int(k0.shape[0]), differing_runs=differing)
+    assert differing == 0
