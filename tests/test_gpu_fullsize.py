@@ -307,13 +307,14 @@ def test_bf16_trains_like_fp32():
     w = lambda c: c.reshape(-1, 10).mean(1)                      # 15 windows of 10 steps (the sampling draws make single steps noisy)
     f, b = w(curves["fp32"]), w(curves["bf16"])
     band = float(np.abs(b - f).max() / f[0])
-    live = f > 0.12 * f[0]                                       # the descent proper.  Below ~10 % of the start the run is a chaotic tail on 4 images
-    rel = float(np.abs(b[live] / f[live] - 1).max())             # (lr 1e-3, momentum 0.9, fresh sampling draws every step) until the OHEM threshold of
-                                                                 # loss.py:62 switches every converged example off and both reach 0.0: measured windows
-                                                                 # fp32 517 112 70 58 47 17 1.1 .04 .02 0 ...   bf16 520 110 68 52 69 31 3.6 1.4 .24 .004 .04 0 ...
+    live = np.arange(f.size) < 3                                 # the descent proper: the first 30 steps.  Later the run is a chaotic tail on 4 images (lr 1e-3,
+    rel = float(np.abs(b[live] / f[live] - 1).max())             # momentum 0.9, fresh sampling draws every step): TWO fp32 runs differ by 30 % in windows 3-5 (fp32-atomic
+                                                                 # summation order), until the OHEM threshold of loss.py:62 switches every converged example off and both
+                                                                 # reach 0.0.  Measured windows, two boxes:   fp32 517 112 70 58 47 17 1.1 .04 .02 0 ... | 518 113 69 81 63 41 11 .9 .2 ...
+                                                                 #                                           bf16 520 110 68 52 69 31 3.6 1.4 .24 0 ... | 522 112 71 63 51 35 4.9 .2 .02 ...
     fall_f, fall_b = f[0] / max(f[-1], 1e-9), b[0] / max(b[-1], 1e-9)
     report("bf16_trains_like_fp32", fp32_windows=[round(float(v), 3) for v in f], bf16_windows=[round(float(v), 3) for v in b], fall_fp32=min(fall_f, 1e9),
            fall_bf16=min(fall_b, 1e9), band_of_first=band, live_windows=int(live.sum()), max_rel_live_window=rel)
     assert np.isfinite(curves["fp32"]).all() and np.isfinite(curves["bf16"]).all()
     assert fall_f >= 20.0 and fall_b >= 20.0, (f, b)
-    assert band < 0.08 and rel < 0.15, (band, rel, f, b)        # measured 0.044 / 0.033
+    assert band < 0.08 and rel < 0.15, (band, rel, f, b)        # measured 0.044 / 0.034 (band: every window), 0.033 / 0.040 (first three windows)
