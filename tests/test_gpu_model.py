@@ -636,3 +636,55 @@ def test_eval_pyramid_is_bit_reproducible(templates):
         differing += int(c.shape != c0.shape or not np.array_equal(c, c0) or not np.array_equal(k, k0))
     report("eval_pyramid_reproducible", candidates=int(c0.shape[0]), kept=int(k0.shape[0]), differing_runs=differing)
     assert differing == 0
+
+
+@pytest.mark.parametrize("training", [False, True])
+def test_forward_is_bit_identical_beside_resource_hogs(training):
+    """r5, after the conv3x3h race: the detector's forward must return the SAME bits whatever else the GPU is doing.  The pass runs alone
+    (reference), then fifteen times while two more streams keep the CUs busy with the single-resource probes of csrc/probe.hip -- LDS-DMA
+    traffic with 96 KiB of LDS per block, LDS reads, HBM streams, MFMA chains, parked waves holding LDS -- i.e. with its blocks sharing
+    CUs, LDS, the LDS-DMA path and the memory system with foreign kernels at unpredictable phases.  Eval mode (folded BN) and training
+    mode with bit-reproducible statistic rows (tf_set_stat_rows(0): no atomics in the forward).  A general guard against kernels that
+    only order their LDS traffic by luck.  (Measured with the UNFIXED conv3x3h: these probes did not trigger its race in 15 runs -- two
+    more detector forwards on other streams do, 6 runs of 30: test_eval_pyramid_is_bit_reproducible is the test with teeth for that one.)"""
+    from tinyfaces import _hip
+    from tinyfaces.models.model import DetectionModel
+    lib = _hip.lib()
+    m = DetectionModel(num_templates=25)
+    _load_oracle_weights(m)
+    m = m.cuda().set_compute_dtype(torch.bfloat16)
+    m = m.train() if training else m.eval()
+    m.model.bn1.momentum = 0.0                             # (training mode: the running means are the shift of the statistic sums -- keep them fixed between runs)
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(3 if training else 1, 3, 500 if training else 1000, 500 if training else 1333, generator=g).cuda()
+    hogs = [torch.cuda.Stream(), torch.cuda.Stream()]
+    win = torch.zeros(256 << 20, dtype=torch.uint8, device="cuda")
+    prev = lib.tf_get_stat_rows()
+
+    def run():
+        with torch.no_grad():
+            return m._run_forward(x, training=training).clone() if training else m(x).clone()
+
+    def hog(round_):
+        kinds = [(4, 256, 96 * 1024, 40), (6, 256, 64 * 1024, 400), (2, 512, 0, 60), (3, 256, 0, 3000), (0, 256, 120 * 1024, 200)]
+        for si, s in enumerate(hogs):
+            kind, blocks, lds, iters = kinds[(round_ + 2 * si) % len(kinds)]
+            _hip.check(lib.tf_debug_probe_chain(kind, blocks, lds, win.data_ptr(), win.numel(), iters, 12, s.cuda_stream), "probe")
+    try:
+        if training:
+            lib.tf_set_stat_rows(0)
+            m._sync_tables(x.device)
+        ref = run()
+        torch.cuda.synchronize()
+        assert torch.equal(run(), ref)                     # (alone it repeats itself)
+        bad = []
+        for r in range(15):
+            hog(r)
+            y = run()
+            torch.cuda.synchronize()
+            if not torch.equal(y, ref):
+                bad.append((r, float((y - ref).abs().max())))
+    finally:
+        lib.tf_set_stat_rows(prev if prev <= 16 else 0)
+    report(f"forward_beside_hogs[training={training}]", differing_runs=len(bad), worst=max([b[1] for b in bad], default=0.0))
+    assert not bad, bad
