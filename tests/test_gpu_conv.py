@@ -712,7 +712,8 @@ C3H_CASES = [
     (1, 21, 70, 64, 256),       # 3 column tiles (the last 6 wide), 2 channel tiles
     (3, 32, 32, 256, 256),      # layer-3 shape (smaller batch)
     (1, 63, 63, 128, 128),      # layer-2 shape
-    (1, 9, 40, 320, 384),       # 5 chunks (odd), 3 channel tiles
+    (1, 9, 40, 320, 384),       # 5 chunks (odd: the one-tap stages), 3 channel tiles
+    (1, 12, 40, 512, 128),      # 8 chunks = 4 two-chunk bodies of the paired-tap loop (r5), a ragged last column tile
 ]
 
 

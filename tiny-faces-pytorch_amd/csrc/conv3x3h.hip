@@ -242,6 +242,11 @@ __global__ void __launch_bounds__(NT, 2) conv3x3h_kernel(const HK a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) xo[t][m][j] ^= XBUF;
   }
+  // (r5, measured and removed: TWO taps per barrier -- the 18 taps of two channel chunks unrolled into 9 two-tap stages, a 2-slot ring of
+  //  two-tap weight slabs (128 KiB), the next frame requested behind the weights so that one counted wait leaves it in flight; parity-green,
+  //  208 VGPRs: 1296.9 / 1292.2 against 1297.3 / 1292.5 img/s, evaluation 5.16 against 4.93 ms per image.  Halving the barriers and counted
+  //  waits of the K loop buys nothing: DESIGN.md 7 row 51.)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (r5: no fragment read in flight when the rings become the staging tile)
   __builtin_amdgcn_s_barrier();                     // all waves done reading the rings -> reuse them as the staging tile
   if constexpr (TRACE) {
     if (logical < 8 && a.trace) {
