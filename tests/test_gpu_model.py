@@ -688,3 +688,52 @@ def test_forward_is_bit_identical_beside_resource_hogs(training):
         lib.tf_set_stat_rows(prev if prev <= 16 else 0)
     report(f"forward_beside_hogs[training={training}]", differing_runs=len(bad), worst=max([b[1] for b in bad], default=0.0))
     assert not bad, bad
+
+
+_FUSED_PROLOGUE_SCRIPT = r'''
+import sys, numpy as np, torch
+sys.path[:0] = [ROOT, ROOT + "/tiny-faces-pytorch_amd"]
+from oracle.model import OracleDetectionModel, tame_init_
+from tinyfaces.models.model import DetectionModel
+m = DetectionModel(num_templates=25)
+m.load_state_dict(tame_init_(OracleDetectionModel(num_templates=25), 0).state_dict())
+m = m.cuda().set_compute_dtype(torch.bfloat16).train()
+g = torch.Generator().manual_seed(0)
+x = torch.randn(2, 3, 160, 224, generator=g).cuda()
+y = m(x)
+gy = (torch.randn(y.shape, generator=g) * 0.1).cuda()
+y.backward(gy)
+names = ["model.conv1.weight", "model.layer2.2.conv1.weight", "model.layer3.4.conv1.weight", "model.layer3.9.conv3.weight", "model.layer3.20.bn3.weight", "score_res4.weight"]
+pd = dict(m.named_parameters())
+np.savez(sys.argv[1], y=y.detach().float().cpu().numpy(), rm=m.model.layer3[6].bn3.running_mean.detach().cpu().numpy(),
+         **{f"g{i}": pd[k].grad.float().cpu().numpy() for i, k in enumerate(names)})
+'''
+
+
+def test_opt_in_fused_bn_prologues_take_the_same_step(tmp_path):
+    """r5: the executor with the fused BatchNorm prologues switched ON (TINYFACES_PWX_FWD=1: bn3 + residual + ReLU of a bottleneck on the
+    operand path of the next conv1, tf_conv2d_bnfwd; TINYFACES_PWX_ALL=1: the BN-backward apply on the operand path of conv3's data gradient,
+    tf_conv2d_bnbwd) against the default graph (every pass a launch of its own), one training forward + backward from the same weights: the
+    maps, the running statistics the fused kernel publishes, and gradients of layers 1-3 + heads.  The knobs are read once per process: two
+    subprocesses.  (The fused graph is opt-in because it is slower, DESIGN.md 7 rows 44-45; it has to stay CORRECT.)"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for tag, extra in (("default", {}), ("fused", {"TINYFACES_PWX_FWD": "1", "TINYFACES_PWX_ALL": "1"})):
+        env = {k: v for k, v in os.environ.items() if not k.startswith("TINYFACES_PWX")}
+        env.update(extra)
+        out = str(tmp_path / f"{tag}.npz")
+        r = subprocess.run([sys.executable, "-c", f"ROOT = {root!r}\n" + _FUSED_PROLOGUE_SCRIPT, out], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        outs[tag] = np.load(out)
+    a, b = outs["default"], outs["fused"]
+    span = float(np.abs(a["y"]).max())
+    d_y = float(np.abs(a["y"] - b["y"]).max()) / span
+    d_rm = float(np.abs(a["rm"] - b["rm"]).max() / (np.abs(a["rm"]).max() + 1e-30))
+    cos = []
+    for i in range(6):
+        u, v = a[f"g{i}"].ravel().astype(np.float64), b[f"g{i}"].ravel().astype(np.float64)
+        cos.append(float(u @ v / (np.linalg.norm(u) * np.linalg.norm(v) + 1e-300)))
+    report("fused_bn_prologues_vs_default", maps_rel=d_y, running_mean_rel=d_rm, grad_cos_min=min(cos), grad_cos=[round(c, 4) for c in cos])
+    assert d_y < 2e-2 and d_rm < 1e-3                     # bf16 maps of two summation orders; the published statistics are fp32
+    assert min(cos) > 0.97, cos                           # (two runs of the DEFAULT graph agree to 0.978 on this fixture: fp32 atomics + bf16)

@@ -698,8 +698,14 @@ extern "C" int tf_detnet_forward_ctx(tf_detnet_ctx* xctx, int single_stream, int
       Plan::Blk& bp = P.blk[i - 1];
       const tf_bn_fwd_desc d3 = fwd_desc(c, Bp.c3, bp.b3);
       tf_bn_fwd_desc dd; if (Bp.has_ds) dd = fwd_desc(c, Bp.ds, bp.bd);
+      const void* resid = Bp.has_ds ? bp.d : (i >= 2 ? P.blk[i - 2].y : P.pool);
       a.x = bp.c3;
-      c.chk(tf_conv2d_bnfwd(&a, &d3, Bp.has_ds ? bp.d : (i >= 2 ? P.blk[i - 2].y : P.pool), Bp.has_ds ? &dd : nullptr, bp.y, srows, (float)Min, eps, mom, c.stream));
+      const int rc = tf_conv2d_bnfwd(&a, &d3, resid, Bp.has_ds ? &dd : nullptr, bp.y, srows, (float)Min, eps, mom, c.stream);
+      if (rc == TF_ERR_UNSUPPORTED) {              // a shape the fused kernel does not take after all: the two launches it stands for
+        c.chk(tf_bn_add_relu_fused(dtype, bp.c3, &d3, resid, Bp.has_ds ? &dd : nullptr, srows, Min, B.cin, (float)Min, eps, mom, bp.y, c.stream));
+        a.x = yin;
+        c.chk(tf_conv2d(&a, c.stream));
+      } else c.chk(rc);
       tail_deferred = false;
     } else c.chk(tf_conv2d(&a, c.stream));
     // a1 = relu(bn1(c1)), materialised on purpose: every consumer (conv2, its weight gradient) uses the LDS-DMA pipeline
