@@ -318,3 +318,47 @@ def test_bf16_trains_like_fp32():
     assert np.isfinite(curves["fp32"]).all() and np.isfinite(curves["bf16"]).all()
     assert fall_f >= 20.0 and fall_b >= 20.0, (f, b)
     assert band < 0.08 and rel < 0.15, (band, rel, f, b)        # measured 0.044 / 0.034 (band: every window), 0.033 / 0.040 (first three windows)
+
+
+def test_training_step_is_bit_reproducible_where_no_atomics_sum():
+    """r5, after the conv3x3h race: at the benchmarked size (12 x 3 x 500 x 500, bf16, two streams) a training forward + backward is repeated
+    six times with reproducible BN statistic rows (tf_set_stat_rows(0)) and the running means held (momentum 0).  Everything that is NOT an
+    fp32-atomic sum must repeat itself bit for bit: the output maps, every BatchNorm gamma / beta gradient (they hang off the whole
+    data-gradient chain: all pointwise and 3x3 data gradients with their mask / statistic epilogues) and every stride-1 3x3 weight gradient of
+    layers 1-3 (slices summed by a second kernel, no atomics) -- while the split-K pointwise weight gradients run beside the chain on the
+    second stream.  (Those are summed with fp32 atomics and differ from run to run by design; they are not compared.)"""
+    from oracle.model import OracleDetectionModel, tame_init_
+    from tinyfaces import _hip
+    from tinyfaces.models.model import DetectionModel
+    lib = _hip.lib()
+    m = DetectionModel(num_templates=25)
+    m.load_state_dict(tame_init_(OracleDetectionModel(num_templates=25), 0).state_dict(), strict=True)
+    m = m.cuda().set_compute_dtype(torch.bfloat16).train()
+    m.model.bn1.momentum = 0.0
+    m.flatten_parameters()
+    x = torch.randn(BS, 3, SIDE, SIDE, generator=torch.Generator().manual_seed(1)).cuda()
+    prev = lib.tf_get_stat_rows()
+    try:
+        lib.tf_set_stat_rows(0)
+        m._sync_tables(x.device)
+        seg = m._segments
+        # (the two STRIDE-2 3x3 convs, layer2.0 / layer3.0 conv2, take the per-tap weight-gradient kernel with coalesced fp32 atomics: by design not bit-reproducible)
+        det = [k for k in seg if ".bn" in k or "downsample.1" in k or (k.endswith("conv2.weight") and k not in ("model.layer2.0.conv2.weight", "model.layer3.0.conv2.weight"))]
+        assert len(det) > 150
+        ref, bad_maps, bad = None, 0, {}
+        for it in range(7):
+            out = m._run_forward(x, training=True)
+            gf = m._run_backward(x, torch.full_like(out, 1e-3), persistent=True)
+            torch.cuda.synchronize()
+            if ref is None:
+                ref = (out.clone(), gf.clone())
+                continue
+            bad_maps += int(not torch.equal(out, ref[0]))
+            for k in det:
+                o, n = seg[k]
+                if not torch.equal(gf[o:o + n], ref[1][o:o + n]):
+                    bad[k] = bad.get(k, 0) + 1
+    finally:
+        lib.tf_set_stat_rows(prev if prev <= 16 else 0)
+    report("train_step_reproducible", compared_tensors=len(det), maps_differing_runs=bad_maps, tensors_that_differed=len(bad))
+    assert bad_maps == 0 and not bad, (bad_maps, sorted(bad.items())[:8])
