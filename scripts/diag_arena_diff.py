@@ -1,4 +1,4 @@
-"""r5 diagnostic, part 6: three levels on three lanes, a fresh session per call; on a mismatch of the big level's map diff the model's whole workspace
+"""r5 diagnostic (how the conv3x3h race was found): three levels on three lanes, a fresh session per call; on a mismatch of the big level's map diff the model's whole workspace
 against the reference run -- every eval activation has its own buffer in the arena, in execution order: the lowest differing offset names the first tensor that differs."""
 import os, sys, numpy as np, torch, ctypes as C
 ROOT = os.environ.get("DIAG_ROOT") or os.environ.get("GRAFT_REPO_ROOT", "/root/repo")

@@ -613,7 +613,7 @@ def test_eval_pyramid_is_bit_reproducible(templates):
     side on the model's lanes -- the candidate list (every box and score of every level, before NMS) and the kept indices must be the same
     arrays every time.  Before the conv3x3h fix (csrc/conv3x3h.hip wait_vmcnt: reads of a ring slot in flight across the barrier that
     frees it) about one run in four differed in the last few candidates of the largest level: the 3x3 convolution of a layer-3 bottleneck
-    returned a few different values when three forwards shared the GPU (scripts/diag_race6.py finds the first differing tensor)."""
+    returned a few different values when three forwards shared the GPU (scripts/diag_arena_diff.py finds the first differing tensor)."""
     from oracle.targets import RF
     from tinyfaces import transforms
     from tinyfaces.evaluation import get_detections

@@ -76,7 +76,7 @@ template <> struct Frag<tf::f16_t> {
 // fragment reads that feed them -- below the NEXT stage's wait + barrier (ISA of every instantiation): a wave then passed the barrier with
 // reads of ring slot s % 3 / the old frame still in flight, and behind that barrier another wave issues the DMA that REFILLS exactly that
 // slot.  The reads normally return long before the DMA lands, but with three pyramid levels side by side on one GPU they sometimes
-// did not: c2 of a layer-3 bottleneck came out a few values different in ~1 of 4 evaluation pyramids (scripts/diag_race6.py walks the
+// did not: c2 of a layer-3 bottleneck came out a few values different in ~1 of 4 evaluation pyramids (scripts/diag_arena_diff.py walks the
 // arena to the first tensor that differs; tests/test_gpu_model.py::test_eval_pyramid_is_bit_reproducible).  With the reads drained before
 // the barrier the refill is ordered behind every read of the slot it overwrites.
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
