@@ -43,7 +43,9 @@ int pick_tile(const tf_conv_args* a) {
     // (r4: a 128 x 128 / eight-wave pointwise kernel, conv_pw8, was built for the K >= 512 GEMMs and measured no faster on any layer shape:
     //  profiles/r04_conv_pw8_negative.txt -- removed again)
     // (not with the in-LDS BN prologue `bnf`: only the ring-less 128 x 64 tile implements it -- ADVICE r3)
-    if (!t46_off && !a->bnf && a->dtype != TF_F32 && nst <= 4 && M >= 16384 && a->Cout % 128 == 0 && a->Cout >= 256) return 46;
+    // (TINYFACES_SHORTK_BIG_TILE: A/B knob -- another tile code for these launches, e.g. 44 = 128 x 128 / 45 = 128 x 64 on the same fragments)
+    static const int shortk_big = [] { const char* e = getenv("TINYFACES_SHORTK_BIG_TILE"); return e ? atoi(e) : 46; }();
+    if (!t46_off && !a->bnf && a->dtype != TF_F32 && nst <= 4 && M >= 16384 && a->Cout % 128 == 0 && a->Cout >= 256) return shortk_big;
     // (TINYFACES_SHORTK_TILE: A/B knob -- another tile code for these launches, e.g. 42 = the same 128 x 64 tile with a 2-slot ring)
     static const int shortk_tile = [] { const char* e = getenv("TINYFACES_SHORTK_TILE"); return e ? atoi(e) : 32; }();
     if (!t12_off && a->dtype != TF_F32 && nst <= 4) return shortk_tile;
