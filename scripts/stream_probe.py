@@ -45,3 +45,19 @@ for nin in (1, 2, 3):
         b.record(); b.synchronize()
         us = a.elapsed_time(b) / 40 * 1e3
         print(f"tile epilogue probe: {nin} in + 1 out x 25 MB, 1536 blocks, {rep}: {us:6.1f} us  {(nin + 1) * mat / us / 1e6:5.2f} TB/s", flush=True)
+# kind 11: memory skeleton of a wave-autonomous streaming pointwise conv (persistent blocks, every wave its own 16-pixel tiles, private 2-slot ring + staging)
+for shape, tag, inb, outb in ((0, "64 -> 256 channels", 128, 512), (1, "256 -> 64 channels", 512, 128)):
+    for px, where in ((187500 // 16 * 16, "M = 187 500 (layer 1, bs = 12)"), (307200, "M = 307 200 (1920 x 2560 level)")):
+        for nw in (4, 8):
+            for blocks in (256, 512, 768, 1024):
+                if nw == 8 and blocks > 512: continue
+                def once(w=0):
+                    rc = l.tf_debug_probe(11, blocks, nw, big.data_ptr() + w * (px * 640), px * 640, px | (shape << 28), stream()); assert rc == 0, rc
+                nwin = max(1, min(4, (1 << 30) // (px * 640)))
+                once(); torch.cuda.synchronize()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for i in range(20): once(i % nwin)
+                b.record(); b.synchronize()
+                us = a.elapsed_time(b) / 20 * 1e3
+                print(f"wave-stream probe {tag}, {where}: {nw} waves x {blocks:4d} blocks: {us:6.1f} us  {px * (inb + outb) / us / 1e6:5.2f} TB/s", flush=True)

@@ -1250,3 +1250,121 @@ def test_conv_pwx_bn_forward_prologue(case):
     ref = torch.relu(bn(xs, 0) + (bn(rs, 1) if ds else rs))
     assert err(one[0].float().view(M, K).cpu(), ref.cpu())[0] < 4e-2
     assert err(one[1].float().view(M, Co).cpu(), one[0].float().view(M, K).cpu() @ q(w0, dt)[:, :, 0, 0].t())[2] < 6e-3
+
+
+# ------------------------------------------------------------------ wave-autonomous streaming pointwise kernel (round 5, csrc/conv_pws.hip)
+PWS_SHAPES = [(64, 256), (256, 64), (64, 64), (256, 128)]
+
+
+@pytest.mark.parametrize("dtype", HALF)
+@pytest.mark.parametrize("shape", PWS_SHAPES)
+def test_conv_pws_against_the_tiled_kernel(dtype, shape):
+    """r5, csrc/conv_pws.hip (tile code 70): the persistent wave-streaming pointwise conv for the short-K / large-M launches == the tiled
+    LDS-DMA kernel (tile 13) on the same operands -- same products, another summation order -- for every epilogue set it takes: plain,
+    STATS with a shift (sum of the rows = the tile kernel's), AFFINE + RELU, AFFINE, AFFINE + RES + RELU, MASK + STATS2; M = 16 637 pixels
+    (not a multiple of the 16-pixel wave tile: a ragged last tile; 1040 tiles over 4 x 256 waves: most waves own one tile, some none);
+    and against torch on exactly representable operands.  fp16: the inference sets only."""
+    from tinyfaces import _hip, ops
+    Cin, Cout = shape
+    N, H, W = 1, 127, 131
+    M = N * H * W
+    g = _g(Cin * 3 + Cout)
+    x = torch.randn(N, H, W, Cin, generator=g).to(dtype).cuda()
+    w0 = torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5
+    wp = ops.pack_weight(w0.cuda(), dtype)
+    aux = (torch.randn(N, H, W, Cout, generator=g) * 0.7).to(dtype).cuda()
+    sc, sh = (torch.rand(Cout, generator=g) + 0.5).cuda(), (torch.randn(Cout, generator=g) * 0.2).cuda()
+    ref = torch.einsum("nhwk,ck->nhwc", x.float().cpu(), q(w0, dtype)[:, :, 0, 0])
+    E = _hip
+    sets = [("plain", 0, {}), ("affine_relu", E.EPI_AFFINE | E.EPI_RELU, dict(epi_scale=sc, epi_shift=sh)), ("affine", E.EPI_AFFINE, dict(epi_scale=sc, epi_shift=sh))]
+    if not (shape == (256, 128)):
+        sets.append(("affine_res_relu", E.EPI_AFFINE | E.EPI_RES | E.EPI_RELU, dict(epi_scale=sc, epi_shift=sh, aux=aux)))
+    if dtype == torch.float16:
+        sets = [s for s in sets if s[0] != "plain"]
+    worst = {}
+    for name, epi, kw in sets:
+        a = ops.conv2d_nhwc(x, wp, Cout, 1, 1, 1, 0, epi=epi, tile=13, **kw)
+        b = ops.conv2d_nhwc(x, wp, Cout, 1, 1, 1, 0, epi=epi, tile=70, **kw)
+        worst[name] = err(b.float().cpu(), a.float().cpu())[2]
+        assert worst[name] < TOL_H[dtype], (name, worst[name])
+        if name == "plain":
+            assert err(b.float().cpu(), ref)[2] < TOL_H[dtype]
+        if name == "affine_res_relu":
+            want = torch.relu(ref * sc.cpu() + sh.cpu() + aux.float().cpu())
+            assert err(b.float().cpu(), want)[2] < TOL_H[dtype]
+    if dtype == torch.bfloat16:
+        shift = (torch.randn(Cout, generator=g) * 0.1).cuda()
+        # STATS with a shift: rows of the statistic buffer differ (tiles vs blocks), their sums must agree
+        def stats(tile, epi, **kw):
+            import ctypes as C
+            a = E.ConvArgs()
+            a.dtype, a.mode = E.TF_BF16, 0
+            a.N, a.H, a.W, a.Cin, a.OH, a.OW, a.Cout, a.KH, a.KW, a.stride, a.pad = N, H, W, Cin, H, W, Cout, 1, 1, 1, 0
+            a.ldy, a.epi, a.tile = Cout, epi, tile
+            y = torch.empty(N, H, W, Cout, dtype=dtype, device="cuda")
+            rows = E.lib().tf_conv_mtiles(C.byref(a))
+            st = torch.zeros(rows, 2, Cout, device="cuda")
+            so = torch.zeros(Cout, device="cuda")
+            a.x, a.w, a.y, a.stat_out = E.ptr(x), E.ptr(wp), E.ptr(y), E.ptr(st)
+            for k_, v_ in kw.items():
+                setattr(a, k_, E.ptr(v_))
+            if epi == E.EPI_STATS:
+                a.stat_shift_out = E.ptr(so)
+            rc = E.lib().tf_conv2d(C.byref(a), E.stream())
+            assert rc == 0, (tile, epi, rc)
+            torch.cuda.synchronize()
+            return y, st.sum(0), so, rows
+        y13, s13, o13, r13 = stats(13, E.EPI_STATS, stat_shift=shift)
+        y70, s70, o70, r70 = stats(70, E.EPI_STATS, stat_shift=shift)
+        assert r70 == E.lib().tf_get_stat_rows() and torch.equal(o13, o70) and torch.equal(o70, shift)
+        worst["stats_y"] = err(y70.float().cpu(), y13.float().cpu())[2]
+        worst["stats_sum"] = float((s70 - s13).abs().max() / s13.abs().max())
+        assert worst["stats_y"] < TOL_H[dtype] and worst["stats_sum"] < 2e-3
+        if shape != (256, 128):
+            ms, mh = (torch.rand(Cout, generator=g) + 0.5).cuda(), (torch.randn(Cout, generator=g) * 0.2).cuda()
+            y13, s13, _, _ = stats(13, E.EPI_MASK | E.EPI_STATS2, aux=aux, mask_scale=ms, mask_shift=mh)
+            y70, s70, _, _ = stats(70, E.EPI_MASK | E.EPI_STATS2, aux=aux, mask_scale=ms, mask_shift=mh)
+            worst["mask_y"] = err(y70.float().cpu(), y13.float().cpu())[2]
+            worst["mask_sum"] = float((s70 - s13).abs().max() / s13.abs().max())
+            # (a mask decision on a value within rounding of zero may differ between the two summation orders: a handful of elements)
+            assert float((y70 != y13).float().mean()) < 0.2 and worst["mask_sum"] < 5e-3
+            want = torch.where(aux.float().cpu() * ms.cpu() + mh.cpu() > 0, ref, torch.zeros_like(ref))
+            assert err(y70.float().cpu(), want)[2] < TOL_H[dtype]
+        if Cin == 64:
+            # the hand-over sets of conv1's data gradient: + residual gradient, masked by ReLU of the previous block's output, BN3-backward sums with its c3
+            yprev = torch.randn(N, H, W, Cout, generator=g).to(dtype).cuda()
+            c3 = (torch.randn(N, H, W, Cout, generator=g) * 1.2).to(dtype).cuda()
+            full = E.EPI_RES | E.EPI_MASK2 | E.EPI_STATS3
+            y13, s13, _, _ = stats(13, full, aux=aux, aux2=yprev, aux3=c3)
+            y70, s70, _, _ = stats(70, full, aux=aux, aux2=yprev, aux3=c3)
+            worst["handover_y"] = err(y70.float().cpu(), y13.float().cpu())[2]
+            worst["handover_sum"] = float((s70 - s13).abs().max() / s13.abs().max())
+            assert worst["handover_y"] < TOL_H[dtype] and worst["handover_sum"] < 2e-3
+            want = torch.where(yprev.float().cpu() > 0, ref + aux.float().cpu(), torch.zeros_like(ref))
+            assert err(y70.float().cpu(), want)[2] < TOL_H[dtype]
+            for epi, kw in ((E.EPI_RES | E.EPI_MASK2, dict(aux=aux, aux2=yprev)), (E.EPI_RES, dict(aux=aux))):
+                a_ = ops.conv2d_nhwc(x, wp, Cout, 1, 1, 1, 0, epi=epi, tile=13, **kw)
+                b_ = ops.conv2d_nhwc(x, wp, Cout, 1, 1, 1, 0, epi=epi, tile=70, **kw)
+                assert err(b_.float().cpu(), a_.float().cpu())[2] < TOL_H[dtype], epi
+    report(f"conv_pws[{dtype},{shape}]", **worst)
+
+
+def test_conv_pws_is_what_the_dispatcher_picks_for_the_layer1_streams():
+    """tile = 0 (auto): the short-K / large-M pointwise launches go to the streaming kernel, everything else stays where it was; a shape or
+    epilogue it does not take is refused when asked for explicitly."""
+    from tinyfaces import _hip, ops
+    x = torch.randn(1, 130, 130, 64, device="cuda").to(torch.bfloat16)
+    wp = ops.pack_weight(torch.randn(256, 64, 1, 1, device="cuda") / 8, torch.bfloat16)
+    _hip.lib().tf_profile_enable(1)
+    ops.conv2d_nhwc(x, wp, 256, 1, 1, 1, 0)                                           # M = 16 900, 64 -> 256: streams
+    ops.conv2d_nhwc(x[:, :100], wp, 256, 1, 1, 1, 0)                                  # M = 13 000 < 16 384: tiled
+    torch.cuda.synchronize()
+    _hip.lib().tf_profile_enable(0)
+    import ctypes as C
+    rows = (C.c_double * (24 * 6))()
+    n = _hip.lib().tf_profile_collect(rows, 24)
+    kinds = {int(rows[i * 6]): int(rows[i * 6 + 1]) for i in range(n)}
+    assert kinds.get(23) == 1 and kinds.get(13) == 1, kinds
+    w512 = ops.pack_weight(torch.randn(512, 64, 1, 1, device="cuda") / 8, torch.bfloat16)
+    with pytest.raises(RuntimeError):
+        ops.conv2d_nhwc(x, w512, 512, 1, 1, 1, 0, tile=70)                            # 64 -> 512: not one of its shapes

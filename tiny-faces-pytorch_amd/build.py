@@ -53,7 +53,7 @@ def build(force=False, verbose=True):
             if out.strip() and verbose:
                 print(out)
     objs = [os.path.join(OBJ, f[:-4] + ".o") for f in srcs]
-    if force or jobs or not os.path.exists(LIB):
+    if force or jobs or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):     # (an object built by hand counts)
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", f"-Wl,--version-script={EXPORTS}", "-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:

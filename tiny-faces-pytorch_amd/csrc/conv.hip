@@ -16,6 +16,8 @@ int tf_conv3x3h_launch(const tf_conv_args* a, hipStream_t stream);
 bool tf_conv_pwx_applicable(const tf_conv_args* a);                                            // conv_pwx.hip
 int tf_conv_pwx_mtiles(const tf_conv_args* a);
 int tf_conv_pwx_launch(const tf_conv_args* a, const tf_bn_bwd_desc* pro, const void* pro_x2, void* pro_out, int pro_rows, float pro_count, hipStream_t stream);
+bool tf_conv_pws_applicable(const tf_conv_args* a);                                            // conv_pws.hip
+int tf_conv_pws_launch(const tf_conv_args* a, hipStream_t stream);
 int tf_conv_pwx_launch_fwd(const tf_conv_args* a, const tf_bn_fwd_desc* bn, const void* res, const tf_bn_fwd_desc* bn_res, void* y_out, int rows, float count,
                            float eps, float momentum, hipStream_t stream);
 
@@ -25,6 +27,10 @@ int pick_tile(const tf_conv_args* a) {
   if (a->tile) return a->tile;
   // 60 = conv_pwx (8 waves, 64 pixels x all output channels, register-staged pixel operand): only on request so far
   // (TINYFACES_PWX_FWD=1: the pointwise convs with 128 / 256 output channels and K >= 128, A/B knob)
+  // 70 = conv_pws (r5): wave-autonomous streaming kernel for the short-K / large-M pointwise launches (layer 1, the large pyramid levels);
+  // TINYFACES_PWS_OFF=1: the tiled kernel as in rounds 1-4
+  static const bool pws_off = getenv("TINYFACES_PWS_OFF") != nullptr;
+  if (!pws_off && tf_conv_pws_applicable(a)) return 70;
   static const bool pwx_fwd = getenv("TINYFACES_PWX_FWD") != nullptr;
   if (pwx_fwd && tf_conv_pwx_applicable(a) && a->Cin >= 512) return 60;
   // measured on the bs=12 500x500 layer shapes (scripts/microbench.py): 128 pixels x 64 channels wins on every
@@ -71,6 +77,7 @@ extern "C" int tf_conv_mtiles(const tf_conv_args* a) {
   const int t = pick_tile(a);
   if (t == 50) { const int mt = tf_conv3x3h_mtiles(a); return mt > tf_get_stat_rows() ? tf_get_stat_rows() : mt; }
   if (t == 60) { const int mt = tf_conv_pwx_mtiles(a); return mt > tf_get_stat_rows() ? tf_get_stat_rows() : mt; }
+  if (t == 70) return tf_get_stat_rows();            // (only chosen with folded rows: its blocks add into row blockIdx % rows)
   const int bm = tile_bm(t);
   const int mt = (int)((M + bm - 1) / bm);
   return (t >= 10 && mt > tf_get_stat_rows()) ? tf_get_stat_rows() : mt;     // the DMA kernel folds its tiles into <= TF_STAT_ROWS rows
@@ -100,6 +107,7 @@ extern "C" int tf_conv2d(const tf_conv_args* a, void* stream_) {
   if (a->bnf && !(t == 32 && a->mode == 0 && a->KH == 1 && a->KW == 1 && a->stride == 1 && a->Cin <= 256)) return TF_ERR_UNSUPPORTED;
   if (t == 50) return tf_conv3x3h_applicable(a, true) ? tf_conv3x3h_launch(a, stream) : TF_ERR_UNSUPPORTED;
   if (t == 60) return tf_conv_pwx_launch(a, nullptr, nullptr, nullptr, 0, 0.f, stream);
+  if (t == 70) return tf_conv_pws_launch(a, stream);
   if (t >= 10) {
     return tf_conv_dma_launch(a, t % 10, t >= 40 ? 2 : (t >= 30 ? 1 : (t >= 20 ? 4 : 3)), stream);
   }

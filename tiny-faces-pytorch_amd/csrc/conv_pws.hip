@@ -1,0 +1,348 @@
+// conv_pws (r5): WAVE-AUTONOMOUS streaming pointwise conv for the short-K / large-M launches of the trunk -- layer 1 at bs = 12
+// (M = 187 500 pixels, 64 <-> 256 channels), the stem-side layers of the large pyramid levels (M = 76 800 / 307 200).
+//
+// Why.  These launches are HBM streams with a tiny GEMM in the middle (120 MB moved for 6 GFLOP), and the tiled LDS-DMA kernel runs them at
+// 2.4-4.2 TB/s where an elementwise kernel reaches 5.5: 5860 short-lived blocks, each of which fetches the same 16 KiB weight tile again,
+// waits out a full memory round trip with nothing behind it, parks its accumulators in a block-wide staging tile and dies.  The memory
+// skeleton of the form below -- csrc/probe.hip kind 11, profiles/r05_conv_pws.txt -- moves the 64 -> 256 layer-1 tensor pair in 24 us
+// (4.95 TB/s) against 39 us for conv_dma.
+//
+// How.  A PERSISTENT block of four waves loads the whole weight matrix (K x N x 2 bytes <= 64 KiB) into LDS once.  After that every wave is
+// a pipeline of its own over tiles of 16 pixels dealt round-robin: LDS-DMA of the tile's input rows (and of the ONE epilogue operand a
+// mode may need: residual / mask tensor) into a private 2-slot ring, `s_waitcnt vmcnt(next tile's DMAs)`, 16x16x32 MFMAs against the
+// resident weights (accumulators: 4 consecutive channels of one pixel per lane), accumulators -> a private fp32 staging tile of 8 pixels ->
+// every lane finishes 8 channels of one pixel (affine / residual / ReLU / mask, statistic sums in registers across ALL its tiles) and stores
+// 16 bytes.  No block barrier after the weight load, no LDS shared between waves but the read-only weights: the only synchronisation of
+// the steady state is a wave's own vmcnt / lgkmcnt.  Statistic sums meet in LDS once at the end: one atomic per block and channel.
+// Epilogue sets (compile-time, as in conv_dma): STATS | AFFINE+RELU | AFFINE | AFFINE+RES+RELU | MASK+STATS2 | none, and for K = 64 the hand-over
+// sets of the data gradient of conv1 (RES+MASK2+STATS3, RES+MASK2, RES: up to three epilogue operands per tile -> two waves per block).
+// Replaces nn.Conv2d (1x1) + BN statistics / folded BN (+ residual + ReLU) of the torchvision Bottleneck (tinyfaces/models/model.py:90-101)
+// and the data gradient of conv3 for those shapes.  bf16 and fp16 operands.
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+#include "common.h"
+#include "lds_dma.h"
+#include "profile.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ uint4 g_pws_zero[8];
+
+constexpr int EPS = 8;
+
+struct PwK {
+  const char* x; const char* w; char* y; const char* aux; const char* aux2; const char* aux3;
+  const float* epi_scale; const float* epi_shift; const float* mask_scale; const float* mask_shift;
+  float* stat_out; const float* stat_shift; float* stat_shift_out;
+  int M, K, ntiles, srows, ldy;
+};
+
+__device__ __forceinline__ int swz(int row) { return ((row >> 1) & 1) ^ (((row >> 2) & 1) << 2) ^ (((row >> 3) & 1) * 6); }
+__device__ __forceinline__ int lds_off(int row, int slot) { return row * 128 + ((slot ^ swz(row)) << 4); }
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <typename T> struct Fr;
+template <> struct Fr<tf::bf16_t> {
+  typedef bf16x8 t;
+  __device__ static __forceinline__ f32x4 mma(t a, t b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct Fr<tf::f16_t> {
+  typedef f16x8 t;
+  __device__ static __forceinline__ f32x4 mma(t a, t b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+
+// KS = K / 64 (64-deep k stages), NF = N / 16 (16-channel accumulator tiles per wave)
+// NW = waves per block: 4, or 2 where the epilogue operands of a tile (up to three 16 x N tensors, double-buffered) leave no room for more
+template <typename T, int KS, int NF, int EPIC, int NW>
+__global__ void __launch_bounds__(NW * 64) conv_pws_kernel(const PwK a) {
+  typedef typename Fr<T>::t frag;
+  constexpr int N = NF * 16, K = KS * 64;
+  constexpr int NAUX = ((EPIC & (TF_EPI_RES | TF_EPI_MASK | TF_EPI_STATS2)) ? 1 : 0) + ((EPIC & TF_EPI_MASK2) ? 1 : 0) + ((EPIC & TF_EPI_STATS3) ? 1 : 0);
+  constexpr bool HAS_AUX = NAUX > 0;
+  constexpr bool HAS_STATS = (EPIC & (TF_EPI_STATS | TF_EPI_STATS2 | TF_EPI_STATS3)) != 0;
+  constexpr int SLAB = KS * N * 128;                // weights: [k stage][N rows][128 B], swizzled like every operand tile of the conv kernels
+  constexpr int XT = KS * 2048;                     // input tile of a wave: [k stage][16 pixels][128 B]
+  constexpr int AUXT = 16 * N * 2;                  // epilogue operand of a tile: 16 pixel rows, plain
+  constexpr int PITCH = N + 4, STG = 8 * PITCH * 4; // staging: 8 pixels x N fp32
+  constexpr int PER = 2 * XT + 2 * NAUX * AUXT + STG;
+  constexpr int NIX = 2 * KS, NI1 = AUXT / 1024, NIA = NAUX * NI1;  // DMA instructions per tile
+  constexpr int CPR = N / EPS, RPP = 64 / CPR, NPASS = 8 / RPP;     // 16-byte chunks per pixel row, rows per pass, passes per 8 pixels
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t smem_u = tf::lds_addr_uniform(smem);
+  const char* zero = reinterpret_cast<const char*>(g_pws_zero) + (lane & 7) * 16;
+
+  // ---- the weights, once: N x KS rows of 128 B, 8 rows per wave-level DMA
+  for (int i = wave; i < KS * N / 8; i += NW) {
+    const int ks = i / (N / 8), rb = i - ks * (N / 8), row = rb * 8 + (lane >> 3);
+    tf::dma16_hidden(a.w + ((size_t)row * K + ks * 64) * sizeof(T) + (((lane & 7) ^ swz(row)) << 4), smem_u + ks * (N * 128) + rb * 1024);
+  }
+
+  // ---- per-lane constants of the store phase: lane -> 8 channels c0 .. c0+7 of pixel rows (lane / CPR) + RPP * pass
+  const int chunk = lane % CPR, prow = lane / CPR, c0 = chunk * EPS;
+  float es[EPS], eh[EPS], ms[EPS], mh[EPS], sft[EPS], s1[EPS], s2[EPS];
+#pragma unroll
+  for (int j = 0; j < EPS; ++j) { es[j] = 1.f; eh[j] = 0.f; ms[j] = 0.f; mh[j] = 0.f; sft[j] = 0.f; s1[j] = 0.f; s2[j] = 0.f; }
+  if constexpr ((EPIC & TF_EPI_AFFINE) != 0) {
+#pragma unroll
+    for (int j = 0; j < EPS; ++j) { es[j] = a.epi_scale[c0 + j]; eh[j] = a.epi_shift[c0 + j]; }
+  }
+  if constexpr ((EPIC & TF_EPI_MASK) != 0) {
+#pragma unroll
+    for (int j = 0; j < EPS; ++j) { ms[j] = a.mask_scale[c0 + j]; mh[j] = a.mask_shift[c0 + j]; }
+  }
+  if constexpr ((EPIC & TF_EPI_STATS) != 0) {
+    if (a.stat_shift) {
+#pragma unroll
+      for (int j = 0; j < EPS; ++j) sft[j] = a.stat_shift[c0 + j];
+    }
+  }
+
+  // ---- this wave's private LDS and its tile walk
+  const uint32_t mine_u = smem_u + SLAB + wave * PER;
+  char* const mine = smem + SLAB + wave * PER;
+  const int stride = gridDim.x * NW;
+  int t = blockIdx.x * NW + wave;
+  auto issue = [&](int tile, int slot) {
+    const int p0 = tile * 16;
+    const bool live = tile < a.ntiles;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = i * 8 + (lane >> 3);
+        const bool ok = live && p0 + row < a.M;
+        tf::dma16_hidden(ok ? a.x + ((size_t)(p0 + row) * K + ks * 64) * sizeof(T) + (((lane & 7) ^ swz(row)) << 4) : zero,
+                         mine_u + slot * XT + ks * 2048 + i * 1024);
+      }
+    if constexpr (HAS_AUX) {
+#pragma unroll
+      for (int q = 0; q < NAUX; ++q) {
+        const char* src = q == 0 ? a.aux : (q == 1 ? a.aux2 : a.aux3);
+#pragma unroll
+        for (int i = 0; i < NI1; ++i) {
+          const int byte = i * 1024 + lane * 16, row = byte / (N * 2);
+          const bool ok = live && p0 + row < a.M;
+          tf::dma16_hidden(ok ? src + (size_t)p0 * a.ldy * sizeof(T) + (size_t)row * (a.ldy - N) * sizeof(T) + byte : zero,
+                           mine_u + 2 * XT + (slot * NAUX + q) * AUXT + i * 1024);
+        }
+      }
+    }
+  };
+  issue(t, 0);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIX + NIA) : "memory");     // the weight pieces this wave requested (they were issued before the first tile)
+  __syncthreads();                                                      // everyone's pieces of the weights are in LDS: the only block barrier of the loop
+
+  const int r = lane & 15, g = lane >> 4;
+  float* const stg = reinterpret_cast<float*>(mine + 2 * XT + 2 * NAUX * AUXT);
+  int slot = 0;
+  for (; t < a.ntiles; t += stride) {
+    issue(t + stride, slot ^ 1);                    // (past the end: zero-page pieces into the free slot, the wait count stays a constant)
+    wait_vmcnt<NIX + NIA>();                        // this tile's pieces landed; only the next tile's may fly (older stores retire first: in order)
+    f32x4 acc[NF];
+#pragma unroll
+    for (int n = 0; n < NF; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const char* xs = mine + slot * XT;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const frag xf = *reinterpret_cast<const frag*>(xs + ks * 2048 + lds_off(r, kk * 4 + g));
+#pragma unroll
+        for (int n = 0; n < NF; ++n) {
+          const frag wf = *reinterpret_cast<const frag*>(smem + ks * (N * 128) + lds_off(n * 16 + r, kk * 4 + g));
+          acc[n] = Fr<T>::mma(wf, xf, acc[n]);
+        }
+      }
+    // ---- epilogue, 8 pixels at a time: lane (pixel r, channel quad g of every 16-channel tile) parks, lane (row prow, chunk) finishes
+    const int p0 = t * 16;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      if ((r >> 3) == half) {
+#pragma unroll
+        for (int n = 0; n < NF; ++n) *reinterpret_cast<f32x4*>(stg + (r & 7) * PITCH + n * 16 + g * 4) = acc[n];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // (one wave: LDS executes its accesses in order; the wait orders the compiler)
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ++ps) {
+        const int row8 = ps * RPP + prow, row = half * 8 + row8, p = p0 + row;
+        float v[EPS];
+        {
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + row8 * PITCH + c0), hi = *reinterpret_cast<const f32x4*>(stg + row8 * PITCH + c0 + 4);
+          v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+        }
+        float ax[EPS], y2[EPS], x3[EPS];
+        const char* auxb = mine + 2 * XT + slot * NAUX * AUXT + row * (N * 2) + chunk * 16;
+        if constexpr (HAS_AUX) tf::unpack16<T>(*reinterpret_cast<const uint4*>(auxb), ax);
+        if constexpr ((EPIC & TF_EPI_MASK2) != 0) tf::unpack16<T>(*reinterpret_cast<const uint4*>(auxb + AUXT), y2);
+        if constexpr ((EPIC & TF_EPI_STATS3) != 0) tf::unpack16<T>(*reinterpret_cast<const uint4*>(auxb + (NAUX - 1) * AUXT), x3);
+        if (p < a.M) {
+          if constexpr ((EPIC & TF_EPI_STATS) != 0) {
+#pragma unroll
+            for (int j = 0; j < EPS; ++j) { const float d = v[j] - sft[j]; s1[j] += d; s2[j] += d * d; }
+          }
+          if constexpr ((EPIC & TF_EPI_AFFINE) != 0) {
+#pragma unroll
+            for (int j = 0; j < EPS; ++j) v[j] = v[j] * es[j] + eh[j];
+          }
+          if constexpr ((EPIC & TF_EPI_RES) != 0) {
+#pragma unroll
+            for (int j = 0; j < EPS; ++j) v[j] += ax[j];
+          }
+          if constexpr ((EPIC & TF_EPI_MASK) != 0) {
+#pragma unroll
+            for (int j = 0; j < EPS; ++j) v[j] = (ax[j] * ms[j] + mh[j] > 0.f) ? v[j] : 0.f;
+          }
+          if constexpr ((EPIC & TF_EPI_MASK2) != 0) {
+#pragma unroll
+            for (int j = 0; j < EPS; ++j) v[j] = (y2[j] > 0.f) ? v[j] : 0.f;
+          }
+          if constexpr ((EPIC & TF_EPI_RELU) != 0) {
+#pragma unroll
+            for (int j = 0; j < EPS; ++j) v[j] = fmaxf(v[j], 0.f);
+          }
+          if constexpr ((EPIC & TF_EPI_STATS2) != 0) {
+#pragma unroll
+            for (int j = 0; j < EPS; ++j) { s1[j] += v[j]; s2[j] += v[j] * ax[j]; }
+          }
+          if constexpr ((EPIC & TF_EPI_STATS3) != 0) {
+#pragma unroll
+            for (int j = 0; j < EPS; ++j) { s1[j] += v[j]; s2[j] += v[j] * x3[j]; }
+          }
+          *reinterpret_cast<uint4*>(a.y + ((size_t)p * a.ldy + c0) * sizeof(T)) = tf::pack16<T>(v);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // the staging tile is consumed before the other half overwrites it
+    }
+    slot ^= 1;
+  }
+  wait_vmcnt<0>();
+
+  // ---- statistic sums: lanes sharing a chunk -> one value per wave, the four waves meet in LDS, ONE atomic per block, sum and channel
+  if constexpr (HAS_STATS) {
+#pragma unroll
+    for (int j = 0; j < EPS; ++j) { s1[j] = tf::lane_group_sum<(CPR < 64 ? CPR : 64)>(s1[j]); s2[j] = tf::lane_group_sum<(CPR < 64 ? CPR : 64)>(s2[j]); }
+    __syncthreads();                                 // every wave left its loop: the private regions can be reused
+    float* red = reinterpret_cast<float*>(smem + SLAB);     // [NW][2][N]
+    if (lane < CPR) {
+#pragma unroll
+      for (int j = 0; j < EPS; ++j) { red[(wave * 2 + 0) * N + lane * EPS + j] = s1[j]; red[(wave * 2 + 1) * N + lane * EPS + j] = s2[j]; }
+    }
+    __syncthreads();
+    const int srow = blockIdx.x % a.srows;
+    for (int e = tid; e < 2 * N; e += NW * 64) {
+      const int k = e / N, c = e - k * N;
+      float v = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < NW; ++wv) v += red[(wv * 2 + k) * N + c];
+      atomicAdd(&a.stat_out[((size_t)srow * 2 + k) * a.ldy + c], v);
+    }
+    if ((EPIC & TF_EPI_STATS) && a.stat_shift && a.stat_shift_out && blockIdx.x == 0)
+      for (int c = tid; c < N; c += NW * 64) a.stat_shift_out[c] = a.stat_shift[c];
+  }
+}
+
+template <typename T, int KS, int NF, int EPIC>
+int launch_one(const tf_conv_args* A, const PwK& k, hipStream_t stream) {
+  constexpr int N = NF * 16;
+  constexpr int NAUX = ((EPIC & (TF_EPI_RES | TF_EPI_MASK | TF_EPI_STATS2)) ? 1 : 0) + ((EPIC & TF_EPI_MASK2) ? 1 : 0) + ((EPIC & TF_EPI_STATS3) ? 1 : 0);
+  constexpr size_t per = 2 * KS * 2048 + 2 * NAUX * 16 * N * 2 + 8 * (N + 4) * 4;
+  constexpr size_t slab = (size_t)KS * N * 128;
+  constexpr int NW = slab + 4 * per <= 160 * 1024 ? 4 : 2;         // four waves per block where their private rings fit beside the weights, else two
+  constexpr size_t lds = slab + NW * per;
+  if constexpr (lds > 160 * 1024) return TF_ERR_UNSUPPORTED;       // (256 -> 128 with an epilogue operand: tf_conv_pws_applicable refuses it)
+  else {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pws_kernel<T, KS, NF, EPIC, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  // persistent grid: as many blocks as fit (LDS decides), at most one wave per tile
+  static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+  const int per_cu = (int)((160 * 1024) / lds) < 1 ? 1 : (int)((160 * 1024) / lds);
+  int blocks = cus * (per_cu > 2 ? 2 : per_cu);
+  const int need = (k.ntiles + NW - 1) / NW;
+  if (blocks > need) blocks = need;
+  const double M = k.M, es = sizeof(T);
+  const double bytes = (M * k.K + (double)N * k.K + M * N * (1 + NAUX)) * es;
+  const double alg_k = A->alg_k > 0 ? A->alg_k : k.K, alg_n = A->alg_n > 0 ? A->alg_n : N;
+  tf::ProfScope prof(23, 2.0 * M * alg_n * alg_k, bytes, stream, k.M, N, k.K, 1, A->mode, A->epi, 2.0 * M * N * k.K, true);     // 23 = conv_pws
+  TF_LAUNCH_TIMED((conv_pws_kernel<T, KS, NF, EPIC, NW>), dim3(blocks), dim3(NW * 64), lds, stream, k);
+  return hipGetLastError() == hipSuccess ? TF_OK : TF_ERR_LAUNCH;
+  }
+}
+
+template <typename T, int KS, int NF>
+int launch_epi(const tf_conv_args* A, const PwK& k, hipStream_t stream) {
+  const bool train = std::is_same<T, tf::bf16_t>::value;
+  switch (A->epi) {
+    case TF_EPI_AFFINE | TF_EPI_RELU: return launch_one<T, KS, NF, TF_EPI_AFFINE | TF_EPI_RELU>(A, k, stream);
+    case TF_EPI_AFFINE: return launch_one<T, KS, NF, TF_EPI_AFFINE>(A, k, stream);
+    case TF_EPI_AFFINE | TF_EPI_RES | TF_EPI_RELU: return launch_one<T, KS, NF, TF_EPI_AFFINE | TF_EPI_RES | TF_EPI_RELU>(A, k, stream);
+    default: break;
+  }
+  if constexpr (std::is_same<T, tf::bf16_t>::value) {       // the training sets: bf16 only (fp16 is inference only)
+    if (A->epi == TF_EPI_STATS) return launch_one<T, KS, NF, TF_EPI_STATS>(A, k, stream);
+    if (A->epi == (TF_EPI_MASK | TF_EPI_STATS2)) return launch_one<T, KS, NF, TF_EPI_MASK | TF_EPI_STATS2>(A, k, stream);
+    if (A->epi == 0) return launch_one<T, KS, NF, 0>(A, k, stream);
+    if constexpr (KS == 1) {                               // the hand-over data gradients of conv1 (planes -> 4 planes / planes): layer 1
+      if (A->epi == (TF_EPI_RES | TF_EPI_MASK2 | TF_EPI_STATS3)) return launch_one<T, KS, NF, TF_EPI_RES | TF_EPI_MASK2 | TF_EPI_STATS3>(A, k, stream);
+      if (A->epi == (TF_EPI_RES | TF_EPI_MASK2)) return launch_one<T, KS, NF, TF_EPI_RES | TF_EPI_MASK2>(A, k, stream);
+      if (A->epi == TF_EPI_RES) return launch_one<T, KS, NF, TF_EPI_RES>(A, k, stream);
+    }
+  }
+  (void)train;
+  return TF_ERR_UNSUPPORTED;
+}
+
+template <typename T>
+int launch(const tf_conv_args* A, hipStream_t stream) {
+  PwK k;
+  k.x = (const char*)A->x; k.w = (const char*)A->w; k.y = (char*)A->y; k.aux = (const char*)A->aux; k.aux2 = (const char*)A->aux2; k.aux3 = (const char*)A->aux3;
+  k.epi_scale = A->epi_scale; k.epi_shift = A->epi_shift; k.mask_scale = A->mask_scale; k.mask_shift = A->mask_shift;
+  k.stat_out = A->stat_out; k.stat_shift = A->stat_shift; k.stat_shift_out = A->stat_shift_out;
+  k.M = A->N * A->OH * A->OW; k.K = A->Cin; k.ntiles = (k.M + 15) / 16; k.srows = tf_get_stat_rows(); k.ldy = A->ldy;
+  const int ks = A->Cin / 64, nf = A->Cout / 16;
+  if (ks == 1 && nf == 16) return launch_epi<T, 1, 16>(A, k, stream);     // 64 -> 256: conv3 / downsample of layer 1
+  if (ks == 4 && nf == 4) return launch_epi<T, 4, 4>(A, k, stream);       // 256 -> 64: conv1 of layer 1, the data gradient of its conv3
+  if (ks == 1 && nf == 4) return launch_epi<T, 1, 4>(A, k, stream);       // 64 -> 64: conv1 of layer1.0
+  if (ks == 4 && nf == 8) return launch_epi<T, 4, 8>(A, k, stream);       // 256 -> 128: conv1 of layer2.0
+  return TF_ERR_UNSUPPORTED;
+}
+
+bool epi_ok(const tf_conv_args* a) {
+  switch (a->epi) {
+    case TF_EPI_AFFINE | TF_EPI_RELU: case TF_EPI_AFFINE: case TF_EPI_AFFINE | TF_EPI_RES | TF_EPI_RELU: return true;
+    case TF_EPI_STATS: case TF_EPI_MASK | TF_EPI_STATS2: case 0: return a->dtype == TF_BF16;
+    case TF_EPI_RES | TF_EPI_MASK2 | TF_EPI_STATS3: case TF_EPI_RES | TF_EPI_MASK2: case TF_EPI_RES: return a->dtype == TF_BF16 && a->Cin == 64;
+    default: return false;
+  }
+}
+
+}  // namespace
+
+// pointwise (1x1, stride 1, pad 0) conv / data gradient with 2-byte operands, (Cin, Cout) in {(64, 256), (256, 64), (64, 64), (256, 128)},
+// ldy == Cout, one of the epilogue sets above, and enough pixels that the launch is a stream (M >= 16 384)
+bool tf_conv_pws_applicable(const tf_conv_args* a) {
+  if (a->dtype != TF_BF16 && a->dtype != TF_F16) return false;
+  if (a->pro_scale || a->bnf) return false;
+  if (a->KH != 1 || a->KW != 1 || a->stride != 1 || a->pad != 0 || a->H != a->OH || a->W != a->OW) return false;
+  if (a->ldy != a->Cout || !epi_ok(a)) return false;
+  // statistic sums are folded into <= TF_STAT_ROWS rows by atomics: the bit-reproducible flow (tf_set_stat_rows(0): one row per tile) keeps conv_dma
+  if ((a->epi & (TF_EPI_STATS | TF_EPI_STATS2 | TF_EPI_STATS3)) && tf_get_stat_rows() > TF_STAT_ROWS) return false;
+  const int ks = a->Cin / 64, nf = a->Cout / 16;
+  if (a->Cin % 64 || a->Cout % 16) return false;
+  if (!((ks == 1 && nf == 16) || (ks == 4 && nf == 4) || (ks == 1 && nf == 4) || (ks == 4 && nf == 8))) return false;
+  if (ks == 4 && nf == 8 && (a->epi & (TF_EPI_RES | TF_EPI_MASK | TF_EPI_STATS2))) return false;      // 64 KiB of weights: no room for an operand ring
+  return (long)a->N * a->OH * a->OW >= 16384;
+}
+int tf_conv_pws_launch(const tf_conv_args* a, hipStream_t stream) {
+  if (!tf_conv_pws_applicable(a)) return TF_ERR_UNSUPPORTED;
+  return a->dtype == TF_BF16 ? launch<tf::bf16_t>(a, stream) : launch<tf::f16_t>(a, stream);
+}

@@ -193,6 +193,48 @@ __global__ void __launch_bounds__(256) tile_probe_kernel(const char* buf, size_t
   }
 }
 
+// kind 11 (r5): the memory skeleton of a WAVE-AUTONOMOUS streaming pointwise conv (short K, large M: layer 1, the large pyramid levels).  Every wave
+// of a persistent block owns tiles of 16 pixels: it pulls the tile's input rows (16 x IN bytes) through a private 2-slot LDS ring by LDS-DMA, reads them
+// back, writes a 16 x OUT-byte result tile into a private staging area and stores it with 16-byte stores -- no block barrier, only its own counted waits.
+// IN / OUT in bytes per pixel: 128 / 512 = the 64 -> 256 conv of layer 1, 512 / 128 = 256 -> 64.  Grid = blocks of NW waves, tiles dealt round-robin.
+template <int IN, int OUT>
+__global__ void __launch_bounds__(512) wave_stream_probe_kernel(const char* src, char* dst, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int XT = 16 * IN, ST = 16 * OUT, PER = 2 * XT + ST;       // ring of two input tiles + one staging tile per wave
+  constexpr int NI = XT / 1024;                                        // DMA instructions per tile (1 KiB each)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+  char* mine = smem + wave * PER;
+  const int stride = gridDim.x * nw;
+  int t = blockIdx.x * nw + wave;
+  auto issue = [&](int tile, int slot) {
+    const char* g = src + (size_t)(tile < ntiles ? tile : 0) * XT + lane * 16;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      typedef __attribute__((address_space(3))) void lds_void;
+      typedef __attribute__((address_space(1))) const void glb_void;
+      __builtin_amdgcn_global_load_lds((glb_void*)(g + i * 1024), (lds_void*)(mine + slot * XT + i * 1024), 16, 0, 0);
+    }
+  };
+  issue(t, 0);
+  int slot = 0;
+  uint4 acc = make_uint4(0, 0, 0, 0);
+  for (; t < ntiles; t += stride) {
+    issue(t + stride, slot ^ 1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");         // this tile landed; the next one (and older stores) may fly
+#pragma unroll
+    for (int i = 0; i < NI; ++i) { const uint4 v = *reinterpret_cast<const uint4*>(mine + slot * XT + i * 1024 + lane * 16); acc.x += v.x; acc.y ^= v.y; acc.z += v.z; acc.w ^= v.w; }
+    char* stg = mine + 2 * XT;
+#pragma unroll
+    for (int i = 0; i < ST / 1024; ++i) *reinterpret_cast<uint4*>(stg + i * 1024 + lane * 16) = acc;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < ST / 1024; ++i)
+      *reinterpret_cast<uint4*>(dst + (size_t)t * ST + i * 1024 + lane * 16) = *reinterpret_cast<const uint4*>(stg + i * 1024 + lane * 16);
+    slot ^= 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 template <int KIND>
 int launch(int blocks, int lds, char* buf, size_t window, int iters, hipStream_t s) {
   static bool attr = false;
@@ -236,6 +278,21 @@ extern "C" int tf_debug_probe(int kind, int blocks, int lds_bytes, void* buf, si
       if (iters == 1) hipLaunchKernelGGL(tile_probe_kernel<1>, dim3(blocks), dim3(256), 0, s, b, mat, 16, rows);
       else if (iters == 2) hipLaunchKernelGGL(tile_probe_kernel<2>, dim3(blocks), dim3(256), 0, s, b, mat, 16, rows);
       else hipLaunchKernelGGL(tile_probe_kernel<3>, dim3(blocks), dim3(256), 0, s, b, mat, 16, rows);
+      return hipGetLastError() == hipSuccess ? TF_OK : TF_ERR_LAUNCH;
+    }
+    case 11: {                                              // iters = pixels | shape << 28 (0: 128 -> 512 B, 1: 512 -> 128 B per pixel) ; lds_bytes = waves per block (4 / 8)
+      const int shape = iters >> 28, px = iters & 0x0fffffff, nw = lds_bytes == 4 ? 4 : 8;
+      const int in = shape ? 512 : 128, out = shape ? 128 : 512, ntiles = px / 16;
+      if (window_bytes < (size_t)px * (in + out)) return TF_ERR_ARG;
+      const size_t l = (size_t)nw * (2 * 16 * in + 16 * out);
+      static bool a0 = false, a1 = false;
+      if (!shape) {
+        if (!a0) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wave_stream_probe_kernel<128, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a0 = true; }
+        hipLaunchKernelGGL((wave_stream_probe_kernel<128, 512>), dim3(blocks), dim3(nw * 64), l, s, b, b + (size_t)px * in, ntiles);
+      } else {
+        if (!a1) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wave_stream_probe_kernel<512, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a1 = true; }
+        hipLaunchKernelGGL((wave_stream_probe_kernel<512, 128>), dim3(blocks), dim3(nw * 64), l, s, b, b + (size_t)px * in, ntiles);
+      }
       return hipGetLastError() == hipSuccess ? TF_OK : TF_ERR_LAUNCH;
     }
     case 7: case 8:
