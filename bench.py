@@ -33,9 +33,9 @@ PEAK_HBM_GBS = 8000.0
 FWD_GFLOP_PER_IMG = 73.559                           # BASELINE.md section 3 (2*MACs of all 97 convs @500x500)
 PROFILE_EVERY = 23                                    # roofline timing: HIP events around every 23rd MFMA launch (287 launches per step is not a multiple: the sample rotates over the layers; 11 in rounds 1-2, ~1 % of the step)
 # kernel kinds of tf_profile_collect (csrc/profile.hip): the executor only launches 12-15; 0-11 are the register-staged kernels kept for the C ABI
-KIND_NAMES = {20: "stem_conv<bf16>", 21: "stem_conv<f16>", 22: "stem_wgrad<bf16>", 6: "conv3x3h<bf16>", 7: "conv3x3h<f16>", 12: "conv_dma<f32>", 13: "conv_dma<bf16>", 14: "wgrad_dma<bf16>", 15: "conv_dma<f16>", 16: "wgrad3x3<bf16>", 17: "conv_pwx<bf16>", 18: "wgrad_group<bf16>", 19: "wgrad3x3_group<bf16>",
+KIND_NAMES = {20: "stem_conv<bf16>", 21: "stem_conv<f16>", 22: "stem_wgrad<bf16>", 6: "conv3x3h<bf16>", 7: "conv3x3h<f16>", 12: "conv_dma<f32>", 13: "conv_dma<bf16>", 14: "wgrad_dma<bf16>", 15: "conv_dma<f16>", 16: "wgrad3x3<bf16>", 17: "conv_pwx<bf16>", 18: "wgrad_group<bf16>", 19: "wgrad3x3_group<bf16>", 23: "conv_pws<bf16|f16>",
               8: "wgrad<f32,64>", 9: "wgrad<f32,128>", 10: "wgrad<bf16,64>", 11: "wgrad<bf16,128>"}
-BF16_KINDS = (3, 4, 5, 6, 7, 10, 11, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22)
+BF16_KINDS = (3, 4, 5, 6, 7, 10, 11, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23)
 
 
 def tame_init_(model, seed=0):
@@ -160,7 +160,7 @@ def cpu_baseline(bs=12, warmup=2, steps=5, eval_warmup=1, eval_runs=5, threads=N
 PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")
 PMC_TRAFFIC_FILE_FP32 = os.path.join(ROOT, "profiles", "r05_pmc_traffic_fp32.json")
 PMC_PATTERNS = {6: ("conv3x3h_kernel<tf::bf16_t,",), 7: ("conv3x3h_kernel<tf::f16_t,",), 13: ("conv_dma_kernel<tf::bf16_t,",), 12: ("conv_dma_kernel<float,",), 15: ("conv_dma_kernel<tf::f16_t,",),
-                14: ("wgrad_dma_kernel",), 16: ("wgrad3x3_kernel",), 17: ("conv_pwx_kernel",), 18: ("wgrad_group_kernel", "wgrad_group_fast_kernel"), 20: ("stem_conv_kernel<tf::bf16_t,",), 21: ("stem_conv_kernel<tf::f16_t,",), 19: ("wgrad3x3_group_kernel",)}
+                14: ("wgrad_dma_kernel",), 16: ("wgrad3x3_kernel",), 17: ("conv_pwx_kernel",), 18: ("wgrad_group_kernel", "wgrad_group_fast_kernel"), 20: ("stem_conv_kernel<tf::bf16_t,",), 21: ("stem_conv_kernel<tf::f16_t,",), 19: ("wgrad3x3_group_kernel",), 23: ("conv_pws_kernel",)}
 
 
 def pmc_traffic(kind, path=None):

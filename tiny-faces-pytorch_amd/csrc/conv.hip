@@ -51,7 +51,10 @@ int pick_tile(const tf_conv_args* a) {
     // (not with the in-LDS BN prologue `bnf`: only the ring-less 128 x 64 tile implements it -- ADVICE r3)
     // (TINYFACES_SHORTK_BIG_TILE: A/B knob -- another tile code for these launches, e.g. 44 = 128 x 128 / 45 = 128 x 64 on the same fragments)
     static const int shortk_big = [] { const char* e = getenv("TINYFACES_SHORTK_BIG_TILE"); return e ? atoi(e) : 46; }();
-    if (!t46_off && !a->bnf && a->dtype != TF_F32 && nst <= 4 && M >= 16384 && a->Cout % 128 == 0 && a->Cout >= 256) return shortk_big;
+    // (TINYFACES_T46_HANDOVER_MIN_M: A/B knob -- the M from which the hand-over data gradients (RES + MASK2 [+ STATS3]: four M x Cout tensors per launch) take it)
+    static const long hand_min_m = [] { const char* e = getenv("TINYFACES_T46_HANDOVER_MIN_M"); return e ? atol(e) : 16384L; }();
+    const long big_min_m = (a->epi & (TF_EPI_MASK2 | TF_EPI_STATS3)) ? hand_min_m : 16384L;
+    if (!t46_off && !a->bnf && a->dtype != TF_F32 && nst <= 4 && M >= big_min_m && a->Cout % 128 == 0 && a->Cout >= 256) return shortk_big;
     // (TINYFACES_SHORTK_TILE: A/B knob -- another tile code for these launches, e.g. 42 = the same 128 x 64 tile with a 2-slot ring)
     static const int shortk_tile = [] { const char* e = getenv("TINYFACES_SHORTK_TILE"); return e ? atoi(e) : 32; }();
     if (!t12_off && a->dtype != TF_F32 && nst <= 4) return shortk_tile;

@@ -40,6 +40,7 @@ struct PwK {
   const float* epi_scale; const float* epi_shift; const float* mask_scale; const float* mask_shift;
   float* stat_out; const float* stat_shift; float* stat_shift_out;
   int M, K, ntiles, srows, ldy;
+  int nsl, nb;       // output-channel slices of N = NF * 16 channels (1: the whole matrix is resident), blocks per slice: grid = nsl * nb
 };
 
 __device__ __forceinline__ int swz(int row) { return ((row >> 1) & 1) ^ (((row >> 2) & 1) << 2) ^ (((row >> 3) & 1) * 6); }
@@ -72,43 +73,53 @@ __global__ void __launch_bounds__(NW * 64) conv_pws_kernel(const PwK a) {
   constexpr int PER = 2 * XT + 2 * NAUX * AUXT + STG;
   constexpr int NIX = 2 * KS, NI1 = AUXT / 1024, NIA = NAUX * NI1;  // DMA instructions per tile
   constexpr int CPR = N / EPS, RPP = 64 / CPR, NPASS = 8 / RPP;     // 16-byte chunks per pixel row, rows per pass, passes per 8 pixels
+  constexpr int NST = 2 * NPASS;                                    // output stores of a wave per tile (they count on the VM counter like the DMAs)
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t smem_u = tf::lds_addr_uniform(smem);
   const char* zero = reinterpret_cast<const char*>(g_pws_zero) + (lane & 7) * 16;
+  // output-channel slices (r5b: N > 256, e.g. 256 -> 1024 of layer 3 as 8 slices of 128): a block keeps ONE slice of the weights resident and
+  // walks the pixel tiles of its share.  Blocks are dealt to the 8 XCDs round-robin by the hardware; the mapping below puts the nsl blocks
+  // that walk the SAME tiles on the same XCD, so the input rows they all read come from HBM once and from that XCD's L2 nsl - 1 times.
+  int slice = 0, bi = blockIdx.x;
+  if (a.nsl > 1) {
+    if ((a.nb & 7) == 0) { const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3; slice = j % a.nsl; bi = (j / a.nsl) * 8 + xcd; }
+    else { slice = blockIdx.x % a.nsl; bi = blockIdx.x / a.nsl; }
+  }
+  const int n0 = slice * N;
 
   // ---- the weights, once: N x KS rows of 128 B, 8 rows per wave-level DMA
   for (int i = wave; i < KS * N / 8; i += NW) {
     const int ks = i / (N / 8), rb = i - ks * (N / 8), row = rb * 8 + (lane >> 3);
-    tf::dma16_hidden(a.w + ((size_t)row * K + ks * 64) * sizeof(T) + (((lane & 7) ^ swz(row)) << 4), smem_u + ks * (N * 128) + rb * 1024);
+    tf::dma16_hidden(a.w + ((size_t)(n0 + row) * K + ks * 64) * sizeof(T) + (((lane & 7) ^ swz(row)) << 4), smem_u + ks * (N * 128) + rb * 1024);
   }
 
   // ---- per-lane constants of the store phase: lane -> 8 channels c0 .. c0+7 of pixel rows (lane / CPR) + RPP * pass
-  const int chunk = lane % CPR, prow = lane / CPR, c0 = chunk * EPS;
+  const int chunk = lane % CPR, prow = lane / CPR, c0 = chunk * EPS, cg = n0 + c0;
   float es[EPS], eh[EPS], ms[EPS], mh[EPS], sft[EPS], s1[EPS], s2[EPS];
 #pragma unroll
   for (int j = 0; j < EPS; ++j) { es[j] = 1.f; eh[j] = 0.f; ms[j] = 0.f; mh[j] = 0.f; sft[j] = 0.f; s1[j] = 0.f; s2[j] = 0.f; }
   if constexpr ((EPIC & TF_EPI_AFFINE) != 0) {
 #pragma unroll
-    for (int j = 0; j < EPS; ++j) { es[j] = a.epi_scale[c0 + j]; eh[j] = a.epi_shift[c0 + j]; }
+    for (int j = 0; j < EPS; ++j) { es[j] = a.epi_scale[cg + j]; eh[j] = a.epi_shift[cg + j]; }
   }
   if constexpr ((EPIC & TF_EPI_MASK) != 0) {
 #pragma unroll
-    for (int j = 0; j < EPS; ++j) { ms[j] = a.mask_scale[c0 + j]; mh[j] = a.mask_shift[c0 + j]; }
+    for (int j = 0; j < EPS; ++j) { ms[j] = a.mask_scale[cg + j]; mh[j] = a.mask_shift[cg + j]; }
   }
   if constexpr ((EPIC & TF_EPI_STATS) != 0) {
     if (a.stat_shift) {
 #pragma unroll
-      for (int j = 0; j < EPS; ++j) sft[j] = a.stat_shift[c0 + j];
+      for (int j = 0; j < EPS; ++j) sft[j] = a.stat_shift[cg + j];
     }
   }
 
   // ---- this wave's private LDS and its tile walk
   const uint32_t mine_u = smem_u + SLAB + wave * PER;
   char* const mine = smem + SLAB + wave * PER;
-  const int stride = gridDim.x * NW;
-  int t = blockIdx.x * NW + wave;
+  const int stride = a.nb * NW;
+  int t = bi * NW + wave;
   auto issue = [&](int tile, int slot) {
     const int p0 = tile * 16;
     const bool live = tile < a.ntiles;
@@ -124,7 +135,7 @@ __global__ void __launch_bounds__(NW * 64) conv_pws_kernel(const PwK a) {
     if constexpr (HAS_AUX) {
 #pragma unroll
       for (int q = 0; q < NAUX; ++q) {
-        const char* src = q == 0 ? a.aux : (q == 1 ? a.aux2 : a.aux3);
+        const char* src = (q == 0 ? a.aux : (q == 1 ? a.aux2 : a.aux3)) + (size_t)n0 * sizeof(T);
 #pragma unroll
         for (int i = 0; i < NI1; ++i) {
           const int byte = i * 1024 + lane * 16, row = byte / (N * 2);
@@ -142,9 +153,15 @@ __global__ void __launch_bounds__(NW * 64) conv_pws_kernel(const PwK a) {
   const int r = lane & 15, g = lane >> 4;
   float* const stg = reinterpret_cast<float*>(mine + 2 * XT + 2 * NAUX * AUXT);
   int slot = 0;
+  bool first = true;
   for (; t < a.ntiles; t += stride) {
     issue(t + stride, slot ^ 1);                    // (past the end: zero-page pieces into the free slot, the wait count stays a constant)
-    wait_vmcnt<NIX + NIA>();                        // this tile's pieces landed; only the next tile's may fly (older stores retire first: in order)
+    // this tile's pieces landed.  The VM counter retires in order and counts stores too: behind this tile's DMAs the wave issued the NST
+    // output stores of the previous tile and the next tile's DMAs, and none of those need to be back -- waiting for the stores (the first
+    // form of this loop: vmcnt(NIX + NIA)) put the write acknowledge of every tile on the critical path of the next one.  The count is
+    // exact: a tile that is followed by another one is never the ragged last tile of the tensor, so all its NST stores were issued.
+    if (first) { wait_vmcnt<NIX + NIA>(); first = false; }
+    else wait_vmcnt<NST + NIX + NIA>();
     f32x4 acc[NF];
 #pragma unroll
     for (int n = 0; n < NF; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -215,7 +232,7 @@ __global__ void __launch_bounds__(NW * 64) conv_pws_kernel(const PwK a) {
 #pragma unroll
             for (int j = 0; j < EPS; ++j) { s1[j] += v[j]; s2[j] += v[j] * x3[j]; }
           }
-          *reinterpret_cast<uint4*>(a.y + ((size_t)p * a.ldy + c0) * sizeof(T)) = tf::pack16<T>(v);
+          *reinterpret_cast<uint4*>(a.y + ((size_t)p * a.ldy + cg) * sizeof(T)) = tf::pack16<T>(v);
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // the staging tile is consumed before the other half overwrites it
@@ -235,16 +252,16 @@ __global__ void __launch_bounds__(NW * 64) conv_pws_kernel(const PwK a) {
       for (int j = 0; j < EPS; ++j) { red[(wave * 2 + 0) * N + lane * EPS + j] = s1[j]; red[(wave * 2 + 1) * N + lane * EPS + j] = s2[j]; }
     }
     __syncthreads();
-    const int srow = blockIdx.x % a.srows;
+    const int srow = bi % a.srows;
     for (int e = tid; e < 2 * N; e += NW * 64) {
       const int k = e / N, c = e - k * N;
       float v = 0.f;
 #pragma unroll
       for (int wv = 0; wv < NW; ++wv) v += red[(wv * 2 + k) * N + c];
-      atomicAdd(&a.stat_out[((size_t)srow * 2 + k) * a.ldy + c], v);
+      atomicAdd(&a.stat_out[((size_t)srow * 2 + k) * a.ldy + n0 + c], v);
     }
-    if ((EPIC & TF_EPI_STATS) && a.stat_shift && a.stat_shift_out && blockIdx.x == 0)
-      for (int c = tid; c < N; c += NW * 64) a.stat_shift_out[c] = a.stat_shift[c];
+    if ((EPIC & TF_EPI_STATS) && a.stat_shift && a.stat_shift_out && bi == 0)
+      for (int c = tid; c < N; c += NW * 64) a.stat_shift_out[n0 + c] = a.stat_shift[n0 + c];
   }
 }
 
@@ -254,10 +271,10 @@ int launch_one(const tf_conv_args* A, const PwK& k, hipStream_t stream) {
   constexpr int NAUX = ((EPIC & (TF_EPI_RES | TF_EPI_MASK | TF_EPI_STATS2)) ? 1 : 0) + ((EPIC & TF_EPI_MASK2) ? 1 : 0) + ((EPIC & TF_EPI_STATS3) ? 1 : 0);
   constexpr size_t per = 2 * KS * 2048 + 2 * NAUX * 16 * N * 2 + 8 * (N + 4) * 4;
   constexpr size_t slab = (size_t)KS * N * 128;
-  constexpr int NW = slab + 4 * per <= 160 * 1024 ? 4 : 2;         // four waves per block where their private rings fit beside the weights, else two
+  constexpr int NW = slab + 4 * per <= 160 * 1024 ? 4 : (slab + 3 * per <= 160 * 1024 ? 3 : 2);     // as many waves (<= 4) as have room for their private rings beside the weights
   constexpr size_t lds = slab + NW * per;
-  if constexpr (lds > 160 * 1024) return TF_ERR_UNSUPPORTED;       // (256 -> 128 with an epilogue operand: tf_conv_pws_applicable refuses it)
-  else {
+  static_assert(lds <= 160 * 1024, "conv_pws: the weight slice and two waves' rings must fit the LDS of a CU");
+  {
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pws_kernel<T, KS, NF, EPIC, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -266,14 +283,20 @@ int launch_one(const tf_conv_args* A, const PwK& k, hipStream_t stream) {
   // persistent grid: as many blocks as fit (LDS decides), at most one wave per tile
   static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
   const int per_cu = (int)((160 * 1024) / lds) < 1 ? 1 : (int)((160 * 1024) / lds);
-  int blocks = cus * (per_cu > 2 ? 2 : per_cu);
+  PwK kk = k;
+  kk.nsl = A->Cout / N;
+  kk.nb = cus * (per_cu > 2 ? 2 : per_cu) / kk.nsl;
+  if (kk.nb < 1) kk.nb = 1;
   const int need = (k.ntiles + NW - 1) / NW;
-  if (blocks > need) blocks = need;
+  if (kk.nb > need) kk.nb = need;
+  if (kk.nsl > 1 && kk.nb > 8) kk.nb &= ~7;                    // (the XCD mapping of the slices wants a multiple of 8)
+  const int blocks = kk.nb * kk.nsl;
   const double M = k.M, es = sizeof(T);
-  const double bytes = (M * k.K + (double)N * k.K + M * N * (1 + NAUX)) * es;
-  const double alg_k = A->alg_k > 0 ? A->alg_k : k.K, alg_n = A->alg_n > 0 ? A->alg_n : N;
-  tf::ProfScope prof(23, 2.0 * M * alg_n * alg_k, bytes, stream, k.M, N, k.K, 1, A->mode, A->epi, 2.0 * M * N * k.K, true);     // 23 = conv_pws
-  TF_LAUNCH_TIMED((conv_pws_kernel<T, KS, NF, EPIC, NW>), dim3(blocks), dim3(NW * 64), lds, stream, k);
+  const double NT = A->Cout;
+  const double bytes = (M * k.K + NT * k.K + M * NT * (1 + NAUX)) * es;
+  const double alg_k = A->alg_k > 0 ? A->alg_k : k.K, alg_n = A->alg_n > 0 ? A->alg_n : NT;
+  tf::ProfScope prof(23, 2.0 * M * alg_n * alg_k, bytes, stream, k.M, A->Cout, k.K, 1, A->mode, A->epi, 2.0 * M * NT * k.K, true);     // 23 = conv_pws
+  TF_LAUNCH_TIMED((conv_pws_kernel<T, KS, NF, EPIC, NW>), dim3(blocks), dim3(NW * 64), lds, stream, kk);
   return hipGetLastError() == hipSuccess ? TF_OK : TF_ERR_LAUNCH;
   }
 }
@@ -291,7 +314,7 @@ int launch_epi(const tf_conv_args* A, const PwK& k, hipStream_t stream) {
     if (A->epi == TF_EPI_STATS) return launch_one<T, KS, NF, TF_EPI_STATS>(A, k, stream);
     if (A->epi == (TF_EPI_MASK | TF_EPI_STATS2)) return launch_one<T, KS, NF, TF_EPI_MASK | TF_EPI_STATS2>(A, k, stream);
     if (A->epi == 0) return launch_one<T, KS, NF, 0>(A, k, stream);
-    if constexpr (KS == 1) {                               // the hand-over data gradients of conv1 (planes -> 4 planes / planes): layer 1
+    if constexpr (KS == 1 || NF == 8) {                    // the hand-over data gradients of conv1 (planes -> 4 planes / planes): layers 1-3
       if (A->epi == (TF_EPI_RES | TF_EPI_MASK2 | TF_EPI_STATS3)) return launch_one<T, KS, NF, TF_EPI_RES | TF_EPI_MASK2 | TF_EPI_STATS3>(A, k, stream);
       if (A->epi == (TF_EPI_RES | TF_EPI_MASK2)) return launch_one<T, KS, NF, TF_EPI_RES | TF_EPI_MASK2>(A, k, stream);
       if (A->epi == TF_EPI_RES) return launch_one<T, KS, NF, TF_EPI_RES>(A, k, stream);
@@ -308,7 +331,13 @@ int launch(const tf_conv_args* A, hipStream_t stream) {
   k.epi_scale = A->epi_scale; k.epi_shift = A->epi_shift; k.mask_scale = A->mask_scale; k.mask_shift = A->mask_shift;
   k.stat_out = A->stat_out; k.stat_shift = A->stat_shift; k.stat_shift_out = A->stat_shift_out;
   k.M = A->N * A->OH * A->OW; k.K = A->Cin; k.ntiles = (k.M + 15) / 16; k.srows = tf_get_stat_rows(); k.ldy = A->ldy;
+  k.nsl = 1; k.nb = 1;
   const int ks = A->Cin / 64, nf = A->Cout / 16;
+  if (nf > 16) {                                                            // sliced: 128 output channels per block
+    if (ks == 4) return launch_epi<T, 4, 8>(A, k, stream);                  // 256 -> 1024: conv3 of layer 3 and the data gradient of its conv1
+    if (ks == 2) return launch_epi<T, 2, 8>(A, k, stream);                  // 128 -> 512: the same of layer 2
+    return TF_ERR_UNSUPPORTED;
+  }
   if (ks == 1 && nf == 16) return launch_epi<T, 1, 16>(A, k, stream);     // 64 -> 256: conv3 / downsample of layer 1
   if (ks == 4 && nf == 4) return launch_epi<T, 4, 4>(A, k, stream);       // 256 -> 64: conv1 of layer 1, the data gradient of its conv3
   if (ks == 1 && nf == 4) return launch_epi<T, 1, 4>(A, k, stream);       // 64 -> 64: conv1 of layer1.0
@@ -320,14 +349,16 @@ bool epi_ok(const tf_conv_args* a) {
   switch (a->epi) {
     case TF_EPI_AFFINE | TF_EPI_RELU: case TF_EPI_AFFINE: case TF_EPI_AFFINE | TF_EPI_RES | TF_EPI_RELU: return true;
     case TF_EPI_STATS: case TF_EPI_MASK | TF_EPI_STATS2: case 0: return a->dtype == TF_BF16;
-    case TF_EPI_RES | TF_EPI_MASK2 | TF_EPI_STATS3: case TF_EPI_RES | TF_EPI_MASK2: case TF_EPI_RES: return a->dtype == TF_BF16 && a->Cin == 64;
+    case TF_EPI_RES | TF_EPI_MASK2 | TF_EPI_STATS3: case TF_EPI_RES | TF_EPI_MASK2: case TF_EPI_RES:
+      return a->dtype == TF_BF16 && (a->Cin == 64 || ((a->Cin == 256 || a->Cin == 128) && a->Cout % 128 == 0));
     default: return false;
   }
 }
 
 }  // namespace
 
-// pointwise (1x1, stride 1, pad 0) conv / data gradient with 2-byte operands, (Cin, Cout) in {(64, 256), (256, 64), (64, 64), (256, 128)},
+// pointwise (1x1, stride 1, pad 0) conv / data gradient with 2-byte operands, (Cin, Cout) in {(64, 256), (256, 64), (64, 64), (256, 128)} or
+// (256 | 128, a multiple of 128 above 256: sliced),
 // ldy == Cout, one of the epilogue sets above, and enough pixels that the launch is a stream (M >= 16 384)
 bool tf_conv_pws_applicable(const tf_conv_args* a) {
   if (a->dtype != TF_BF16 && a->dtype != TF_F16) return false;
@@ -338,9 +369,17 @@ bool tf_conv_pws_applicable(const tf_conv_args* a) {
   if ((a->epi & (TF_EPI_STATS | TF_EPI_STATS2 | TF_EPI_STATS3)) && tf_get_stat_rows() > TF_STAT_ROWS) return false;
   const int ks = a->Cin / 64, nf = a->Cout / 16;
   if (a->Cin % 64 || a->Cout % 16) return false;
+  const long M = (long)a->N * a->OH * a->OW;
+  if (nf > 16) {
+    // sliced: 256 -> 512 / 1024, 128 -> 512 in slices of 128 output channels.  Built, parity-green (tile = 70 on request), and SLOWER than the
+    // tiled kernel on every layer-2/3 shape (alone: 39.8 vs 24.9 us on the layer-3 hand-over gradient; in the step: -5 %, profiles/r05_conv_pws.txt):
+    // two waves per CU hold one 24 KiB tile in flight each.  The dispatcher takes it only with TINYFACES_PWS_SLICED=1.
+    static const bool sliced = getenv("TINYFACES_PWS_SLICED") != nullptr;
+    if (!(ks == 4 || ks == 2) || a->Cout % 128 != 0 || M < 8192) return false;
+    return sliced || a->tile == 70;
+  }
   if (!((ks == 1 && nf == 16) || (ks == 4 && nf == 4) || (ks == 1 && nf == 4) || (ks == 4 && nf == 8))) return false;
-  if (ks == 4 && nf == 8 && (a->epi & (TF_EPI_RES | TF_EPI_MASK | TF_EPI_STATS2))) return false;      // 64 KiB of weights: no room for an operand ring
-  return (long)a->N * a->OH * a->OW >= 16384;
+  return M >= 16384;
 }
 int tf_conv_pws_launch(const tf_conv_args* a, hipStream_t stream) {
   if (!tf_conv_pws_applicable(a)) return TF_ERR_UNSUPPORTED;
