@@ -821,6 +821,14 @@ def main():
                                          "(SURVEY.md 8d); executed = the 2*M*N*K of the GEMM the kernel ran (stride-2 data gradients at 4x, padded stem / head channels)",
                            "algorithmic_gb_s": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9, 1),
                            "share_of_timed_region": round(dom["ms"] * PROFILE_EVERY / (dt * 1e3), 3)}
+        fam = [r for r in prof if r["kind"] in (13, 23)]
+        if dom["kind"] in (13, 23) and len(fam) == 2:
+            # r5: the short-K / large-M pointwise launches (the launches of this class nearest to the HBM roof) left conv_dma for conv_pws; the two
+            # together are the launches `roofline` of rounds 1-4 was quoted on
+            out["roofline"]["with_conv_pws"] = {**{k: v for k, v in roof_of(sum(r["flops"] for r in fam), sum(r["bytes"] for r in fam), sum(r["ms"] for r in fam) * 1e-3, peak).items()
+                                                   if k in ("bound", "achieved", "unit", "frac", "frac_mfma", "frac_hbm")},
+                                                "note": "conv_dma + conv_pws launches of the timed region together: the kernel class `roofline` was quoted on through round 4 "
+                                                        "(conv_pws took its 14 launches per step with the most bytes per launch)"}
         stb = pmc_step_traffic() if args.dtype == "bf16" and world == 1 else None
         if stb:       # the step as a whole against the OTHER roof: a training-mode-BN step at bs = 12 moves every activation several times
             out["roofline_step"] = {"bound": "hbm", "traffic_gb_per_step": round(stb / 1e9, 2), "achieved": round(stb / (ms_per_step * 1e-3) / 1e9, 1),

@@ -1363,6 +1363,15 @@ def test_conv_pws_is_what_the_dispatcher_picks_for_the_layer1_streams():
     n = _hip.lib().tf_profile_collect(rows, 24)
     kinds = {int(rows[i * 6]): int(rows[i * 6 + 1]) for i in range(n)}
     assert kinds.get(23) == 1 and kinds.get(13) == 1, kinds
+    # the sliced form (N > 256) is parity-tested on request and never the dispatcher's own choice (it is slower: DESIGN.md section 7 row 54)
+    x256 = torch.randn(1, 130, 130, 256, device="cuda").to(torch.bfloat16)
+    w1024 = ops.pack_weight(torch.randn(1024, 256, 1, 1, device="cuda") / 16, torch.bfloat16)
+    _hip.lib().tf_profile_enable(1)
+    ops.conv2d_nhwc(x256, w1024, 1024, 1, 1, 1, 0)
+    torch.cuda.synchronize()
+    _hip.lib().tf_profile_enable(0)
+    n = _hip.lib().tf_profile_collect(rows, 24)
+    assert {int(rows[i * 6]) for i in range(n)} == {13}
     w512 = ops.pack_weight(torch.randn(512, 64, 1, 1, device="cuda") / 8, torch.bfloat16)
     with pytest.raises(RuntimeError):
         ops.conv2d_nhwc(x, w512, 512, 1, 1, 1, 0, tile=70)                            # 64 -> 512: not one of its shapes

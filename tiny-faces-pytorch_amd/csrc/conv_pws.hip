@@ -16,6 +16,9 @@
 // the steady state is a wave's own vmcnt / lgkmcnt.  Statistic sums meet in LDS once at the end: one atomic per block and channel.
 // Epilogue sets (compile-time, as in conv_dma): STATS | AFFINE+RELU | AFFINE | AFFINE+RES+RELU | MASK+STATS2 | none, and for K = 64 the hand-over
 // sets of the data gradient of conv1 (RES+MASK2+STATS3, RES+MASK2, RES: up to three epilogue operands per tile -> two waves per block).
+// Output-channel slices (N > 256: 256 -> 512 / 1024, 128 -> 512): a block keeps a 128-channel slice resident and the nsl blocks that walk the
+// same pixel tiles sit on one XCD.  Parity-green and slower than the tiled kernel (64 KiB of weights leave room for two waves x one tile in
+// flight): on request (tile = 70) or with TINYFACES_PWS_SLICED=1 only.
 // Replaces nn.Conv2d (1x1) + BN statistics / folded BN (+ residual + ReLU) of the torchvision Bottleneck (tinyfaces/models/model.py:90-101)
 // and the data gradient of conv3 for those shapes.  bf16 and fp16 operands.
 #include <cstdio>
