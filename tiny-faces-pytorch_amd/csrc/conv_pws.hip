@@ -62,6 +62,10 @@ template <> struct Fr<tf::f16_t> {
 
 // KS = K / 64 (64-deep k stages), NF = N / 16 (16-channel accumulator tiles per wave)
 // NW = waves per block: 4, or 2 where the epilogue operands of a tile (up to three 16 x N tensors, double-buffered) leave no room for more
+constexpr int pws_naux(int epic) { return ((epic & (TF_EPI_RES | TF_EPI_MASK | TF_EPI_STATS2)) ? 1 : 0) + ((epic & TF_EPI_MASK2) ? 1 : 0) + ((epic & TF_EPI_STATS3) ? 1 : 0); }
+constexpr int pws_per(int ks, int n, int naux) { return 2 * ks * 2048 + 2 * naux * 16 * n * 2 + 8 * (n + 4) * 4; }      // private LDS of a wave
+constexpr bool pws_wreg(int ks, int nf) { return ks * 2 * nf <= 32; }
+
 template <typename T, int KS, int NF, int EPIC, int NW>
 __global__ void __launch_bounds__(NW * 64) conv_pws_kernel(const PwK a) {
   typedef typename Fr<T>::t frag;
@@ -69,7 +73,8 @@ __global__ void __launch_bounds__(NW * 64) conv_pws_kernel(const PwK a) {
   constexpr int NAUX = ((EPIC & (TF_EPI_RES | TF_EPI_MASK | TF_EPI_STATS2)) ? 1 : 0) + ((EPIC & TF_EPI_MASK2) ? 1 : 0) + ((EPIC & TF_EPI_STATS3) ? 1 : 0);
   constexpr bool HAS_AUX = NAUX > 0;
   constexpr bool HAS_STATS = (EPIC & (TF_EPI_STATS | TF_EPI_STATS2 | TF_EPI_STATS3)) != 0;
-  constexpr int SLAB = KS * N * 128;                // weights: [k stage][N rows][128 B], swizzled like every operand tile of the conv kernels
+  constexpr bool WREG = pws_wreg(KS, NF);           // the whole weight matrix as MFMA fragments in <= 128 registers of every wave
+  constexpr int SLAB = KS * N * 128;                    // weights: [k stage][N rows][128 B], swizzled like every operand tile of the conv kernels
   constexpr int XT = KS * 2048;                     // input tile of a wave: [k stage][16 pixels][128 B]
   constexpr int AUXT = 16 * N * 2;                  // epilogue operand of a tile: 16 pixel rows, plain
   constexpr int PITCH = N + 4, STG = 8 * PITCH * 4; // staging: 8 pixels x N fp32
@@ -154,6 +159,19 @@ __global__ void __launch_bounds__(NW * 64) conv_pws_kernel(const PwK a) {
   __syncthreads();                                                      // everyone's pieces of the weights are in LDS: the only block barrier of the loop
 
   const int r = lane & 15, g = lane >> 4;
+  // r5b: where the matrix is <= 32 KiB a wave keeps its fragments in REGISTERS for all its tiles (128 VGPRs; the accumulators live in AGPRs): the
+  // slab is read once per wave instead of once per 16-pixel tile, 34 instead of 66 KiB of LDS traffic per tile -- the LDS pipe, not HBM, was
+  // what bounded the 64 -> 256 / 256 -> 64 launches.  (Fragments straight from global memory, no slab, two blocks per CU at <= 256 registers:
+  // measured equal in the step and slower alone, profiles/r05_conv_pws.txt section 5.)
+  frag wreg[WREG ? KS * 2 : 1][WREG ? NF : 1];
+  if constexpr (WREG) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int n = 0; n < NF; ++n) wreg[ks * 2 + kk][n] = *reinterpret_cast<const frag*>(smem + ks * (N * 128) + lds_off(n * 16 + r, kk * 4 + g));
+  }
   float* const stg = reinterpret_cast<float*>(mine + 2 * XT + 2 * NAUX * AUXT);
   int slot = 0;
   bool first = true;
@@ -176,8 +194,11 @@ __global__ void __launch_bounds__(NW * 64) conv_pws_kernel(const PwK a) {
         const frag xf = *reinterpret_cast<const frag*>(xs + ks * 2048 + lds_off(r, kk * 4 + g));
 #pragma unroll
         for (int n = 0; n < NF; ++n) {
-          const frag wf = *reinterpret_cast<const frag*>(smem + ks * (N * 128) + lds_off(n * 16 + r, kk * 4 + g));
-          acc[n] = Fr<T>::mma(wf, xf, acc[n]);
+          if constexpr (WREG) acc[n] = Fr<T>::mma(wreg[ks * 2 + kk][n], xf, acc[n]);
+          else {
+            const frag wf = *reinterpret_cast<const frag*>(smem + ks * (N * 128) + lds_off(n * 16 + r, kk * 4 + g));
+            acc[n] = Fr<T>::mma(wf, xf, acc[n]);
+          }
         }
       }
     // ---- epilogue, 8 pixels at a time: lane (pixel r, channel quad g of every 16-channel tile) parks, lane (row prow, chunk) finishes
@@ -273,7 +294,7 @@ int launch_one(const tf_conv_args* A, const PwK& k, hipStream_t stream) {
   constexpr int N = NF * 16;
   constexpr int NAUX = ((EPIC & (TF_EPI_RES | TF_EPI_MASK | TF_EPI_STATS2)) ? 1 : 0) + ((EPIC & TF_EPI_MASK2) ? 1 : 0) + ((EPIC & TF_EPI_STATS3) ? 1 : 0);
   constexpr size_t per = 2 * KS * 2048 + 2 * NAUX * 16 * N * 2 + 8 * (N + 4) * 4;
-  constexpr size_t slab = (size_t)KS * N * 128;
+  constexpr size_t slab = (size_t)KS * N * 128;        // (<= 32 KiB: register-resident, see the kernel)
   constexpr int NW = slab + 4 * per <= 160 * 1024 ? 4 : (slab + 3 * per <= 160 * 1024 ? 3 : 2);     // as many waves (<= 4) as have room for their private rings beside the weights
   constexpr size_t lds = slab + NW * per;
   static_assert(lds <= 160 * 1024, "conv_pws: the weight slice and two waves' rings must fit the LDS of a CU");
