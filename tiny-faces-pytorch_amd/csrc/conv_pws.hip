@@ -1,21 +1,23 @@
 // conv_pws (r5): WAVE-AUTONOMOUS streaming pointwise conv for the short-K / large-M launches of the trunk -- layer 1 at bs = 12
 // (M = 187 500 pixels, 64 <-> 256 channels), the stem-side layers of the large pyramid levels (M = 76 800 / 307 200).
 //
-// Why.  These launches are HBM streams with a tiny GEMM in the middle (120 MB moved for 6 GFLOP), and the tiled LDS-DMA kernel runs them at
-// 2.4-4.2 TB/s where an elementwise kernel reaches 5.5: 5860 short-lived blocks, each of which fetches the same 16 KiB weight tile again,
-// waits out a full memory round trip with nothing behind it, parks its accumulators in a block-wide staging tile and dies.  The memory
-// skeleton of the form below -- csrc/probe.hip kind 11, profiles/r05_conv_pws.txt -- moves the 64 -> 256 layer-1 tensor pair in 24 us
-// (4.95 TB/s) against 39 us for conv_dma.
+// Why.  These launches are HBM streams with a tiny GEMM in the middle (120 MB moved for 6 GFLOP).  The tiled LDS-DMA kernel runs them as 5860
+// short-lived blocks, each of which fetches the same 16 KiB weight tile again, waits out a full memory round trip with nothing behind it, parks
+// its accumulators in a block-wide staging tile and dies.  The memory skeleton of the form below -- csrc/probe.hip kind 11,
+// profiles/r05_conv_pws.txt -- moves the 64 -> 256 layer-1 tensor pair in 24 us (4.95 TB/s); this kernel needs 30 us, conv_dma 32-39.
 //
-// How.  A PERSISTENT block of four waves loads the whole weight matrix (K x N x 2 bytes <= 64 KiB) into LDS once.  After that every wave is
-// a pipeline of its own over tiles of 16 pixels dealt round-robin: LDS-DMA of the tile's input rows (and of the ONE epilogue operand a
-// mode may need: residual / mask tensor) into a private 2-slot ring, `s_waitcnt vmcnt(next tile's DMAs)`, 16x16x32 MFMAs against the
-// resident weights (accumulators: 4 consecutive channels of one pixel per lane), accumulators -> a private fp32 staging tile of 8 pixels ->
-// every lane finishes 8 channels of one pixel (affine / residual / ReLU / mask, statistic sums in registers across ALL its tiles) and stores
-// 16 bytes.  No block barrier after the weight load, no LDS shared between waves but the read-only weights: the only synchronisation of
-// the steady state is a wave's own vmcnt / lgkmcnt.  Statistic sums meet in LDS once at the end: one atomic per block and channel.
-// Epilogue sets (compile-time, as in conv_dma): STATS | AFFINE+RELU | AFFINE | AFFINE+RES+RELU | MASK+STATS2 | none, and for K = 64 the hand-over
-// sets of the data gradient of conv1 (RES+MASK2+STATS3, RES+MASK2, RES: up to three epilogue operands per tile -> two waves per block).
+// How.  A PERSISTENT block of two to four waves loads the whole weight matrix (K x N x 2 bytes <= 64 KiB) into LDS once; where it is <= 32 KiB
+// every wave then copies its 32 MFMA fragments into 128 VGPRs and never reads the slab again.  After that every wave is a pipeline of its own
+// over tiles of 16 pixels dealt round-robin: LDS-DMA of the tile's input rows and of up to three epilogue operands (residual / mask / statistic
+// tensors) into a PRIVATE 2-slot ring; ONE counted `s_waitcnt vmcnt` per tile -- the VM counter retires in order and counts stores, so the
+// count leaves the previous tile's output stores and the next tile's DMAs in flight --; 16x16x32 MFMAs (accumulators: 4 consecutive channels of
+// one pixel per lane, in AGPRs); accumulators -> a private fp32 staging tile of 8 pixels -> every lane finishes 8 channels of one pixel
+// (affine / residual / ReLU / masks, statistic sums in registers across ALL its tiles) and stores 16 bytes.  No block barrier after the weight
+// load, no LDS shared between waves but the read-only weights: the only synchronisation of the steady state is a wave's own vmcnt / lgkmcnt
+// (ISA audit: tests/test_cabi.py::test_conv_pws_tile_loop_keeps_its_ring_rules).  Statistic sums meet in LDS once at the end: one atomic per
+// block and channel.
+// Epilogue sets (compile-time, as in conv_dma): STATS | AFFINE+RELU | AFFINE | AFFINE+RES+RELU | MASK+STATS2 | none, and the hand-over sets of the
+// data gradient of conv1 (RES+MASK2+STATS3, RES+MASK2, RES: three operand rings per wave -> two waves per block).
 // Output-channel slices (N > 256: 256 -> 512 / 1024, 128 -> 512): a block keeps a 128-channel slice resident and the nsl blocks that walk the
 // same pixel tiles sit on one XCD.  Parity-green and slower than the tiled kernel (64 KiB of weights leave room for two waves x one tile in
 // flight): on request (tile = 70) or with TINYFACES_PWS_SLICED=1 only.
@@ -61,7 +63,7 @@ template <> struct Fr<tf::f16_t> {
 };
 
 // KS = K / 64 (64-deep k stages), NF = N / 16 (16-channel accumulator tiles per wave)
-// NW = waves per block: 4, or 2 where the epilogue operands of a tile (up to three 16 x N tensors, double-buffered) leave no room for more
+// NW = waves per block: as many (<= 4) as have room for their private rings beside the weight slab
 constexpr int pws_naux(int epic) { return ((epic & (TF_EPI_RES | TF_EPI_MASK | TF_EPI_STATS2)) ? 1 : 0) + ((epic & TF_EPI_MASK2) ? 1 : 0) + ((epic & TF_EPI_STATS3) ? 1 : 0); }
 constexpr int pws_per(int ks, int n, int naux) { return 2 * ks * 2048 + 2 * naux * 16 * n * 2 + 8 * (n + 4) * 4; }      // private LDS of a wave
 constexpr bool pws_wreg(int ks, int nf) { return ks * 2 * nf <= 32; }
