@@ -157,8 +157,34 @@ def cpu_baseline(bs=12, warmup=2, steps=5, eval_warmup=1, eval_runs=5, threads=N
             "cpu": _cpu_model(), "host_threads": os.cpu_count(), "torch": torch.__version__}
 
 
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")
-PMC_TRAFFIC_FILE_FP32 = os.path.join(ROOT, "profiles", "r05_pmc_traffic_fp32.json")
+def _profile_file(name):
+    """profiles/r06_<name> (this round's pass over the final binary); the round-5 file while that pass has not been taken yet."""
+    for rp in ("r06", "r05"):
+        p = os.path.join(ROOT, "profiles", f"{rp}_{name}")
+        if os.path.exists(p):
+            return p
+    return os.path.join(ROOT, "profiles", f"r06_{name}")
+
+
+PMC_TRAFFIC_FILE = _profile_file("pmc_traffic.json")
+PMC_TRAFFIC_FILE_FP32 = _profile_file("pmc_traffic_fp32.json")
+PROFILE_STAMP_FILE = _profile_file("stamp.json")
+
+
+def profile_staleness(identity, traffic_path=None, stamp_path=None):
+    """r6: the committed PMC / rocprof files are measurements of ONE binary.  scripts/pmc_traffic.py stamps the traffic file,
+    scripts/stamp_profiles.py the kernel-stats summary, with the identity of the library they were taken on (tf_version, digest of its
+    sources, sha256 of the .so); a stamp that is missing or differs from the LOADED library's source digest is reported as stale."""
+    def stale(path, key=None):
+        if not os.path.exists(path):
+            return True
+        with open(path) as f:
+            d = json.load(f)
+        lib = d.get(key) if key else d
+        return not isinstance(lib, dict) or lib.get("build_id") != identity["build_id"]
+    return {"traffic_stale": stale(traffic_path or PMC_TRAFFIC_FILE, "library"), "rocprof_stale": stale(stamp_path or PROFILE_STAMP_FILE),
+            "library": {"tf_version": identity["tf_version"], "build_id": identity["build_id"], "so_sha256": identity["so_sha256"][:16]},
+            "files": [os.path.relpath(traffic_path or PMC_TRAFFIC_FILE, ROOT), os.path.relpath(ROCPROF_STATS_FILE, ROOT)]}
 PMC_PATTERNS = {6: ("conv3x3h_kernel<tf::bf16_t,",), 7: ("conv3x3h_kernel<tf::f16_t,",), 13: ("conv_dma_kernel<tf::bf16_t,",), 12: ("conv_dma_kernel<float,",), 15: ("conv_dma_kernel<tf::f16_t,",),
                 14: ("wgrad_dma_kernel",), 16: ("wgrad3x3_kernel",), 17: ("conv_pwx_kernel",), 18: ("wgrad_group_kernel", "wgrad_group_fast_kernel"), 20: ("stem_conv_kernel<tf::bf16_t,",), 21: ("stem_conv_kernel<tf::f16_t,",), 19: ("wgrad3x3_group_kernel",), 23: ("conv_pws_kernel",)}
 
@@ -196,7 +222,7 @@ def pmc_step_traffic(path=None):
     return sum(v["hbm_bytes"] * v["launches"] for v in k.values()) / (sgd / 3.0)
 
 
-ROCPROF_STATS_FILE = os.path.join(ROOT, "profiles", "r05_train_bs12_bf16_kernel_stats.csv")
+ROCPROF_STATS_FILE = _profile_file("train_bs12_bf16_kernel_stats.csv")
 
 
 def rocprof_avg_us(kind):
@@ -311,7 +337,16 @@ def bench_eval(model, templates, device, runs=20):       # warm, m
     ms = float(np.median(times[1:])) * 1e3
     ms_b = float(np.median(tb[1:])) * 1e3
     gflop = 1829.4
-    return {"ms_per_image": round(ms, 3), "pyramid": "480x640+960x1280+1920x2560", "lanes": max(1, len(model._lanes) + 1), "candidates": n_cand, "kept": n_keep,
+    extra = {}
+    try:
+        extra.update(bench_eval_end_to_end(model, templates, device, runs=max(4, runs // 2)))
+    except Exception as e:
+        extra["end_to_end_error"] = repr(e)
+    try:
+        extra.update(bench_eval_fp32(model, levels, t_d, masks, templates, device))
+    except Exception as e:
+        extra["fp32_error"] = repr(e)
+    return {"ms_per_image": round(ms, 3), **extra, "pyramid": "480x640+960x1280+1920x2560", "lanes": max(1, len(model._lanes) + 1), "candidates": n_cand, "kept": n_keep,
             "batched": {"images": B, "ms_per_image": round(ms_b, 3), "same_keeps_as_single": bool(batched_ok), "achieved_tflops": round(gflop / ms_b, 2),
                         "frac_of_bf16_mfma_peak": round(gflop / ms_b / PEAK_TFLOPS["bf16"], 4),
                         "note": "get_detections_batch form: 8 images back to back, one host synchronisation, one batched NMS (ms_per_image above is the "
@@ -320,6 +355,72 @@ def bench_eval(model, templates, device, runs=20):       # warm, m
             "threshold_note": "calibrated once per run to the 99.5th percentile of the sigmoid scores of the three maps (random weights have no "
                               "WIDER-like sparsity, SURVEY.md 8d); the timed images reuse it",
             "achieved_tflops": round(gflop / ms, 2), "frac_of_bf16_mfma_peak": round(gflop / ms / PEAK_TFLOPS["bf16"], 4)}
+
+
+def bench_eval_end_to_end(model, templates, device, runs=8):
+    """r6: uint8 image in -> detections out.  One 1280x960 uint8 image on the HOST goes through the product call
+    `evaluation.get_detections(..., scales=(-1, 0, 1), pyramid_on_gpu=True)`: the upload of the 3.7 MB image, the three Pillow-exact resizes +
+    ToTensor + Normalize on the GPU (tf_image_prepare), three forwards on the lanes, decode, one NMS, the copy of the surviving rows back.
+    Inside one constant_weights() session like evaluate_model.py's image loop."""
+    from PIL import Image
+    from tinyfaces import evaluation, ops, transforms
+    model.eval()
+    rs = np.random.RandomState(11)
+    base = rs.randint(0, 256, (60, 80, 3)).astype(np.uint8)      # blocky random image (pure pixel noise resamples to grey at scale 0.5)
+    img = Image.fromarray(np.kron(base, np.ones((16, 16, 1), np.uint8)) ^ rs.randint(0, 32, (960, 1280, 3)).astype(np.uint8))
+    tfm = transforms.Compose([transforms.ToTensor(), transforms.Normalize([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])])
+    with torch.no_grad(), model.constant_weights(reserve=(1, 1920, 2560)):
+        levels = evaluation._pyramid_levels(img, (-1, 0, 1), tfm, True, device)
+        outs = model.forward_levels([x for _, x in levels])
+        allp = torch.cat([torch.sigmoid(o[0, :25]).flatten() for o in outs])
+        thr = float(torch.quantile(allp[torch.randperm(allp.numel(), device=device)[:1000000]], 0.995))
+        times, kept = [], 0
+        for _ in range(runs + 2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            d = evaluation.get_detections(model, img, templates, ops.RF, tfm, prob_thresh=thr, nms_thresh=0.3, scales=(-1, 0, 1), device=device, pyramid_on_gpu=True)
+            times.append(time.perf_counter() - t0)
+            kept = int(d.shape[0])
+    return {"end_to_end_ms_per_image": round(float(np.median(times[2:])) * 1e3, 3), "end_to_end_kept": kept,
+            "end_to_end_note": "evaluation.get_detections(pyramid_on_gpu=True) on one 1280x960 uint8 PIL image held by the host: upload, GPU resize + normalise of the "
+                               "three levels, forwards, decode, NMS, rows back to the host (ms_per_image above starts from resident normalised levels)"}
+
+
+def bench_eval_fp32(model, levels, t_d, masks, templates, device, runs=5):
+    """r6: the same pyramid on the fp32 instantiation -- the path whose NMS-surviving index set is asserted identical
+    to the oracle's (tests/test_gpu_fullsize.py); `ms_per_image` is the bf16 path, whose parity bar is the separated-logit fixture of
+    tests/test_gpu_fullsize.py::test_get_detections_bf16_fp16_keep_set_on_separated_logits."""
+    from tinyfaces import ops
+    from tinyfaces.models.model import DetectionModel
+    m32 = DetectionModel(num_objects=1, num_templates=25)
+    m32.load_state_dict(model.state_dict())
+    m32 = m32.set_compute_dtype("fp32").to(device).eval()
+    cap = sum((x.shape[2] // 8 + 1) * (x.shape[3] // 8 + 1) for _, x in levels) * 25
+    dets = torch.empty(cap, 5, dtype=torch.float64, device=device)
+    times, thr, n_keep = [], None, 0
+    with torch.no_grad(), m32.constant_weights(reserve=(1, 1920, 2560)):
+        for it in range(runs + 2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            count = torch.zeros(1, dtype=torch.int32, device=device)
+            outs = m32.forward_levels([x for _, x in levels])
+            if thr is None:
+                allp = torch.cat([torch.sigmoid(o[0, :25]).flatten() for o in outs])
+                thr = float(torch.quantile(allp[torch.randperm(allp.numel(), device=device)[:1000000]], 0.995))
+                continue
+            for (s_, x), out in zip(levels, outs):
+                ops.decode_compact(out[0], t_d, masks[s_][0], masks[s_][1], thr, s_, dets, count)
+            n = int(count.item())
+            keep = ops.nms(dets[:n, :4].contiguous(), dets[:n, 4].contiguous(), 0.3)
+            res = dets[:n][keep].cpu()
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+            n_keep = res.shape[0]
+    del m32
+    torch.cuda.empty_cache()
+    ms = float(np.median(times[1:])) * 1e3
+    return {"fp32_ms_per_image": round(ms, 3), "fp32_kept": n_keep, "fp32_frac_of_fp32_mfma_peak": round(1829.4 / ms / PEAK_TFLOPS["fp32"], 4),
+            "fp32_note": "the same three resident levels on the fp32 parity instantiation (v_mfma_f32_16x16x4_f32): the path with index-exact NMS survivors vs the CPU oracle"}
 
 
 def bench_eval_forward(model, device, bs=12, runs=10):
@@ -806,15 +907,17 @@ def main():
                            "achieved_tflops": round(ach, 2), "peak_tflops": peak,
                            "arithmetic_intensity_flop_per_byte": round(dom["flops"] / max(dom["bytes"], 1.0), 1), "machine_balance_flop_per_byte": round(peak * 1e12 / (PEAK_HBM_GBS * 1e9), 1),
                            "traffic": pmc_traffic(dom["kind"]),
-                           "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes of this command (profiles/r05_pmc_traffic.json); "
-                                           "algorithmic bytes per launch = %d" % round(dom["bytes"] / dom["launches"]),
+                           **{k: v for k, v in profile_staleness(_hip.identity()).items() if k in ("traffic_stale", "rocprof_stale")},
+                           "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes of this command (%s); traffic_stale / rocprof_stale: "
+                                           "the file's library stamp differs from the loaded library (profiles_identity); "
+                                           "algorithmic bytes per launch = %d" % (os.path.relpath(PMC_TRAFFIC_FILE, ROOT), round(dom["bytes"] / dom["launches"])),
                            "launches_sampled": dom["launches"], "launches_per_step": round(dom["launches"] * PROFILE_EVERY / args.steps, 1),
                            "sampling": f"HIP events around 1 launch in {PROFILE_EVERY} over the timed region (weight gradients run concurrently on a second stream)",
                            "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
                            "rocprof_avg_launch_us": rocprof_avg_us(dom["kind"]),
                            "frac_rocprof_clock": (lambda us: roof_of(dom["flops"] / dom["launches"], dom["bytes"] / dom["launches"], us * 1e-6, peak)["frac"] if us else None)(rocprof_avg_us(dom["kind"])),
                            "rocprof_note": "true kernel duration in the committed rocprofv3 --kernel-trace --stats summary of this command "
-                                           "(profiles/r05_train_bs12_bf16_kernel_stats.csv); the HIP-event bracket adds the queue's inter-packet latency (~5-6 us)",
+                                           "(%s); the HIP-event bracket adds the queue's inter-packet latency (~5-6 us)" % os.path.relpath(ROCPROF_STATS_FILE, ROOT),
                            "algorithmic_gflop_per_launch": round(dom["flops"] / dom["launches"] / 1e9, 3),
                            "executed_gflop_per_launch": round(dom["xflops"] / dom["launches"] / 1e9, 3),
                            "flops_note": "achieved / frac count ALGORITHMIC flops: 2 x the MACs of the forward convolution a launch belongs to on unpadded channels "
@@ -835,8 +938,9 @@ def main():
                                     "peak": 8000.0, "unit": "GB/s", "frac": round(stb / (ms_per_step * 1e-3) / 8e12, 4),
                                     "ms_per_step_at_6300_gb_s": round(stb / 6.3e12 * 1e3, 2),
                                     "mfma_frac_of_step": round(3 * FWD_GFLOP_PER_IMG * args.batch / ms_per_step / PEAK_TFLOPS["bf16"], 4),
+                                    "traffic_stale": profile_staleness(_hip.identity())["traffic_stale"],
                                     "note": "all kernels of a step, HBM bytes from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, "
-                                            "profiles/r05_pmc_traffic.json) over this run's step time; the step is nearer to the HBM roof than to the MFMA roof"}
+                                            "%s) over this run's step time; the step is nearer to the HBM roof than to the MFMA roof" % os.path.relpath(PMC_TRAFFIC_FILE, ROOT)}
         out["kernels"] = [{"kernel": KIND_NAMES.get(r["kind"], str(r["kind"])), "launches_per_step": round(r["launches"] * PROFILE_EVERY / args.steps, 1),
                            "ms_per_step": round(r["ms"] * PROFILE_EVERY / args.steps, 3),
                            "tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 1), "gb_s": round(r["bytes"] / (r["ms"] * 1e-3) / 1e9, 1),
@@ -860,6 +964,7 @@ def main():
                             for r in extra["ss_prof"]]}
         if "error" in extra:
             out["kernels_single_stream"] = {"error": extra["error"]}
+    out["profiles_identity"] = profile_staleness(_hip.identity())
     if comm is not None:
         out["allreduce"] = comm
     if world == 1 and args.dtype == "bf16" and not args.no_fp32_path:

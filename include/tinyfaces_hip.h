@@ -37,6 +37,8 @@ extern "C" {
 #define TF_F16 2      /* IEEE half operands, fp32 accumulation: inference only (BASELINE.json configs[4]); the training entry points refuse it */
 
 int tf_version(void);
+/* r6: digest (16 hex digits of a sha256) of the sources and compiler flags the library was built from; profiles/ files are stamped with it */
+const char* tf_build_id(void);
 /* number of exported symbols a binding must resolve; names via tf_symbol_name(i) */
 int tf_symbol_count(void);
 const char* tf_symbol_name(int i);

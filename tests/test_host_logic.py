@@ -734,3 +734,44 @@ def test_bench_roofline_bound_is_decided_per_kernel_and_gpus_n_self_launches(mon
     monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)          # fewer devices than ranks: refused with a reason, nothing launched
     seen.clear()
     assert bench.self_launch(4) == 3 and not seen and "only 1 GPU" in capsys.readouterr().err
+
+
+def test_bench_flags_profiles_taken_with_another_library_as_stale():
+    """r6: the committed PMC traffic file and the rocprof summary carry the identity of the library they were measured on
+    (scripts/pmc_traffic.py / scripts/stamp_profiles.py: tf_version, source digest, sha256 of the .so); bench.py reports them stale when the
+    loaded library's source digest differs or the stamp is missing."""
+    import importlib.util
+    import json
+    import os
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod3", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    ident = {"tf_version": 600, "build_id": "0123456789abcdef", "so_sha256": "f" * 64}
+    with tempfile.TemporaryDirectory() as d:
+        traffic, stamp = os.path.join(d, "t.json"), os.path.join(d, "s.json")
+        json.dump({"kernels": {}, "library": ident}, open(traffic, "w"))
+        json.dump(ident, open(stamp, "w"))
+        r = bench.profile_staleness(ident, traffic, stamp)
+        assert r["traffic_stale"] is False and r["rocprof_stale"] is False and r["library"]["build_id"] == ident["build_id"]
+        other = dict(ident, build_id="fedcba9876543210")
+        r = bench.profile_staleness(other, traffic, stamp)
+        assert r["traffic_stale"] is True and r["rocprof_stale"] is True
+        json.dump({"kernels": {}}, open(traffic, "w"))                 # an unstamped file (rounds 1-5) is stale by definition
+        assert bench.profile_staleness(ident, traffic, stamp)["traffic_stale"] is True
+        assert bench.profile_staleness(ident, traffic, os.path.join(d, "missing.json"))["rocprof_stale"] is True
+
+
+def test_library_build_id_is_the_digest_of_its_sources():
+    """tf_build_id() = build.py's sha256 over csrc/*, the public header and the compiler flags: the stamp of every committed profile."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("tf_build", os.path.join(root, "tiny-faces-pytorch_amd", "build.py"))
+    build = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(build)
+    from tinyfaces import _hip
+    ident = _hip.identity()
+    assert ident["build_id"] == build.source_digest() and len(ident["build_id"]) == 16
+    assert ident["tf_version"] >= 600 and len(ident["so_sha256"]) == 64

@@ -28,15 +28,32 @@ def _deps_mtime():
     return max(os.path.getmtime(h) for h in hdrs)
 
 
+def source_digest():
+    """tf_build_id(): sha256 over every source of the library (csrc/*, the public header) and the compiler flags, 16 hex digits."""
+    import hashlib
+    h = hashlib.sha256()
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))] + [os.path.join(os.path.dirname(HERE), "include", "tinyfaces_hip.h")]
+    for p in files:
+        if os.path.isfile(p):
+            h.update(os.path.basename(p).encode() + b"\0")
+            with open(p, "rb") as fh:
+                h.update(fh.read())
+    h.update(" ".join(COMMON + sorted(EXACT)).encode())
+    return h.hexdigest()[:16]
+
+
 def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
     hdr_m = _deps_mtime()
+    digest = source_digest()
+    stamp = os.path.join(OBJ, "build_id.txt")
+    restamp = not os.path.exists(stamp) or open(stamp).read().strip() != digest      # capi.o carries the digest: rebuilt whenever any source changed
     jobs = []
     for f in srcs:
         src, obj = os.path.join(CSRC, f), os.path.join(OBJ, f[:-4] + ".o")
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_m):
-            cmd = [HIPCC] + COMMON + (["-ffp-contract=off"] if f in EXACT else []) + ["-c", src, "-o", obj]
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_m) or (f == "capi.hip" and restamp):
+            cmd = [HIPCC] + COMMON + (["-ffp-contract=off"] if f in EXACT else []) + ([f'-DTF_BUILD_ID="{digest}"'] if f == "capi.hip" else []) + ["-c", src, "-o", obj]
             jobs.append((f, cmd))
 
     def run(job):
@@ -52,6 +69,8 @@ def build(force=False, verbose=True):
                 raise RuntimeError(f"hipcc failed for {f}:\n{out}")
             if out.strip() and verbose:
                 print(out)
+    with open(stamp, "w") as fh:
+        fh.write(digest + "\n")
     objs = [os.path.join(OBJ, f[:-4] + ".o") for f in srcs]
     if force or jobs or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):     # (an object built by hand counts)
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", f"-Wl,--version-script={EXPORTS}", "-o", LIB] + objs

@@ -3,7 +3,7 @@
 #include "debug_api.h"
 
 static const char* const kSymbols[] = {
-    "tf_version", "tf_symbol_count", "tf_symbol_name",
+    "tf_version", "tf_build_id", "tf_symbol_count", "tf_symbol_name",
     "tf_targets_workspace_bytes", "tf_dense_overlap_targets", "tf_dense_overlap_iou", "tf_pairwise_iou_distance",
     "tf_nms_workspace_bytes", "tf_nms_f64", "tf_nms_batched_workspace_bytes", "tf_nms_f64_batched",
     "tf_decode_workspace_bytes", "tf_decode_compact",
@@ -26,7 +26,13 @@ void set_next_stop_event(hipEvent_t e) { g_next_stop_event = e; }
 hipEvent_t take_next_stop_event() { hipEvent_t e = g_next_stop_event; g_next_stop_event = nullptr; return e; }
 }  // namespace tf
 
-extern "C" int tf_version(void) { return 500; }   // r5: tf_conv2d_bnfwd (block tail on the next conv1's operand path); r4: context + hooks + communicator entry points
+extern "C" int tf_version(void) { return 600; }   // r6: tf_build_id; r5: tf_conv2d_bnfwd; r4: context + hooks + communicator entry points
+#ifndef TF_BUILD_ID
+#define TF_BUILD_ID "unstamped"
+#endif
+// digest of the sources this library was built from (build.py: sha256 over csrc/* + include/tinyfaces_hip.h + the compiler flags): what a
+// committed profile is stamped with, so that a measurement taken with another binary is recognised as stale (bench.py `traffic_stale`)
+extern "C" const char* tf_build_id(void) { return TF_BUILD_ID; }
 static int g_stat_rows = 8;
 extern "C" int tf_set_stat_rows(int rows) { g_stat_rows = rows <= 0 ? (1 << 30) : (rows > TF_STAT_ROWS ? TF_STAT_ROWS : rows); return TF_OK; }
 extern "C" int tf_get_stat_rows(void) { return g_stat_rows; }

@@ -235,6 +235,105 @@ __global__ void __launch_bounds__(512) wave_stream_probe_kernel(const char* src,
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+
+// kind 12 (r6): does LDS-DMA traffic slow the matrix pipe?  One block of 768 threads per CU: waves 0-7 (two per SIMD) issue nothing but
+// v_mfma_f32_32x32x16_bf16 on register operands (8 per round and wave = the 512 cycles of matrix-pipe time of a conv3x3h K stage), optionally with the
+// 8 ds_read_b128 of a stage; waves 8-11 (one per SIMD) stream `dma_per_round` 1 KiB LDS-DMA instructions each per round from an L2-resident window
+// into a 64 KiB LDS ring (5 each = the 20 KiB of a stage), never waiting for more than the ring needs.  No barrier anywhere: the two groups share
+// nothing but the CU.  mode bits: 1 MFMA waves run, 2 loader waves run, 4 MFMA waves also read fragments from LDS, 8 the loaders use global_load into
+// registers instead of LDS-DMA, 16 the loaders store to LDS with ds_write_b128 instead (no memory traffic).  rounds = iters >> 8, mode = iters & 255.
+typedef __bf16 pbf16x8 __attribute__((ext_vector_type(8)));
+typedef float pf32x16 __attribute__((ext_vector_type(16)));
+template <int MODE>
+__global__ void __launch_bounds__(768) mix_probe_kernel(const char* buf, size_t window, int rounds, int dma_per_round, float* sink) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];       // 64 KiB ring (loaders) + 64 KiB fragment area (readers)
+  const int lane = threadIdx.x & 63, wave_hw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // bit 64: the loaders are the OLDEST waves of the block (hardware waves 0-3) instead of the youngest (8-11)
+  const int wave = (MODE & 64) ? (wave_hw < 4 ? wave_hw + 8 : wave_hw - 4) : wave_hw;
+  if (wave < 8) {
+    if (!(MODE & 1)) return;
+    pf32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = pf32x16(0.f);
+    pbf16x8 fa[4], fb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { fa[i] = pbf16x8((__bf16)(1.0f + lane)); fb[i] = pbf16x8((__bf16)(0.5f + i)); }
+    const char* frag = smem + 65536 + wave * 8192 + lane * 16;
+    if (MODE & 128) {
+      // bit 128: NO loader waves -- every MFMA wave issues its own share of the DMA, one instruction behind every (8 / dma_per_round)-th MFMA
+      const char* base = buf + ((size_t)blockIdx.x * (1u << 20)) % (window - (1u << 20)) + lane * 16;
+      unsigned ofs = wave * 65536u;
+      auto dma1 = [&]() {
+        typedef __attribute__((address_space(3))) void lds_void;
+        typedef __attribute__((address_space(1))) const void glb_void;
+        __builtin_amdgcn_global_load_lds((glb_void*)(base + (ofs & ((1u << 20) - 1))), (lds_void*)(smem + ((ofs >> 10) & 7) * 8192 + wave * 1024), 16, 0, 0);
+        ofs += 1024;
+      };
+      for (int r = 0; r < rounds; ++r) {
+        if (MODE & 4) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { fa[i] = *reinterpret_cast<const pbf16x8*>(frag + i * 1024); fb[i] = *reinterpret_cast<const pbf16x8*>(frag + 4096 + i * 1024); }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[i], acc[i], 0, 0, 0);
+          if (dma_per_round >= 4 || (dma_per_round == 3 && i < 3) || (dma_per_round == 2 && (i & 1) == 0) || (dma_per_round == 1 && i == 0)) dma1();
+          acc[(i + 2) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[(i + 1) & 3], fb[i], acc[(i + 2) & 3], 0, 0, 0);
+          if (dma_per_round >= 8 || (dma_per_round > 4 && i < dma_per_round - 4)) dma1();
+        }
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else
+    for (int r = 0; r < rounds; ++r) {
+      if (MODE & 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { fa[i] = *reinterpret_cast<const pbf16x8*>(frag + i * 1024); fb[i] = *reinterpret_cast<const pbf16x8*>(frag + 4096 + i * 1024); }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[i], acc[i], 0, 0, 0);
+        acc[(i + 2) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[(i + 1) & 3], fb[i], acc[(i + 2) & 3], 0, 0, 0);
+      }
+    }
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v += acc[i][0] + acc[i][7];
+    if (v == 123.456f) sink[0] = v;
+  } else {
+    if (!(MODE & 2) || (MODE & 128)) return;
+    if (MODE & 32) __builtin_amdgcn_s_setprio(3);     // bit 32: the loaders win every issue arbitration
+    const int q = wave - 8;
+    // each CU walks its own 1 MiB of the window again and again (L2-resident after the first pass)
+    const char* base = buf + ((size_t)blockIdx.x * (1u << 20)) % (window - (1u << 20)) + lane * 16;
+    uint4 keep = make_uint4(0, 0, 0, 0);
+    unsigned ofs = q * 65536u;
+    for (int r = 0; r < rounds; ++r) {
+      for (int i = 0; i < dma_per_round; ++i) {
+        const char* g = base + (ofs & ((1u << 20) - 1));
+        char* dst = smem + ((ofs >> 10) & 15) * 4096 + q * 1024;
+        if (MODE & 8) { const uint4 v = *reinterpret_cast<const uint4*>(g); keep.x ^= v.x; keep.y += v.y; keep.z ^= v.z; keep.w += v.w; }
+        else if (MODE & 16) { *reinterpret_cast<uint4*>(dst + lane * 16) = keep; keep.x += 1; }
+        else {
+          typedef __attribute__((address_space(3))) void lds_void;
+          typedef __attribute__((address_space(1))) const void glb_void;
+          __builtin_amdgcn_global_load_lds((glb_void*)g, (lds_void*)dst, 16, 0, 0);
+        }
+        ofs += 1024;
+      }
+      if (!(MODE & 24)) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");      // at most two rounds in flight per loader
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (keep.x == 0x12345u && keep.y == 77u) sink[1] = (float)keep.z;
+  }
+}
+template <int MODE>
+int launch_mix(int blocks, char* buf, size_t window, int iters, int dma, hipStream_t s) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mix_probe_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipLaunchKernelGGL(mix_probe_kernel<MODE>, dim3(blocks), dim3(768), 128 * 1024, s, buf, window, iters >> 8, dma, reinterpret_cast<float*>(buf + window - 4096));
+  return hipGetLastError() == hipSuccess ? TF_OK : TF_ERR_LAUNCH;
+}
+
 template <int KIND>
 int launch(int blocks, int lds, char* buf, size_t window, int iters, hipStream_t s) {
   static bool attr = false;
@@ -294,6 +393,23 @@ extern "C" int tf_debug_probe(int kind, int blocks, int lds_bytes, void* buf, si
         hipLaunchKernelGGL((wave_stream_probe_kernel<512, 128>), dim3(blocks), dim3(nw * 64), l, s, b, b + (size_t)px * in, ntiles);
       }
       return hipGetLastError() == hipSuccess ? TF_OK : TF_ERR_LAUNCH;
+    }
+    case 12: {                                              // iters = rounds << 8 | mode; lds_bytes = LDS-DMA instructions per loader wave and round (default 5)
+      if (window_bytes < (4u << 20)) return TF_ERR_ARG;
+      const int dma = lds_bytes > 0 && lds_bytes <= 32 ? lds_bytes : 5;
+      switch (iters & 255) {
+        case 1: return launch_mix<1>(blocks, b, window_bytes, iters, dma, s);   case 2: return launch_mix<2>(blocks, b, window_bytes, iters, dma, s);
+        case 3: return launch_mix<3>(blocks, b, window_bytes, iters, dma, s);   case 5: return launch_mix<5>(blocks, b, window_bytes, iters, dma, s);
+        case 7: return launch_mix<7>(blocks, b, window_bytes, iters, dma, s);   case 10: return launch_mix<10>(blocks, b, window_bytes, iters, dma, s);
+        case 11: return launch_mix<11>(blocks, b, window_bytes, iters, dma, s); case 15: return launch_mix<15>(blocks, b, window_bytes, iters, dma, s);
+        case 18: return launch_mix<18>(blocks, b, window_bytes, iters, dma, s); case 19: return launch_mix<19>(blocks, b, window_bytes, iters, dma, s);
+        case 23: return launch_mix<23>(blocks, b, window_bytes, iters, dma, s);
+        case 35: return launch_mix<35>(blocks, b, window_bytes, iters, dma, s); case 39: return launch_mix<39>(blocks, b, window_bytes, iters, dma, s);
+        case 129: return launch_mix<129>(blocks, b, window_bytes, iters, dma, s); case 133: return launch_mix<133>(blocks, b, window_bytes, iters, dma, s);
+        case 67: return launch_mix<67>(blocks, b, window_bytes, iters, dma, s); case 99: return launch_mix<99>(blocks, b, window_bytes, iters, dma, s);
+        case 103: return launch_mix<103>(blocks, b, window_bytes, iters, dma, s); case 43: return launch_mix<43>(blocks, b, window_bytes, iters, dma, s);
+      }
+      return TF_ERR_ARG;
     }
     case 7: case 8:
       if (blocks > 1024 || blocks % 8) return TF_ERR_ARG;   // every block must be resident at once (256 CUs x 4)

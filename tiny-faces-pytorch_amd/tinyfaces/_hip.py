@@ -83,6 +83,7 @@ class WgradArgs(C.Structure):
 
 _SIGNATURES = {
     "tf_version": (i32, []),
+    "tf_build_id": (C.c_char_p, []),
     "tf_symbol_count": (i32, []),
     "tf_symbol_name": (C.c_char_p, [i32]),
     "tf_targets_workspace_bytes": (sz, [i32]),
@@ -190,6 +191,16 @@ def lib():
                 fn.restype, fn.argtypes = res, args
         _lib = l
     return _lib
+
+
+def identity():
+    """What a committed profile is stamped with (scripts/pmc_traffic.py, scripts/stamp_profiles.py) and what bench.py compares it to:
+    the ABI version, the digest of the sources the loaded library was built from, and the sha256 of the library file itself."""
+    import hashlib
+    l = lib()
+    with open(LIB_PATH, "rb") as f:
+        sha = hashlib.sha256(f.read()).hexdigest()
+    return {"tf_version": int(l.tf_version()), "build_id": l.tf_build_id().decode(), "so_sha256": sha}
 
 
 def symbols():
