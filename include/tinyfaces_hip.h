@@ -423,7 +423,8 @@ int tf_detnet_backward(int dtype, const float* x_nchw, int N, int H, int W, int 
  *                        (the executor stream that carries the bucket: tf_detnet_hooks) without holding that stream up
  *   tf_comm_join       `stream` waits for every collective issued so far (call it on the training stream before tf_sgd_step)
  *   tf_comm_allreduce_hook  a ready-made tf_grad_ready_fn: tf_detnet_hooks.fn = tf_comm_allreduce_hook, .user = a tf_comm_plan that maps
- *                        the registered blocks to element ranges of the flat gradient; plan.rc keeps the first error, plan.issued counts */
+ *                        the registered blocks to element ranges of the flat gradient; plan.rc keeps the first error, plan.issued counts,
+ *                        plan.status[k] says which buckets were issued (a caller with another exchange at hand reduces the others itself) */
 #define TF_COMM_ID_BYTES 128
 typedef struct tf_comm tf_comm;
 int tf_comm_available(void);
@@ -440,6 +441,7 @@ typedef struct tf_comm_plan {
   int n; const int* blocks;      /* the blocks registered in tf_detnet_hooks (backward order; -1 = the end of the pass) */
   const int64_t* start; const int64_t* end;      /* element range of bucket k */
   int rc, issued;                /* out: first error (TF_OK), collectives issued since the caller reset it */
+  int* status;                   /* r6, optional [n], out: 1 = bucket k's collective was issued, < 0 = its error code, untouched = hook not reached */
 } tf_comm_plan;
 void tf_comm_allreduce_hook(int block, void* stream, void* user /* tf_comm_plan* */);
 

@@ -18,8 +18,9 @@ def timeit(fn, reps=20):
 dt = torch.bfloat16
 TILE = int(os.environ.get("C3H_TILE", "50"))
 shapes = [(12, 32, 32), (1, 120, 160), (1, 60, 80), (12, 63, 63)]
+CINS = [int(v) for v in os.environ.get("C3H_CINS", "64,128,256,512,1024").split(",")]
 for (N, H, W) in shapes:
-    for Cin in (64, 128, 256, 512, 1024):
+    for Cin in CINS:
         for Cout in (256,):
             x = torch.randn(N, H, W, Cin, device="cuda").to(dt)
             w = torch.randn(Cout, Cin, 3, 3, device="cuda") * 0.05

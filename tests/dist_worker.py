@@ -48,10 +48,42 @@ def main():
         torch.cuda.synchronize()
         snaps.append(eng.flat_p.detach().cpu().numpy().copy())
     if rank == 0:
-        np.savez(out_path, *snaps)
+        np.savez(out_path, *snaps, native=np.array([0 if eng._native is None else 1, eng.native_fallbacks]))
     torch.distributed.barrier()
     eng.close()
 
 
+def main_native_fallback():
+    """r6: `dist_worker.py native-fallback OUT`: ONE rank with a 1-rank RCCL group.  Engine A takes the native exchange (C hook) with
+    TINYFACES_COMM_FAIL_BUCKET=1 in the environment: the hook refuses bucket 1 in its first step, the engine must reduce that bucket through
+    torch.distributed, leave the native exchange and carry on with the ctypes callback; engine B runs the same steps on the torch.distributed
+    exchange from the start.  Both must end with the same parameters (the sum over one rank is the identity)."""
+    out_path = sys.argv[2]
+    from tinyfaces import _hip, parallel
+    from tinyfaces.engine import TrainEngine
+    golden_path = os.path.join(ROOT, "tests", "golden", "trainer.npz")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29547")
+    os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+    parallel.init_from_env("nccl")
+    torch.cuda.set_device(0)
+    _hip.lib().tf_set_stat_rows(0)
+    res = {}
+    for tag, native in (("a", True), ("b", False)):
+        m, c, batches = build(golden_path)
+        eng = TrainEngine(m, c, lr=1e-4, momentum=0.9, weight_decay=5e-4, device="cuda:0", bucket_mb=10, native_exchange=native)
+        res[tag + "_native_at_start"] = 0 if eng._native is None else 1
+        img, cm, rm = [t.cuda() for t in batches[0]]
+        for s in range(3):
+            eng.step(img, cm.clone(), rm)
+            if s == 0:
+                res[tag + "_native_after_step1"] = 0 if eng._native is None else 1
+        torch.cuda.synchronize()
+        res[tag + "_flat"] = eng.flat_p.detach().cpu().numpy().copy()
+        res[tag + "_fallbacks"] = eng.native_fallbacks
+        eng.close()
+    np.savez(out_path, **res)
+    torch.distributed.destroy_process_group()
+
+
 if __name__ == "__main__":
-    main()
+    main_native_fallback() if sys.argv[1] == "native-fallback" else main()

@@ -29,6 +29,10 @@ def test_two_rank_engine_equals_single_process_gradient_average(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=500, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     dist = np.load(out)
+    # r6: with more than one rank the engine's DEFAULT is the native RCCL hook; two ranks sharing one device are refused by RCCL ("Duplicate GPU
+    # detected"), every rank sees the refusal (MIN over the gloo group) and the engine falls back to the torch.distributed callback -- once
+    native_now, fallbacks = [int(v) for v in dist["native"]]
+    assert native_now == 0 and fallbacks == 1, (native_now, fallbacks)
     dist = [dist[f"arr_{i}"] for i in range(STEPS)]
 
     # the same two micro-batches in ONE process: two replicas, gradients summed, the fused SGD folds the 1/2 in (engine.py)
@@ -182,6 +186,24 @@ def test_native_exchange_one_rank_communicator_and_hook():
         assert rel < 1e-3
     finally:
         lib().tf_comm_destroy(comm)
+
+
+def test_native_exchange_falls_back_to_torch_distributed_on_a_failed_bucket(tmp_path):
+    """r6: the C hook is the default exchange for world > 1 and any non-zero rc must end in the torch.distributed exchange, not
+    in a lost bucket.  A 1-rank RCCL group; TINYFACES_COMM_FAIL_BUCKET=1 makes tf_comm_allreduce_hook refuse bucket 1: the engine reduces it
+    itself behind the join, leaves the native exchange (native_fallbacks == 1, the ctypes callback from step 2 on) and ends where an engine that
+    used torch.distributed all along ends."""
+    out = str(tmp_path / "nf.npz")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", TINYFACES_COMM_FAIL_BUCKET="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", RANK="0", WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), "native-fallback", out], capture_output=True, text=True, timeout=400, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    d = np.load(out)
+    assert int(d["a_native_at_start"]) == 1 and int(d["a_native_after_step1"]) == 0 and int(d["a_fallbacks"]) == 1
+    assert int(d["b_native_at_start"]) == 0 and int(d["b_fallbacks"]) == 0
+    assert "not issued" in r.stdout                                         # the engine says what happened, once
+    rel = float(np.abs(d["a_flat"] - d["b_flat"]).max() / np.abs(d["b_flat"]).max())
+    report("native_exchange_fallback", rel=rel)
+    assert np.isfinite(d["a_flat"]).all() and rel < 1e-5, rel
 
 
 def test_evaluate_model_two_ranks_write_what_one_process_writes(tmp_path):

@@ -19,6 +19,13 @@
 // to cover them: profiles/r02a_microbench_mma32_tiles.txt).
 // The K loop is written for instruction count (see below): 23 us per launch = 628 TFLOP/s on the layer-3 shape
 // (profiles/r02_conv3x3h_trace.txt: stage stamps, ablations, the versions that did not work).
+// r6 (profiles/r06_conv3x3h.txt): a K stage takes 880 cycles where its 16 MFMAs per SIMD need 512 (MFMAs alone 535, + fragment reads 600-700,
+// + barrier and counted wait ~100, + the DMA ~190): the parts of a stage add up, they do not overlap.  Six forms were built to parity and
+// measured against this one -- K half 1 multiplying behind the barrier while K half 0 reads ("ping-pong"), a ring of 4 / 5 slots, dedicated
+// loader waves (8 MFMA waves that never touch vector memory + 4 loaders, with and without a deeper ring), the DMA instructions spread between
+// the MFMAs, a tile of 8 rows x 64 channels (12.8 instead of 19.4 KiB of operands per stage) -- and every one is equal or slower.  A probe
+// without any barrier (csrc/probe.hip kind 12) shows the law underneath: vector-memory instructions of OTHER waves make no progress while a
+// CU's matrix pipes are saturated, and every global_load_lds a wave issues between its own MFMAs costs its SIMD about one MFMA slot.
 // Epilogue = conv_dma's (fp32 tile in LDS, 16 output bytes per thread, every TF_EPI_* flag), for 512 threads.
 #include <cstdio>
 #include <cstdlib>
@@ -92,7 +99,7 @@ __device__ __forceinline__ void dma16(const void* gsrc, void* lds_wave_base) {
 constexpr int TRACE_BYTES = 8 * 64 * 8 * 8;
 // EPIC (r4): the epilogue flag set as a compile-time constant (-1: read a.epi), like conv_dma_kernel's: the three sets a training step and
 // an evaluation forward use get their own instantiation, the dead modes of the generic epilogue fold away.
-template <typename T, bool TRACE, int EPIC = -1, bool IL = false>
+template <typename T, bool TRACE, int EPIC = -1>
 __global__ void __launch_bounds__(NT, 2) conv3x3h_kernel(const HK a) {
   const int epi_flags = EPIC >= 0 ? EPIC : a.epi;
   typedef typename Frag<T>::t frag;
@@ -197,17 +204,9 @@ __global__ void __launch_bounds__(NT, 2) conv3x3h_kernel(const HK a) {
       // weight stage st has landed once only what was issued after it is still in flight: stage st+1 (WPASS), plus the next
       // chunk's frame (XPASS) when the previous stage was a first tap (the frame is issued BEFORE that stage's weights, so every
       // earlier frame / stage has retired by then: loads retire in order); the very last stage has nothing younger
-      if (IL) {
-        // r6, interleaved issue: a stage issues [W piece 0, W piece 1 of stage st+2, one frame piece at taps 0..3] BETWEEN its MFMAs.  Younger than
-        // stage st's slab: stage st+1's two pieces and the frame pieces of the two stages before this one
-        constexpr int xy = tap == 1 ? 1 : (tap >= 2 && tap <= 4) ? 2 : tap == 5 ? 1 : 0;
-        if (tap == 8) { if (more) wait_vmcnt<WPASS>(); else wait_vmcnt<0>(); }
-        else { if (more) wait_vmcnt<WPASS + xy>(); else wait_vmcnt<WPASS>(); }
-      } else {
       if (tap == 8) { if (more) wait_vmcnt<WPASS>(); else wait_vmcnt<0>(); }
       else if (tap == 1) { if (more) wait_vmcnt<WPASS + XPASS>(); else wait_vmcnt<WPASS>(); }
       else wait_vmcnt<WPASS>();
-      }
       stamp(st, 1);
       __builtin_amdgcn_s_barrier();                 // everyone's pieces landed; everyone finished reading stage st-1's buffers
       stamp(st, 2);
@@ -219,49 +218,10 @@ __global__ void __launch_bounds__(NT, 2) conv3x3h_kernel(const HK a) {
           else if (more) issue_w(std::integral_constant<int, (tap + 2) % 3>{}, (tap + 2 - 9) * tapC + kchunk + 128);
         }
       };
-      if (!IL) issue();      // (issuing after the first MFMA group instead was measured: no difference, profiles/r02_conv3x3h_trace.txt)
-      // r6 IL: ONE DMA instruction behind every second MFMA (profiles/r06_conv3x3h.txt section 6: a vector-memory instruction overlaps with the
-      // MFMAs of its own wave when it sits between them; as a burst in front of them it costs its full service time)
-      auto issue_piece = [&](auto P) {
-        constexpr int p = decltype(P)::value;         // 0, 1: weight rows lrow + 64 p of stage st+2; 2: frame piece `tap` (taps 0..3) of the next chunk
-        if (TRACE && (a.dbg & 1)) return;
-        if (p < 2) {
-          const int kofs = tap < 7 ? (tap + 2) * tapC + kchunk : (tap + 2 - 9) * tapC + kchunk + 128;
-          if (tap < 7 || more) dma16(wptr[p < 2 ? p : 0] + kofs, smem + W_AT + ((tap + 2) % 3) * WBUF + wave_u * 1024 + (p < 2 ? p : 0) * 8192);
-        } else if (tap < XPASS && more) {
-          constexpr int i = tap < XPASS ? tap : 0;
-          dma16(xptr[i], smem + x_buf * XBUF + wave_u * 1024 + i * 8192);
-          xptr[i] += xstep[i];
-          if (tap == XPASS - 1) x_buf ^= 1;
-        }
-      };
+      issue();               // (issuing after the first MFMA group instead was measured: no difference, profiles/r02_conv3x3h_trace.txt)
       stamp(st, 3);
       if (!TRACE || !(a.dbg & 2)) {
         const char* wb = smem + (tap % 3) * WBUF;
-        if (IL) {
-          // all eight fragment reads of the stage first (the j = 1 fragments land under the j = 0 MFMAs), then the MFMAs with the DMA between them
-          frag xs[2][2], ws[2][2];
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-#pragma unroll
-            for (int m = 0; m < 2; ++m) xs[j][m] = *reinterpret_cast<const frag*>(smem + xo[tap][m][j]);
-#pragma unroll
-            for (int n = 0; n < 2; ++n) ws[j][n] = *reinterpret_cast<const frag*>(wb + woff[n][j]);
-          }
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            acc[0][0] = Frag<T>::mma(ws[j][0], xs[j][0], acc[0][0]);
-            acc[0][1] = Frag<T>::mma(ws[j][0], xs[j][1], acc[0][1]);
-            __builtin_amdgcn_sched_barrier(0);
-            if (j == 0) issue_piece(std::integral_constant<int, 0>{}); else issue_piece(std::integral_constant<int, 2>{});
-            __builtin_amdgcn_sched_barrier(0);
-            acc[1][0] = Frag<T>::mma(ws[j][1], xs[j][0], acc[1][0]);
-            acc[1][1] = Frag<T>::mma(ws[j][1], xs[j][1], acc[1][1]);
-            __builtin_amdgcn_sched_barrier(0);
-            if (j == 0) issue_piece(std::integral_constant<int, 1>{});
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        } else {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           frag xf[2], wf[2];
@@ -273,7 +233,6 @@ __global__ void __launch_bounds__(NT, 2) conv3x3h_kernel(const HK a) {
           for (int n = 0; n < 2; ++n)
 #pragma unroll
             for (int m = 0; m < 2; ++m) acc[n][m] = Frag<T>::mma(wf[n], xf[m], acc[n][m]);
-        }
         }
       }
       stamp(st, 4);
@@ -474,24 +433,15 @@ int min_blocks() {
   return v;
 }
 
-template <typename T, bool TRACE, int EPIC, bool IL>
-void launch_one(const HK& k, hipStream_t stream) {
+template <typename T, bool TRACE, int EPIC = -1>
+void launch_var(const HK& k, hipStream_t stream) {
   static bool attr_set[64] = {};                     // per DEVICE: the attribute belongs to the current device's copy of the function
   int dev = 0; (void)hipGetDevice(&dev);
   if (!attr_set[dev & 63]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3h_kernel<T, TRACE, EPIC, IL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3h_kernel<T, TRACE, EPIC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set[dev & 63] = true;
   }
-  TF_LAUNCH_TIMED((conv3x3h_kernel<T, TRACE, EPIC, IL>), dim3(k.mtiles * k.ntiles), dim3(NT), TRACE && RING_BYTES + TRACE_BYTES > LDS_BYTES ? RING_BYTES + TRACE_BYTES : LDS_BYTES, stream, k);
-}
-bool il_on() {
-  static const bool v = [] { const char* e = getenv("TINYFACES_CONV3H_IL"); return e ? atoi(e) != 0 : true; }();
-  return v;
-}
-template <typename T, bool TRACE, int EPIC = -1>
-void launch_var(const HK& k, hipStream_t stream) {
-  if (!TRACE && il_on()) launch_one<T, TRACE, EPIC, !TRACE>(k, stream);
-  else launch_one<T, TRACE, EPIC, false>(k, stream);
+  TF_LAUNCH_TIMED((conv3x3h_kernel<T, TRACE, EPIC>), dim3(k.mtiles * k.ntiles), dim3(NT), TRACE && RING_BYTES + TRACE_BYTES > LDS_BYTES ? RING_BYTES + TRACE_BYTES : LDS_BYTES, stream, k);
 }
 
 template <typename T>

@@ -56,7 +56,7 @@ class DetnetHooks(C.Structure):
 class CommPlan(C.Structure):
     """tf_comm_plan (include/tinyfaces_hip.h): block -> element range of the flat gradient, for tf_comm_allreduce_hook."""
     _fields_ = [("comm", vp), ("grad_flat", vp), ("n", i32), ("blocks", C.POINTER(i32)), ("start", C.POINTER(i64)), ("end", C.POINTER(i64)),
-                ("rc", i32), ("issued", i32)]
+                ("rc", i32), ("issued", i32), ("status", C.POINTER(i32))]
 
 
 class ConvArgs(C.Structure):

@@ -24,7 +24,7 @@ from ._hip import lib
 
 
 class TrainEngine:
-    def __init__(self, model, criterion, lr=1e-4, momentum=0.9, weight_decay=5e-4, device="cuda", bucket_mb=10, native_exchange=False):
+    def __init__(self, model, criterion, lr=1e-4, momentum=0.9, weight_decay=5e-4, device="cuda", bucket_mb=10, native_exchange=None):
         self.device = torch.device(device)
         self.model = model.to(self.device).train()
         self.criterion = criterion
@@ -39,7 +39,10 @@ class TrainEngine:
         self.lr, self.momentum, self.weight_decay = lr, momentum, weight_decay
         self.bucket_elems = int(bucket_mb * (1 << 20) // 4)
         self.steps = 0
-        self.native_exchange = bool(native_exchange)
+        # r6: None = the default rule (_want_native): the library's own RCCL hook when the world is larger than one rank and librccl resolves,
+        # the torch.distributed callback otherwise and whenever the native set-up or a native step reports an error
+        self.native_exchange = native_exchange
+        self.native_fallbacks = 0             # how often the engine left the native exchange (set-up refused / a bucket's collective failed)
         self.skip_allreduce = False          # measurement knob (bench.py): a step without the exchange, to size what the overlap hides
         self._overlap = None
         self._native = None
@@ -113,7 +116,7 @@ class TrainEngine:
         # through the torch.distributed group that already exists (any backend).  Opt-in: like the torch path it has only ever seen a
         # 1-rank group on hardware (tests/test_gpu_dist.py); the default stays the torch.distributed callback below.
         self._native = None
-        if (self.native_exchange or os.environ.get("TINYFACES_ALLREDUCE_NATIVE")) and not self._use_comm_stream and not self.sgd_per_bucket:
+        if self._want_native() and not self._use_comm_stream and not self.sgd_per_bucket:
             self._native = self._setup_native(ranges)
         self._works, self._cb_error, self._ext_streams = [], None, {}
         self._block_range = {r[0]: (r[1], r[2]) for r in ranges}
@@ -126,20 +129,54 @@ class TrainEngine:
         self._overlap = dict(ranges=ranges, events=events, comm=torch.cuda.Stream(device=self.device) if self._use_comm_stream or self.sgd_per_bucket else None,
                              keep=(blocks, handles))
 
+    def _want_native(self):
+        """Which exchange (r6).  An explicit choice wins: `native_exchange=True / False`, TINYFACES_ALLREDUCE_NATIVE=1 / 0.
+        Otherwise the C hook (ncclAllReduce issued by the library itself, no Python inside the backward enqueue) is the default as soon as there
+        is more than one rank; `_setup_native` falls back to the torch.distributed callback when RCCL refuses (no librccl, ranks sharing a
+        device, a failing ncclCommInitRank), and every rank takes the same decision."""
+        env = os.environ.get("TINYFACES_ALLREDUCE_NATIVE")
+        if self.native_exchange is not None:
+            return bool(self.native_exchange)
+        if env is not None:
+            return env not in ("", "0")
+        return parallel.is_distributed() and parallel.world_size() > 1
+
+    def _all_ranks_ok(self, ok):
+        """The same verdict on every rank: MIN over the torch.distributed group that carried us here (any backend)."""
+        if not (dist.is_initialized() and dist.get_world_size() > 1):
+            return bool(ok)
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t.item()))
+
     def _setup_native(self, ranges):
+        """The communicator + the hook's plan, or None (= use the torch.distributed callback) when any rank could not set it up."""
         from . import _hip
-        if not lib().tf_comm_available():
-            raise RuntimeError("TINYFACES_ALLREDUCE_NATIVE: librccl.so could not be resolved at run time")
+        explicit = self.native_exchange is True or os.environ.get("TINYFACES_ALLREDUCE_NATIVE") not in (None, "", "0")
+        if not self._all_ranks_ok(bool(lib().tf_comm_available())):
+            if explicit:
+                raise RuntimeError("TINYFACES_ALLREDUCE_NATIVE: librccl.so could not be resolved at run time")
+            self.native_fallbacks += 1
+            return None
         ident = [bytes(_hip.TF_COMM_ID_BYTES)]
         if parallel.rank() == 0:
             buf = C.create_string_buffer(_hip.TF_COMM_ID_BYTES)
-            _hip.check(lib().tf_comm_unique_id(buf), "tf_comm_unique_id")
-            ident = [buf.raw]
+            if lib().tf_comm_unique_id(buf) == 0:
+                ident = [buf.raw]
         if dist.is_initialized() and dist.get_world_size() > 1:
             dist.broadcast_object_list(ident, src=0)
         comm = C.c_void_p()
         with torch.cuda.device(self.device):
-            _hip.check(lib().tf_comm_init(ident[0], parallel.rank(), parallel.world_size(), C.byref(comm)), "tf_comm_init")
+            rc = lib().tf_comm_init(ident[0], parallel.rank(), parallel.world_size(), C.byref(comm)) if any(ident[0]) else -1
+        if not self._all_ranks_ok(rc == 0):
+            if rc == 0:
+                lib().tf_comm_destroy(comm)
+            if explicit:
+                raise RuntimeError(f"native exchange: tf_comm_init failed on a rank (this rank: rc = {rc})")
+            if parallel.rank() == 0:
+                print("tinyfaces: the native RCCL exchange could not be set up (tf_comm_init); using the torch.distributed exchange", flush=True)
+            self.native_fallbacks += 1
+            return None
         n = len(ranges)
         blocks = (C.c_int * n)(*[r[0] for r in ranges])
         start = (C.c_int64 * n)(*[r[1] for r in ranges])
@@ -148,7 +185,9 @@ class TrainEngine:
         plan.comm, plan.grad_flat, plan.n = comm, self.model._grad_flat_persistent.data_ptr(), n
         plan.blocks, plan.start, plan.end = C.cast(blocks, C.POINTER(C.c_int)), C.cast(start, C.POINTER(C.c_int64)), C.cast(end, C.POINTER(C.c_int64))
         plan.rc, plan.issued = 0, 0
-        return dict(comm=comm, plan=plan, keep=(blocks, start, end), n=n)
+        status = (C.c_int * n)()
+        plan.status = C.cast(status, C.POINTER(C.c_int))
+        return dict(comm=comm, plan=plan, keep=(blocks, start, end, status), n=n, status=status, ranges=ranges)
 
     def _on_bucket(self, block, stream_ptr, _user):
         """Called by the executor while it enqueues the backward pass: bucket `block` is final at the tail of `stream_ptr`."""
@@ -168,6 +207,15 @@ class TrainEngine:
                 self._works.append(dist.all_reduce(g[start:end], op=dist.ReduceOp.SUM, async_op=True))
         except BaseException as e:       # an exception must not unwind through the C frames of the executor
             self._cb_error = e
+
+    def _leave_native(self):
+        """From the C hook back to the ctypes callback (same buckets, same events): after a native step that reported an error."""
+        if self._native is not None:
+            lib().tf_comm_destroy(self._native["comm"])
+            self._native = None
+        self.native_fallbacks += 1
+        self.model._grad_callback = self._cb
+        self.model._grad_callback_user = None
 
     def _drain_exchange(self):
         """Error path of step(): whatever the gradient hooks issued before the backward call failed is waited for, so that neither the
@@ -276,14 +324,29 @@ class TrainEngine:
             return
         if self._native is not None:
             # the collectives were issued by tf_comm_allreduce_hook during the backward call: the training stream waits for the communicator
-            plan = self._native["plan"]
+            nat = self._native
+            plan = nat["plan"]
             issued, rc = plan.issued, plan.rc
+            status = list(nat["status"])
             plan.issued, plan.rc = 0, 0
-            if rc != 0 or issued != self._native["n"]:
-                raise RuntimeError(f"data-parallel step (native exchange): {issued} of {self._native['n']} gradient buckets were reduced, rc = {rc}")
+            for k in range(nat["n"]):
+                nat["status"][k] = 0
             from . import _hip
             with torch.cuda.device(self.device):
-                _hip.check(lib().tf_comm_join(self._native["comm"], torch.cuda.current_stream(self.device).cuda_stream), "tf_comm_join")
+                _hip.check(lib().tf_comm_join(nat["comm"], torch.cuda.current_stream(self.device).cuda_stream), "tf_comm_join")
+            if rc != 0 or issued != nat["n"]:
+                # r6: a bucket whose collective could not be issued (or whose hook never ran) is reduced HERE through torch.distributed, behind the
+                # join (the training stream has the whole gradient by now), and the engine leaves the native exchange for good: from the next
+                # step on the ctypes callback issues every bucket.  (The hook fails on every rank alike or not at all -- an ncclAllReduce that one
+                # rank cannot enqueue leaves its peers waiting in theirs, which only the group's timeout ends.)
+                missing = [k for k in range(nat["n"]) if status[k] != 1]
+                for k in missing:
+                    _, start, end = nat["ranges"][k]
+                    dist.all_reduce(gflat[start:end], op=dist.ReduceOp.SUM)
+                if parallel.rank() == 0:
+                    print(f"tinyfaces: native exchange: {len(missing)} of {nat['n']} gradient buckets were not issued (rc = {rc}); reduced through "
+                          "torch.distributed, which carries the exchange from here on", flush=True)
+                self._leave_native()
             return
         if self._overlap is not None and not self._use_comm_stream:
             # the collectives were issued by _on_bucket during the backward call: the training stream waits for them here
