@@ -358,16 +358,16 @@ def bench_eval(model, templates, device, runs=20):       # warm, m
 
 
 def bench_eval_end_to_end(model, templates, device, runs=8):
-    """r6: uint8 image in -> detections out.  One 1280x960 uint8 image on the HOST goes through the product call
+    """r6: image in -> detections out.  One 1280x960 image on the HOST goes through the product call
     `evaluation.get_detections(..., scales=(-1, 0, 1), pyramid_on_gpu=True)`: the upload of the 3.7 MB image, the three Pillow-exact resizes +
     ToTensor + Normalize on the GPU (tf_image_prepare), three forwards on the lanes, decode, one NMS, the copy of the surviving rows back.
     Inside one constant_weights() session like evaluate_model.py's image loop."""
-    from PIL import Image
     from tinyfaces import evaluation, ops, transforms
     model.eval()
     rs = np.random.RandomState(11)
     base = rs.randint(0, 256, (60, 80, 3)).astype(np.uint8)      # blocky random image (pure pixel noise resamples to grey at scale 0.5)
-    img = Image.fromarray(np.kron(base, np.ones((16, 16, 1), np.uint8)) ^ rs.randint(0, 32, (960, 1280, 3)).astype(np.uint8))
+    u8 = np.kron(base, np.ones((16, 16, 1), np.uint8)) ^ rs.randint(0, 32, (960, 1280, 3)).astype(np.uint8)
+    img = torch.from_numpy(u8).permute(2, 0, 1).float().div(255)      # what the val loader hands evaluate_model.py: a float CHW tensor in [0, 1] on the host (wider_face.py:224-233)
     tfm = transforms.Compose([transforms.ToTensor(), transforms.Normalize([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])])
     with torch.no_grad(), model.constant_weights(reserve=(1, 1920, 2560)):
         levels = evaluation._pyramid_levels(img, (-1, 0, 1), tfm, True, device)
@@ -382,7 +382,7 @@ def bench_eval_end_to_end(model, templates, device, runs=8):
             times.append(time.perf_counter() - t0)
             kept = int(d.shape[0])
     return {"end_to_end_ms_per_image": round(float(np.median(times[2:])) * 1e3, 3), "end_to_end_kept": kept,
-            "end_to_end_note": "evaluation.get_detections(pyramid_on_gpu=True) on one 1280x960 uint8 PIL image held by the host: upload, GPU resize + normalise of the "
+            "end_to_end_note": "evaluation.get_detections(pyramid_on_gpu=True) on one 1280x960 image tensor held by the host (the val loader's contract): quantise to uint8, upload, GPU resize + normalise of the "
                                "three levels, forwards, decode, NMS, rows back to the host (ms_per_image above starts from resident normalised levels)"}
 
 

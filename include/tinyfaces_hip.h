@@ -331,7 +331,10 @@ int tf_bn_add_relu_fused(int dtype, const void* x, const tf_bn_fwd_desc* bn, con
                          int rows, int64_t M, int C, float count, float eps, float momentum, void* y, void* stream);
 int tf_bn_bwd_apply_fused(int dtype, const void* g, const void* y /* NULL: no ReLU mask */, const void* x, const tf_bn_bwd_desc* bn,
                           int rows, int64_t M, int C, float count, void* out, void* stream);
-/* r3: tf_bn_bwd_apply_fused + the pointwise tf_conv2d that consumes its output, in ONE launch (csrc/conv_pwx.hip): the conv's pixel
+#ifdef TF_EXPERIMENTAL
+/* EXPERIMENTAL BUILD ONLY (build.py --experimental): parity-green, measured slower than the two launches on every layer,
+ * not part of the default library.
+ * r3: tf_bn_bwd_apply_fused + the pointwise tf_conv2d that consumes its output, in ONE launch (csrc/conv_pwx.hip): the conv's pixel
  * operand is A*x + B*x2 + D (a->x = the incoming gradient g, x2 = the BatchNorm's input, coefficients from `bn`'s statistic rows as in
  * tf_bn_bwd_apply_fused, dgamma / dbeta published), the applied tensor is also written to applied_out [M][Cin] (NULL: not kept).
  * Replaces the backward of BatchNorm2d followed by the data gradient of the 1x1 conv in front of it (torchvision Bottleneck.bn3 / conv3
@@ -346,6 +349,7 @@ int tf_conv2d_bnbwd(const tf_conv_args* a, const tf_bn_bwd_desc* bn, const void*
  * Same shape limits and error codes as tf_conv2d_bnbwd. */
 int tf_conv2d_bnfwd(const tf_conv_args* a, const tf_bn_fwd_desc* bn, const void* res, const tf_bn_fwd_desc* bn_res, void* y_out, int rows, float count,
                     float eps, float momentum, void* stream);
+#endif /* TF_EXPERIMENTAL */
 /* score4_upsample (frozen bilinear ConvTranspose2d k4 s2 p1, model.py:34-40,107) + crop (:110-124)
  * + add (:126); wup_diag [C][4][4] = the channel diagonal of the (C,C,4,4) weight; output NCHW fp32. */
 int tf_upsample_add_crop(int dtype, const void* s3, const void* s4, const float* wup_diag, int B, int C, int ldc,

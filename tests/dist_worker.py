@@ -62,9 +62,7 @@ def main_native_fallback():
     from tinyfaces import _hip, parallel
     from tinyfaces.engine import TrainEngine
     golden_path = os.path.join(ROOT, "tests", "golden", "trainer.npz")
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29547")
-    os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-    parallel.init_from_env("nccl")
+    assert parallel.init_from_env("nccl"), "TINYFACES_FORCE_DIST=1 must be set: a 1-rank RCCL group"
     torch.cuda.set_device(0)
     _hip.lib().tf_set_stat_rows(0)
     res = {}

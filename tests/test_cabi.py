@@ -17,8 +17,10 @@ def built():
     return mod.build(verbose=False)
 
 
-def _declared():
+def _declared(experimental=False):
     src = open(os.path.join(ROOT, "include", "tinyfaces_hip.h")).read()
+    if not experimental:       # the default library does not carry the `#ifdef TF_EXPERIMENTAL` entry points (measured-and-lost kernels)
+        src = re.sub(r"#ifdef TF_EXPERIMENTAL.*?#endif /\* TF_EXPERIMENTAL \*/", "", src, flags=re.S)
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(tf_[a-z0-9_]+)\s*\(", src)))
 
@@ -26,8 +28,11 @@ def _declared():
 def test_library_exports_every_declared_symbol(built, hip):
     import ctypes
     l = ctypes.CDLL(built)
-    declared = _declared()
+    declared = _declared(hip.experimental())
     assert len(declared) >= 35
+    if not hip.experimental():      # r6: the default library is WITHOUT the kernels that lost (conv_pwx: tf_conv2d_bnbwd / tf_conv2d_bnfwd)
+        assert not hasattr(l, "tf_conv2d_bnfwd") and not hasattr(l, "tf_conv2d_bnbwd")
+        assert set(_declared(True)) - set(declared) == {"tf_conv2d_bnbwd", "tf_conv2d_bnfwd"}
     for name in declared:
         assert hasattr(l, name), f"{name} declared in include/tinyfaces_hip.h but not exported"
     listed = hip.symbols()
@@ -43,7 +48,11 @@ def test_library_exports_only_the_c_abi(built):
     names = [ln.split()[-1] for ln in out.splitlines() if ln.strip()]
     assert names and not [n for n in names if n.startswith("_Z")], [n for n in names if n.startswith("_Z")][:5]
     dbg = set(re.findall(r"\b(tf_[a-z0-9_]+)\s*\(", open(os.path.join(ROOT, "tiny-faces-pytorch_amd", "csrc", "debug_api.h")).read()))
-    assert set(names) == set(_declared()) | dbg
+    import ctypes
+    fn = ctypes.CDLL(built).tf_build_id
+    fn.restype = ctypes.c_char_p
+    exp = fn().decode().endswith("+x")
+    assert set(names) == set(_declared(exp)) | dbg
 
 
 def test_binding_signatures_cover_the_abi(hip):
@@ -133,7 +142,7 @@ def test_conv_pwx_k_loop_holds_only_the_hand_counted_waits(tmp_path):
     import re
     import subprocess
     src = os.path.join(ROOT, "tiny-faces-pytorch_amd", "csrc", "conv_pwx.hip")
-    r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-save-temps", "-c", src, "-o", str(tmp_path / "pwx.o")],
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-DTF_EXPERIMENTAL", "-save-temps", "-c", src, "-o", str(tmp_path / "pwx.o")],      # (r6: an experimental-build kernel)
                        cwd=tmp_path, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     asm = open(tmp_path / "conv_pwx-hip-amdgcn-amd-amdhsa-gfx950.s").read()
@@ -213,7 +222,8 @@ def test_no_lds_read_is_in_flight_across_a_barrier_that_frees_its_ring_slot(tmp_
     import subprocess
     path = os.path.join(ROOT, "tiny-faces-pytorch_amd", "csrc", src)
     out = tmp_path / "k.s"
-    r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", path, "-o", str(out)],
+    exp = ["-DTF_EXPERIMENTAL"] if src == "conv_pwx.hip" else []        # (r6: conv_pwx is an experimental-build kernel; the others are audited as shipped)
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17"] + exp + ["-S", "--cuda-device-only", path, "-o", str(out)],
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     found = _barriers_with_lds_in_flight(open(out).read())

@@ -716,6 +716,9 @@ def test_opt_in_fused_bn_prologues_take_the_same_step(tmp_path):
     tf_conv2d_bnbwd) against the default graph (every pass a launch of its own), one training forward + backward from the same weights: the
     maps, the running statistics the fused kernel publishes, and gradients of layers 1-3 + heads.  The knobs are read once per process: two
     subprocesses.  (The fused graph is opt-in because it is slower; it has to stay CORRECT.)"""
+    from tinyfaces import _hip as _hip_x
+    if not _hip_x.experimental():
+        pytest.skip("the fused BatchNorm prologues (conv_pwx) are compiled into the experimental build only (build.py --experimental)")
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = {}

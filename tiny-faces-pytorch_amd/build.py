@@ -17,6 +17,9 @@ LIB = os.path.join(HERE, "tinyfaces", "libtinyfaces_hip.so")
 EXPORTS = os.path.join(CSRC, "exports.map")   # only tf_* leaves the library
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# --experimental / TINYFACES_BUILD_EXPERIMENTAL=1: compile the measured-and-lost kernels in as well (csrc/common.h: TF_EXPERIMENTAL)
+if os.environ.get("TINYFACES_BUILD_EXPERIMENTAL") or "--experimental" in sys.argv:
+    COMMON = COMMON + ["-DTF_EXPERIMENTAL"]
 # files whose float64 arithmetic must round exactly like numpy's: no FMA contraction
 EXACT = {"targets.hip", "nms.hip", "decode.hip", "augment.hip"}
 

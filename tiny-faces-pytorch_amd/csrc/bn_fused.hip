@@ -13,6 +13,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "tuning.h"
 
 namespace {
 
@@ -252,7 +253,7 @@ inline dim3 fused_grid(int64_t M, int C, int dtype) {
   const int rpp = 256 / (cs / eps);
   const int slices = C / cs;
   int64_t gx = (M + rpp - 1) / rpp;
-  static const int total_cap = [] { const char* e = getenv("TINYFACES_EW_BLOCKS"); return e ? atoi(e) : 2048; }();
+  const int total_cap = tf::tuning().ew_blocks;
   const int64_t cap = std::max(1, total_cap / slices);   // ~2k blocks: enough loads in flight, bounded coefficient re-derivation
   if (gx > cap) gx = cap;
   if (gx < 1) gx = 1;

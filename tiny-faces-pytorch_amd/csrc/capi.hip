@@ -12,7 +12,10 @@ static const char* const kSymbols[] = {
     "tf_conv_mtiles", "tf_conv2d", "tf_pack_weight", "tf_pack_weights_batched", "tf_pack_weights_tiled", "tf_conv2d_wgrad", "tf_conv2d_wgrad_group", "tf_wgrad_workspace_bytes", "tf_unpack_dw",
     "tf_stem_im2col", "tf_stem_conv", "tf_stem_wgrad", "tf_maxpool_fwd", "tf_maxpool_bwd", "tf_maxpool_bwd_stats", "tf_colstats_blocks", "tf_colstats",
     "tf_bn_finalize", "tf_bn_fold", "tf_bn_bwd_finalize", "tf_bn_bwd_apply", "tf_bn_relu", "tf_bn_add_relu",
-    "tf_bn_relu_fused", "tf_bn_add_relu_fused", "tf_bn_bwd_apply_fused", "tf_conv2d_bnbwd", "tf_conv2d_bnfwd",
+    "tf_bn_relu_fused", "tf_bn_add_relu_fused", "tf_bn_bwd_apply_fused",
+#if TF_EXP
+    "tf_conv2d_bnbwd", "tf_conv2d_bnfwd",       // experimental build only (common.h)
+#endif
     "tf_upsample_add_crop", "tf_upsample_add_crop_bwd", "tf_reduce_partials",
     "tf_detnet_num_params", "tf_detnet_param_name", "tf_detnet_param_numel", "tf_detnet_workspace_bytes",
     "tf_detnet_out_shape", "tf_detnet_param_region_bytes", "tf_detnet_forward", "tf_detnet_backward", "tf_detnet_ctx_create", "tf_detnet_ctx_destroy", "tf_detnet_forward_ctx", "tf_detnet_backward_ctx", "tf_comm_available", "tf_comm_unique_id", "tf_comm_init", "tf_comm_destroy", "tf_comm_rank", "tf_comm_world", "tf_allreduce_bucket", "tf_comm_join", "tf_comm_allreduce_hook",
@@ -32,7 +35,7 @@ extern "C" int tf_version(void) { return 600; }   // r6: tf_build_id; r5: tf_con
 #endif
 // digest of the sources this library was built from (build.py: sha256 over csrc/* + include/tinyfaces_hip.h + the compiler flags): what a
 // committed profile is stamped with, so that a measurement taken with another binary is recognised as stale (bench.py `traffic_stale`)
-extern "C" const char* tf_build_id(void) { return TF_BUILD_ID; }
+extern "C" const char* tf_build_id(void) { return TF_EXP ? TF_BUILD_ID "+x" : TF_BUILD_ID; }      // "+x": built with TF_EXPERIMENTAL
 static int g_stat_rows = 8;
 extern "C" int tf_set_stat_rows(int rows) { g_stat_rows = rows <= 0 ? (1 << 30) : (rows > TF_STAT_ROWS ? TF_STAT_ROWS : rows); return TF_OK; }
 extern "C" int tf_get_stat_rows(void) { return g_stat_rows; }

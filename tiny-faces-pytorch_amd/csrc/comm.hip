@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "common.h"
+#include "tuning.h"
 
 namespace {
 
@@ -86,7 +87,7 @@ extern "C" int tf_comm_unique_id(void* id_out) {
 extern "C" int tf_comm_init(const void* id128, int rank, int world, tf_comm** out) {
   if (!id128 || !out || world < 1 || rank < 0 || rank >= world) return TF_ERR_ARG;
   if (!rccl().ok) return TF_ERR_UNSUPPORTED;
-  if (getenv("TINYFACES_COMM_FAIL_INIT")) return TF_ERR_LAUNCH;      // test knob: the fall-back of the engine to the torch.distributed exchange
+  if (tf::tuning().comm_fail_init) return TF_ERR_LAUNCH;      // test knob: the fall-back of the engine to the torch.distributed exchange
   tf_comm* c = new tf_comm;
   c->rank = rank; c->world = world;
   if (hipGetDevice(&c->device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return TF_ERR_LAUNCH; }
@@ -145,7 +146,7 @@ extern "C" int tf_comm_join(tf_comm* c, void* stream) {
 extern "C" void tf_comm_allreduce_hook(int block, void* stream, void* user) {
   tf_comm_plan* p = (tf_comm_plan*)user;
   if (!p || !p->comm || !p->grad_flat) return;
-  static const int fail_bucket = [] { const char* e = getenv("TINYFACES_COMM_FAIL_BUCKET"); return e ? atoi(e) : -1; }();      // test knob (same on every rank)
+  const int fail_bucket = tf::tuning().comm_fail_bucket;      // test knob (same on every rank)
   for (int k = 0; k < p->n; ++k)
     if (p->blocks[k] == block) {
       const int rc = k == fail_bucket ? TF_ERR_LAUNCH

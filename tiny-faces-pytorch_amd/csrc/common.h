@@ -1,5 +1,13 @@
 // Shared device helpers for the tiny-faces gfx950 kernels (CDNA4, wave64).
 #pragma once
+// TF_EXPERIMENTAL (build.py --experimental / TINYFACES_BUILD_EXPERIMENTAL=1): the kernels that were built to parity, measured and LOST stay in the tree for
+// re-measurement but are not part of the default library: conv_pwx (BatchNorm prologues: tf_conv2d_bnbwd / tf_conv2d_bnfwd), the output-channel slices of
+// conv_pws and the in-LDS BN prologue of the ring-less pointwise kernel (tf_conv_args.bnf).  DESIGN.md section 7 rows 14-16, 44, 45, 54.
+#ifdef TF_EXPERIMENTAL
+#define TF_EXP 1
+#else
+#define TF_EXP 0
+#endif
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>

@@ -7,6 +7,7 @@
 // kernel and was removed: tf_conv2d returns TF_ERR_UNSUPPORTED for tile codes < 10 and for pro_scale (tf_conv2d_wgrad keeps its prologue).
 #include <cstdlib>
 #include "common.h"
+#include "tuning.h"
 #include "profile.h"
 
 int tf_conv_dma_launch(const tf_conv_args* a, int tile, int depth, hipStream_t stream);   // conv_dma.hip
@@ -29,9 +30,9 @@ int pick_tile(const tf_conv_args* a) {
   // (TINYFACES_PWX_FWD=1: the pointwise convs with 128 / 256 output channels and K >= 128, A/B knob)
   // 70 = conv_pws (r5): wave-autonomous streaming kernel for the short-K / large-M pointwise launches (layer 1, the large pyramid levels);
   // TINYFACES_PWS_OFF=1: the tiled kernel as in rounds 1-4
-  static const bool pws_off = getenv("TINYFACES_PWS_OFF") != nullptr;
+  const bool pws_off = tf::tuning().pws_off;
   if (!pws_off && tf_conv_pws_applicable(a)) return 70;
-  static const bool pwx_fwd = getenv("TINYFACES_PWX_FWD") != nullptr;
+  const bool pwx_fwd = tf::tuning().pwx_fwd;
   if (pwx_fwd && tf_conv_pwx_applicable(a) && a->Cin >= 512) return 60;
   // measured on the bs=12 500x500 layer shapes (scripts/microbench.py): 128 pixels x 64 channels wins on every
   // layer (more, smaller tiles -> more blocks in flight per CU); 64x64 only when even that leaves CUs idle.
@@ -40,23 +41,23 @@ int pick_tile(const tf_conv_args* a) {
     // LDS-DMA pipeline.  bf16 convs of <= 4 K-stages (K <= 256 pointwise) are dispatch + epilogue bound: 128-pixel tiles without a
     // ring halve their block count at the same 4 blocks per CU (+0.6 % on the step, A/B on one box: 1036.6 -> 1043.3 img/s);
     // everything else 64x64 with the ring depth chosen by K.  The choice lives HERE so that tf_conv_mtiles agrees with the launch.
-    static const bool t12_off = getenv("TINYFACES_T12_SHORTK_OFF") != nullptr;
+    const bool t12_off = tf::tuning().t12_shortk_off;
     const int nst = a->KH * a->KW * (a->Cin / 64);
     // r3: ... except where the launch is big enough to be throughput-bound: from M = 16 384 pixels on, 64 pixels x 128 channels on
     // 32x32x16 fragments with a 2-deep ring moves the same bytes faster (1920x2560 pyramid level: 256 -> 1024 at M = 19 200 35.6 -> 30.7 us,
     // 128 -> 512 at M = 76 800 49.1 -> 40.8 us, 64 -> 256 at M = 307 200 103 -> 95 us; profiles/r03_microbench_eval.txt)
-    static const bool t46_off = getenv("TINYFACES_T46_SHORTK_OFF") != nullptr;
+    const bool t46_off = tf::tuning().t46_shortk_off;
     // (r4: a 128 x 128 / eight-wave pointwise kernel, conv_pw8, was built for the K >= 512 GEMMs and measured no faster on any layer shape:
     //  profiles/r04_conv_pw8_negative.txt -- removed again)
     // (not with the in-LDS BN prologue `bnf`: only the ring-less 128 x 64 tile implements it -- ADVICE r3)
     // (TINYFACES_SHORTK_BIG_TILE: A/B knob -- another tile code for these launches, e.g. 44 = 128 x 128 / 45 = 128 x 64 on the same fragments)
-    static const int shortk_big = [] { const char* e = getenv("TINYFACES_SHORTK_BIG_TILE"); return e ? atoi(e) : 46; }();
+    const int shortk_big = tf::tuning().shortk_big_tile;
     // (TINYFACES_T46_HANDOVER_MIN_M: A/B knob -- the M from which the hand-over data gradients (RES + MASK2 [+ STATS3]: four M x Cout tensors per launch) take it)
-    static const long hand_min_m = [] { const char* e = getenv("TINYFACES_T46_HANDOVER_MIN_M"); return e ? atol(e) : 16384L; }();
+    const long hand_min_m = tf::tuning().t46_handover_min_m;
     const long big_min_m = (a->epi & (TF_EPI_MASK2 | TF_EPI_STATS3)) ? hand_min_m : 16384L;
     if (!t46_off && !a->bnf && a->dtype != TF_F32 && nst <= 4 && M >= big_min_m && a->Cout % 128 == 0 && a->Cout >= 256) return shortk_big;
     // (TINYFACES_SHORTK_TILE: A/B knob -- another tile code for these launches, e.g. 42 = the same 128 x 64 tile with a 2-slot ring)
-    static const int shortk_tile = [] { const char* e = getenv("TINYFACES_SHORTK_TILE"); return e ? atoi(e) : 32; }();
+    const int shortk_tile = tf::tuning().shortk_tile;
     if (!t12_off && a->dtype != TF_F32 && nst <= 4) return shortk_tile;
     // 32x32x16 fragments (64 pixels x 128 channels per block, 32 x 64 per wave, 2-deep ring) win where a launch still has several
     // blocks per CU AND a long K loop: 3x3 convs / K >= 576 with M >= 16 384 pixels -- layer 2 at bs = 12 (26.3 vs 32.9 us forward,
@@ -66,7 +67,7 @@ int pick_tile(const tf_conv_args* a) {
     // 3x3 / stride 1 with >= 128 output channels and enough tiles to fill the chip: the halo-resident kernel (conv3x3h.hip), which
     // moves each input byte into LDS once per 64-channel chunk instead of once per tap
     if (tf_conv3x3h_applicable(a, false)) return 50;
-    static const bool mma32_off = getenv("TINYFACES_MMA32_OFF") != nullptr;
+    const bool mma32_off = tf::tuning().mma32_off;
     if (!mma32_off && a->dtype != TF_F32 && nst >= 9 && M >= 16384 && a->Cout % 128 == 0) return 46;
     return 13;
   }
@@ -120,6 +121,7 @@ extern "C" int tf_conv2d(const tf_conv_args* a, void* stream_) {
 // tf_bn_bwd_apply_fused + tf_conv2d (pointwise, mode 0 or 1) in ONE launch: the conv's pixel operand is A*x + B*x2 + D with the
 // BatchNorm-backward coefficients of `bn` (derived in-kernel from its statistic rows), the applied tensor also goes to `applied_out`
 // (the weight gradient's operand).  conv_pwx.hip; TF_ERR_UNSUPPORTED for shapes it does not take (the caller runs the two kernels).
+#if TF_EXP
 extern "C" int tf_conv2d_bnbwd(const tf_conv_args* a, const tf_bn_bwd_desc* bn, const void* x2, void* applied_out, int rows, float count, void* stream_) {
   if (!a || !a->x || !a->w || !a->y || !bn || !x2) return TF_ERR_ARG;
   if ((a->epi & (TF_EPI_STATS | TF_EPI_STATS2 | TF_EPI_STATS3)) && !a->stat_out) return TF_ERR_ARG;
@@ -149,3 +151,4 @@ extern "C" int tf_conv2d_bnfwd(const tf_conv_args* a, const tf_bn_fwd_desc* bn, 
   if (rows < 1 || rows > TF_STAT_ROWS) return TF_ERR_ARG;
   return tf_conv_pwx_launch_fwd(a, bn, res, bn_res, y_out, rows, count, eps, momentum, (hipStream_t)stream_);
 }
+#endif

@@ -31,6 +31,7 @@
 #include <cstdlib>
 #include <type_traits>
 #include "common.h"
+#include "tuning.h"
 #include "debug_api.h"
 #include "profile.h"
 
@@ -419,18 +420,9 @@ __global__ void __launch_bounds__(NT, 2) conv3x3h_kernel(const HK a) {
 }
 
 unsigned long long* g_trace = nullptr;
-int dbg_flags() {
-  static const int v = [] {
-    const char* e = getenv("TINYFACES_CONV3H_DBG");
-    const int d = e ? atoi(e) : 0;
-    if (d) fprintf(stderr, "tinyfaces: TINYFACES_CONV3H_DBG=%d -- timing-ablation mode, convolution RESULTS ARE INVALID\n", d);
-    return d;
-  }();
-  return v;
-}
+int dbg_flags() { return tf::tuning().conv3h_dbg; }
 int min_blocks() {
-  static const int v = [] { const char* e = getenv("TINYFACES_CONV3H_MINBLOCKS"); return e ? atoi(e) : 160; }();
-  return v;
+  return tf::tuning().conv3h_minblocks;
 }
 
 template <typename T, bool TRACE, int EPIC = -1>
@@ -464,7 +456,7 @@ int launch(const tf_conv_args* A, hipStream_t stream) {
   if (A->epi & TF_EPI_MASK2) bytes += M * A->Cout * es;
   if (A->epi & TF_EPI_STATS3) bytes += M * A->Cout * es;
   tf::ProfScope prof(A->dtype == TF_BF16 ? 6 : 7, 2.0 * M * A->Cout * Kt, bytes, stream, (int)M, A->Cout, k.Ktot, 9, A->mode, A->epi, -1.0, true);   // 6 = conv3x3h bf16, 7 = f16
-  static const bool spec_off = getenv("TINYFACES_EPI_SPEC_OFF") != nullptr;       // A/B knob (shared with conv_dma)
+  const bool spec_off = tf::tuning().epi_spec_off;       // A/B knob (shared with conv_dma)
   if (g_trace) launch_var<T, true>(k, stream);
   else if (spec_off) launch_var<T, false>(k, stream);
   else if (A->epi == TF_EPI_STATS) launch_var<T, false, TF_EPI_STATS>(k, stream);                                           // training forward
@@ -483,11 +475,11 @@ bool tf_conv3x3h_applicable(const tf_conv_args* a, bool forced) {
   if (a->KH != 3 || a->KW != 3 || a->stride != 1 || a->pad != 1 || a->H != a->OH || a->W != a->OW) return false;
   if (a->Cin % 64 != 0 || a->Cout % BN != 0 || a->pro_scale) return false;
   if (forced) return true;
-  static const bool off = getenv("TINYFACES_CONV3H_OFF") != nullptr;
+  const bool off = tf::tuning().conv3h_off;
   if (off) return false;
   // >= 4 channel chunks (36 stages): with the 18 stages of layer 2 (128 channels) the prologue / epilogue weigh too much and the
   // 64 x 128 im2col tile wins (A/B on one box: 1116 / 1114 img/s without layer 2, 1107 / 1111 with)
-  static const int min_cin = [] { const char* e = getenv("TINYFACES_CONV3H_MINCIN"); return e ? atoi(e) : 256; }();
+  const int min_cin = tf::tuning().conv3h_mincin;
   if (a->Cin < min_cin) return false;
   const long blocks = (long)a->N * ((a->OH + TR - 1) / TR) * ((a->OW + TC - 1) / TC) * (a->Cout / BN);
   return blocks >= min_blocks();

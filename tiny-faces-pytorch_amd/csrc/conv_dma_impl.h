@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <type_traits>
 #include "common.h"
+#include "tuning.h"
 #include "profile.h"
 
 namespace {
@@ -339,7 +340,7 @@ __global__ void __launch_bounds__(256, MMA == 32 ? 2 : (NS <= 2 && BM == 128 && 
     // (ring-less, 1-4 stages, latency-bound with 4 blocks per CU), so the fix-up rides in time other blocks spend waiting, and the
     // separate bn_relu launch (one per bottleneck on the forward chain) disappears.  Coefficients: bn_fused.hip fwd_table, all Cin <= 256
     // channels per block, in a 2 KiB table behind the staging tile; block 0 publishes scale / shift / mean / invstd + running statistics.
-    constexpr bool FIX = KIND == 1 && sizeof(T) == 2 && EPIC < 0;      // (the specialised instantiations are never launched with a prologue)
+    constexpr bool FIX = TF_EXP && KIND == 1 && sizeof(T) == 2 && EPIC < 0;      // (the specialised instantiations are never launched with a prologue)
     constexpr int TAB_AT = (BUF > BM * (BN + 4) * 4 ? BUF : BM * (BN + 4) * 4);
     float* ctab = reinterpret_cast<float*>(smem + TAB_AT);
     if constexpr (FIX) {
@@ -584,6 +585,7 @@ int launch_kind(const tf_conv_args* A, hipStream_t stream, int pcls = -1) {
   k.stat_shift = A->stat_shift; k.stat_shift_out = A->stat_shift_out;
   k.pro = 0; k.pf_rows = 0; k.pf_count = k.pf_eps = k.pf_mom = 0.f;
   k.pf_stat = k.pf_gamma = k.pf_beta = k.pf_sshift = nullptr; k.pf_scale = k.pf_shift = k.pf_mean = k.pf_invstd = k.pf_rmean = k.pf_rvar = nullptr; k.pf_out = nullptr;
+  if (A->bnf && !TF_EXP) return TF_ERR_UNSUPPORTED;      // the in-LDS BatchNorm prologue is an experimental-build feature (common.h)
   if (A->bnf) {
     if (!(NS == 1 && KIND == 1 && sizeof(T) == 2) || A->Cin > 256) return TF_ERR_UNSUPPORTED;
     const tf_bn_fwd_desc* d = A->bnf;
@@ -613,16 +615,7 @@ int launch_kind(const tf_conv_args* A, hipStream_t stream, int pcls = -1) {
   k.ntiles = (A->Cout + BN - 1) / BN; k.mode = A->mode; k.epi = A->epi;
   const int mtiles = (k.M + BM - 1) / BM;
   k.mtiles = mtiles; k.srows = tf_get_stat_rows();
-  {
-    static int dbg = -1;
-    if (dbg < 0) {
-      const char* e = getenv("TF_CONV_DBG");
-      dbg = e ? atoi(e) : 0;
-      if (dbg & 15) fprintf(stderr, "tinyfaces: TF_CONV_DBG=%d -- timing-ablation mode, convolution RESULTS ARE INVALID\n", dbg);
-      else if (dbg) fprintf(stderr, "tinyfaces: TF_CONV_DBG=%d -- A/B form of the statistic epilogue (results unchanged)\n", dbg);
-    }
-    k.dbg = dbg;
-  }
+  k.dbg = tf::tuning().conv_dbg;
   size_t lds = (size_t)NS * (BM + BN) * 128;
   const size_t stg = (size_t)BM * (BN + 4) * 4;
   if (stg > lds) lds = stg;
@@ -664,7 +657,7 @@ int launch_kind(const tf_conv_args* A, hipStream_t stream, int pcls = -1) {
     constexpr bool SPEC = sizeof(T) == 2 && ((MMA == 32 && BM == 64 && BN == 128 && NS == 2) || (MMA == 16 && BM == 128 && BN == 64 && NS == 1 && KIND != 2) || (MMA == 16 && BM == 128 && BN == 64 && NS == 2 && KIND == 1) ||
                                              (MMA == 16 && BM == 64 && BN == 64 && NS <= 3));
     constexpr bool TRAIN = std::is_same<T, tf::bf16_t>::value;          // the training flag sets: bf16 only (fp16 is inference only)
-    static const bool spec_off = getenv("TINYFACES_EPI_SPEC_OFF") != nullptr;       // A/B knob
+    const bool spec_off = tf::tuning().epi_spec_off;       // A/B knob
     const dim3 grid(mtiles * k.ntiles);
     bool done = false;
     if constexpr (SPEC) {
@@ -700,7 +693,7 @@ int launch(const tf_conv_args* A, hipStream_t stream) {
   // gradient's own pixels, scattered to the even-even positions of the 2x larger output raster (the rest is zero, or the residual
   // operand): the pointwise kernel with a row map instead of the transposed gather over all four parities.  Epilogues that reduce over
   // the output raster (statistics) or read a mask there keep the generic kernel; TINYFACES_SCATTER_DGRAD_OFF=1: A/B knob.
-  static const bool scat_off = getenv("TINYFACES_SCATTER_DGRAD_OFF") != nullptr;
+  const bool scat_off = tf::tuning().scatter_dgrad_off;
   if (!scat_off && A->mode == 1 && A->KH == 1 && A->KW == 1 && A->stride == 2 && A->pad == 0 && A->OH >= 2 * A->H - 1 && A->OW >= 2 * A->W - 1 &&
       !(A->epi & ~(TF_EPI_RES | TF_EPI_AFFINE)) && A->ldy == A->Cout)
     return launch_kind<T, BM, BN, NS, 1, MMA>(A, stream);
@@ -709,7 +702,7 @@ int launch(const tf_conv_args* A, hipStream_t stream) {
   // walks all 9 for every pixel and reads the zero page for the rest (4x the stages, DMAs and MFMAs: 134 and 113 us per launch at
   // bs = 12, 8-13x over their roofline, profiles/r02_layer_table.md).  Four launches, each a gather over its class's half-resolution
   // raster with its own tap list; rows scatter back to (2h + ph, 2w + pw); statistic sums fold into the same rows by atomics.
-  static const bool par_off = getenv("TINYFACES_PARITY_DGRAD_OFF") != nullptr;
+  const bool par_off = tf::tuning().parity_dgrad_off;
   if (!par_off && A->mode == 1 && A->stride == 2 && A->KH == 3 && A->KW == 3 && A->pad == 1 && A->OH >= 2 && A->OW >= 2 &&
       (tf_get_stat_rows() <= TF_STAT_ROWS || !(A->epi & (TF_EPI_STATS | TF_EPI_STATS2 | TF_EPI_STATS3)))) {
     for (int pc = 0; pc < 4; ++pc) {
@@ -738,10 +731,10 @@ int launch_half(const tf_conv_args* a, int tile, int depth, hipStream_t stream) 
     // convs of up to 16 K-stages (every 1x1 of the trunk, K <= 1024) are dispatch + prologue + epilogue bound rather than
     // K-loop bound: a 2-deep ring is 32 KiB of LDS, so five blocks fit a CU instead of three and more of those phases
     // overlap.  A/B on one box, img/s: 956 (3-deep everywhere), 989 (<= 4 stages), 996 (<= 8), 1008 (<= 16), 1001 (all).
-    static const int ns2_max = [] { const char* e = getenv("TINYFACES_NS2_MAXSTAGES"); return e ? atoi(e) : 16; }();
+    const int ns2_max = tf::tuning().ns2_maxstages;
     const int nst = a->KH * a->KW * (a->Cin / 64);
     // ... and no ring at all up to 4 stages (17 KiB of LDS, 8 blocks/CU): 1007 -> 1013 img/s
-    static const int ns1_max = [] { const char* e = getenv("TINYFACES_NS1_MAXSTAGES"); return e ? atoi(e) : 4; }();
+    const int ns1_max = tf::tuning().ns1_maxstages;
     if (nst <= ns1_max) return launch<T, 64, 64, 1>(a, stream);
     if (nst <= ns2_max) return launch<T, 64, 64, 2>(a, stream);
     return launch<T, 64, 64, 3>(a, stream);

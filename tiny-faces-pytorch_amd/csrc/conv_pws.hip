@@ -27,6 +27,7 @@
 #include <cstdlib>
 #include <type_traits>
 #include "common.h"
+#include "tuning.h"
 #include "lds_dma.h"
 #include "profile.h"
 
@@ -359,9 +360,11 @@ int launch(const tf_conv_args* A, hipStream_t stream) {
   k.M = A->N * A->OH * A->OW; k.K = A->Cin; k.ntiles = (k.M + 15) / 16; k.srows = tf_get_stat_rows(); k.ldy = A->ldy;
   k.nsl = 1; k.nb = 1;
   const int ks = A->Cin / 64, nf = A->Cout / 16;
-  if (nf > 16) {                                                            // sliced: 128 output channels per block
+  if (nf > 16) {                                                            // sliced: 128 output channels per block (experimental build only)
+#if TF_EXP
     if (ks == 4) return launch_epi<T, 4, 8>(A, k, stream);                  // 256 -> 1024: conv3 of layer 3 and the data gradient of its conv1
     if (ks == 2) return launch_epi<T, 2, 8>(A, k, stream);                  // 128 -> 512: the same of layer 2
+#endif
     return TF_ERR_UNSUPPORTED;
   }
   if (ks == 1 && nf == 16) return launch_epi<T, 1, 16>(A, k, stream);     // 64 -> 256: conv3 / downsample of layer 1
@@ -400,8 +403,8 @@ bool tf_conv_pws_applicable(const tf_conv_args* a) {
     // sliced: 256 -> 512 / 1024, 128 -> 512 in slices of 128 output channels.  Built, parity-green (tile = 70 on request), and SLOWER than the
     // tiled kernel on every layer-2/3 shape (alone: 39.8 vs 24.9 us on the layer-3 hand-over gradient; in the step: -5 %, profiles/r05_conv_pws.txt):
     // two waves per CU hold one 24 KiB tile in flight each.  The dispatcher takes it only with TINYFACES_PWS_SLICED=1.
-    static const bool sliced = getenv("TINYFACES_PWS_SLICED") != nullptr;
-    if (!(ks == 4 || ks == 2) || a->Cout % 128 != 0 || M < 8192) return false;
+    const bool sliced = tf::tuning().pws_sliced;
+    if (!TF_EXP || !(ks == 4 || ks == 2) || a->Cout % 128 != 0 || M < 8192) return false;
     return sliced || a->tile == 70;
   }
   if (!((ks == 1 && nf == 16) || (ks == 4 && nf == 4) || (ks == 1 && nf == 4) || (ks == 4 && nf == 8))) return false;

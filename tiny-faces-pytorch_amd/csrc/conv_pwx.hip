@@ -27,9 +27,12 @@
 // MFMA roles (8 waves = 4 channel groups x 2 K halves on 32x32x16, halves merged through fp32 staging tiles) and the epilogue (every
 // TF_EPI_* flag, compile-time flag set EPIC for the executor's instantiations) are those of the r3 kernel / conv_dma.
 // bf16 only (the fp32 parity path keeps the unfused kernels).
+#include "common.h"
+#if TF_EXP
 #include <cstdio>
 #include <cstdlib>
 #include "common.h"
+#include "tuning.h"
 #include "lds_dma.h"
 #include "profile.h"
 
@@ -564,7 +567,7 @@ int tf_conv_pwx_launch(const tf_conv_args* A, const tf_bn_bwd_desc* pro, const v
   k.xc = (const char*)pro_x2; k.t1 = (char*)pro_out;
   k.pstat = pro->stat; k.pgamma = pro->gamma; k.pmean = pro->mean; k.pinvstd = pro->invstd; k.pdgamma = pro->dgamma; k.pdbeta = pro->dbeta;
   k.prows = pro_rows; k.pnk = pro->nk; k.pkidx = pro->kidx; k.pcount = pro_count;
-  static const bool spec_off = getenv("TINYFACES_EPI_SPEC_OFF") != nullptr;
+  const bool spec_off = tf::tuning().epi_spec_off;
   if (!spec_off && A->epi == (TF_EPI_MASK | TF_EPI_STATS2)) return launch_bn<2, TF_EPI_MASK | TF_EPI_STATS2>(A, k, wide, stream);     // the executor's conv3 data gradient
   return launch_bn<2, -1>(A, k, wide, stream);
 }
@@ -582,8 +585,15 @@ int tf_conv_pwx_launch_fwd(const tf_conv_args* A, const tf_bn_fwd_desc* bn, cons
   if (bn_res) k.f2 = tab_of(bn_res);
   k.feps = eps; k.fmom = momentum; k.prows = rows; k.pcount = count;
   const bool wide = A->Cout % 256 == 0;
-  static const bool spec_off = getenv("TINYFACES_EPI_SPEC_OFF") != nullptr;
+  const bool spec_off = tf::tuning().epi_spec_off;
   const bool spec = !spec_off && A->epi == TF_EPI_STATS;                                  // the executor's training-mode conv1
   if (bn_res) return spec ? launch_bn<4, TF_EPI_STATS>(A, k, wide, stream) : launch_bn<4, -1>(A, k, wide, stream);
   return spec ? launch_bn<3, TF_EPI_STATS>(A, k, wide, stream) : launch_bn<3, -1>(A, k, wide, stream);
 }
+
+#else   // default build: the fused BatchNorm prologues are not part of the library (common.h: TF_EXPERIMENTAL)
+bool tf_conv_pwx_applicable(const tf_conv_args*) { return false; }
+int tf_conv_pwx_mtiles(const tf_conv_args*) { return 0; }
+int tf_conv_pwx_launch(const tf_conv_args*, const tf_bn_bwd_desc*, const void*, void*, int, float, hipStream_t) { return TF_ERR_UNSUPPORTED; }
+int tf_conv_pwx_launch_fwd(const tf_conv_args*, const tf_bn_fwd_desc*, const void*, const tf_bn_fwd_desc*, void*, int, float, float, float, hipStream_t) { return TF_ERR_UNSUPPORTED; }
+#endif

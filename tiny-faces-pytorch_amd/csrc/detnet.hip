@@ -35,6 +35,7 @@
 #include <vector>
 
 #include "common.h"
+#include "tuning.h"
 
 extern "C" {
 int tf_stem_im2col(const float*, int, int, int, int, void*, int, void*);
@@ -56,10 +57,11 @@ int tf_bn_relu(int, const void*, const float*, const float*, int64_t, int, void*
 int tf_upsample_add_crop(int, const void*, const void*, const float*, int, int, int, int, int, int, int, float*, void*);
 int tf_upsample_add_crop_bwd(int, const float*, const float*, int, int, int, int, int, int, int, void*, void*, void*);
 int tf_reduce_partials(const float*, int, int, int, int, int, float*, int, void*);
-int tf_conv2d_bnbwd(const tf_conv_args*, const tf_bn_bwd_desc*, const void*, void*, int, float, void*);
-int tf_conv2d_bnfwd(const tf_conv_args*, const tf_bn_fwd_desc*, const void*, const tf_bn_fwd_desc*, void*, int, float, float, float, void*);
 int tf_conv2d_wgrad_group(const tf_wgrad_args*, int, void*);
 }
+// (conv_pwx.hip; TF_ERR_UNSUPPORTED in the default build: the C entry points tf_conv2d_bnbwd / tf_conv2d_bnfwd exist in the experimental build only)
+int tf_conv_pwx_launch(const tf_conv_args*, const tf_bn_bwd_desc*, const void*, void*, int, float, hipStream_t);
+int tf_conv_pwx_launch_fwd(const tf_conv_args*, const tf_bn_fwd_desc*, const void*, const tf_bn_fwd_desc*, void*, int, float, float, float, hipStream_t);
 
 namespace {
 
@@ -69,7 +71,7 @@ constexpr int kStemK = 192;     // 147 taps*channels padded to 3 x 64
 // TINYFACES_STEM_DIRECT_OFF=1: the path of rounds 1-3; TINYFACES_STEM_WGRAD_IM2COL=1: only the weight gradient over the im2col matrix (built on
 // the second stream at the top of the backward pass).
 bool stem_direct_mode(int dtype, bool training, bool fused) {
-  static const bool off = getenv("TINYFACES_STEM_DIRECT_OFF") != nullptr;
+  const bool off = tf::tuning().stem_direct_off;
   return !off && dtype != TF_F32 && (!training || fused);
 }
 constexpr int kHeadLd = 128;    // 125 outputs padded
@@ -140,7 +142,7 @@ const Arch& arch() {
 // this many bottlenecks per launch (tf_conv2d_wgrad_group: full-K tiles, no split-K / atomics / partial tiles); their dY operands then
 // live in per-block buffers instead of the two parity sets.  TINYFACES_WGRAD_GROUP=0: the per-block launches of rounds 1-3.
 inline int wgrad_group_size() {
-  static const int g = [] { const char* e = getenv("TINYFACES_WGRAD_GROUP"); const int v = e ? atoi(e) : 8; return v < 0 ? 0 : (v > 22 ? 22 : v); }();
+  const int g = tf::tuning().wgrad_group;
   return g;
 }
 inline bool wgrad_group_mode(int dtype, int training) { return training && dtype == TF_BF16 && wgrad_group_size() > 0; }
@@ -348,7 +350,7 @@ struct Ctx {
   // weight-gradient stream wait for it.  hipEventRecord costs a barrier packet = an ~8 us bubble on the data-gradient chain
   // (profiles/r02_step_timeline.txt), three to four times per bottleneck.
   hipEvent_t pending = nullptr;
-  static bool kernel_events() { static const bool on = getenv("TINYFACES_FORK_BY_RECORD") == nullptr; return on; }
+  static bool kernel_events() { return !tf::tuning().fork_by_record; }
   void arm_fork() { if (!side || !kernel_events()) return; pending = next_event(); if (pending) tf::set_next_stop_event(pending); }
   void fork_armed(hipStream_t to = nullptr) {
     if (!side) return;
@@ -418,7 +420,7 @@ void bn_forward(Ctx& c, const ConvUnit& u, int C, BnBuf& b, bool training, const
 // s in the extra row of the BN's statistic region, where the consumer's table picks it up (fused flow only; bn_fused.hip fwd_table).
 // E[x^2] - mean^2 from fp32 sums loses (mean / std)^2 of the significant bits; around the running mean it loses ((mean - s) / std)^2.
 void stat_shift(tf_conv_args& a, const Ctx& c, const ConvUnit& u, const BnBuf& b, bool fused) {
-  static const bool off = getenv("TINYFACES_STAT_SHIFT_OFF") != nullptr;       // A/B + parity knob
+  const bool off = tf::tuning().stat_shift_off;       // A/B + parity knob
   if (!fused || off || !b.fst || u.rmean < 0) return;
   a.stat_shift = (const float*)c.params[u.rmean];
   a.stat_shift_out = b.fst + (size_t)TF_STAT_ROWS * 2 * b.C;
@@ -513,7 +515,7 @@ namespace {
 hipStream_t make_stream() {
   hipStream_t s = nullptr;
   int least = 0, greatest = 0;
-  static const bool low_prio = getenv("TINYFACES_SIDE_PRIO_LOW") != nullptr;      // A/B knob (the default of rounds 1-2)
+  const bool low_prio = tf::tuning().side_prio_low;      // A/B knob (the default of rounds 1-2)
   if (!low_prio || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess ||
       hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least) != hipSuccess) {
     if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) s = nullptr;
@@ -576,7 +578,7 @@ extern "C" int tf_detnet_forward_ctx(tf_detnet_ctx* xctx, int single_stream, int
   // statistics folded into <= TF_STAT_ROWS rows: the elementwise consumers finalize them in-kernel (bn_fused.hip);
   // unfolded (tf_set_stat_rows(0), bit-reproducible sums): separate finalize kernels on the shared partial buffer
   const int srows = tf_get_stat_rows();
-  static const bool g_unfused_env = getenv("TINYFACES_UNFUSED_BN") != nullptr;     // A/B knob
+  const bool g_unfused_env = tf::tuning().unfused_bn;     // A/B knob
   const bool fused = tr && srows <= TF_STAT_ROWS && !g_unfused_env;
   // statistic rows start at zero: the per-BN regions and, right behind them in the arena, the head of the shared partial buffer -- ONE memset
   if (tr && hipMemsetAsync(P.stat_fwd, 0, (size_t)((char*)P.partial - (char*)P.stat_fwd) + (size_t)TF_STAT_ROWS * 3 * 1024 * 4, c.stream) != hipSuccess) c.chk(TF_ERR_LAUNCH);
@@ -587,12 +589,12 @@ extern "C" int tf_detnet_forward_ctx(tf_detnet_ctx* xctx, int single_stream, int
   // take as long as back to back and the fork / join events cost a little: 1153 / 1153 img/s against 1161 / 1159 inline (A/B on one box).
   bool pack_joined = false;
   hipStream_t g_pack_stream = nullptr;             // = the context's second stream: idle during the forward pass, no further hardware queue
-  static const bool pack_side_env = getenv("TINYFACES_PACK_SIDE") != nullptr;
+  const bool pack_side_env = tf::tuning().pack_side;
   // r3, second form: only the weights of layer 3 and of the heads (62 % of the bytes) go to the second stream, forked at the top of the step
   // and joined in front of the first layer-3 bottleneck: they are packed beside the stem and layers 1-2, whose launches are latency-bound
   // at bs = 12, instead of in front of them.  TINYFACES_PACK_SPLIT_OFF=1: everything inline.
-  static const bool pack_split_off = getenv("TINYFACES_PACK_SPLIT_OFF") != nullptr;
-  static const bool single_env = getenv("TINYFACES_SINGLE_STREAM") != nullptr;
+  const bool pack_split_off = tf::tuning().pack_split_off;
+  const bool single_env = tf::tuning().single_stream;
   const bool pack_split = tr && !ready && !pack_side_env && !pack_split_off && !single_env && !single_stream && xctx;
   bool pack_side = tr && !ready && (pack_side_env || pack_split);
   if (pack_side) {
@@ -605,7 +607,7 @@ extern "C" int tf_detnet_forward_ctx(tf_detnet_ctx* xctx, int single_stream, int
   const bool stem_direct = stem_direct_mode(dtype, tr, fused);
   // r4 experiment, NEGATIVE, opt-in (TINYFACES_PACK_FORK_LATE=1): the layer-3 packing forked BEHIND the stem conv instead of at the top of the
   // step (beside it the conv takes 99 instead of 56 us): 1273.0 / 1274.2 against 1276.1 / 1276.1 img/s -- the packing then overlaps layer 1
-  static const bool fork_late_env = getenv("TINYFACES_PACK_FORK_LATE") != nullptr;
+  const bool fork_late_env = tf::tuning().pack_fork_late;
   const bool pack_late = pack_side && pack_split && stem_direct && fork_late_env;
   if (pack_side && !pack_late) {           // everything enqueued so far (the previous step's SGD: the masters) precedes the packing
     if (hipEventRecord(xctx->pack_fork, c.stream) != hipSuccess || hipStreamWaitEvent(g_pack_stream, xctx->pack_fork, 0) != hipSuccess) c.chk(TF_ERR_LAUNCH);
@@ -622,7 +624,7 @@ extern "C" int tf_detnet_forward_ctx(tf_detnet_ctx* xctx, int single_stream, int
     // (TINYFACES_PACK_FIRST_SIDE=1): packed on the second stream as well, first in its order, beside the stem's im2col, the caller's
     // stream waiting for them in front of the stem conv
     if (pack_side && pack_split && (int)i == A.layer_end[1] + 1) {
-      static const bool first_inline = getenv("TINYFACES_PACK_FIRST_SIDE") == nullptr;
+      const bool first_inline = !tf::tuning().pack_first_side;
       if (first_inline) c.flush_packs();
       else {
         c.flush_packs(g_pack_stream);
@@ -700,7 +702,7 @@ extern "C" int tf_detnet_forward_ctx(tf_detnet_ctx* xctx, int single_stream, int
       tf_bn_fwd_desc dd; if (Bp.has_ds) dd = fwd_desc(c, Bp.ds, bp.bd);
       const void* resid = Bp.has_ds ? bp.d : (i >= 2 ? P.blk[i - 2].y : P.pool);
       a.x = bp.c3;
-      const int rc = tf_conv2d_bnfwd(&a, &d3, resid, Bp.has_ds ? &dd : nullptr, bp.y, srows, (float)Min, eps, mom, c.stream);
+      const int rc = tf_conv_pwx_launch_fwd(&a, &d3, resid, Bp.has_ds ? &dd : nullptr, bp.y, srows, (float)Min, eps, mom, c.stream);
       if (rc == TF_ERR_UNSUPPORTED) {              // a shape the fused kernel does not take after all: the two launches it stands for
         c.chk(tf_bn_add_relu_fused(dtype, bp.c3, &d3, resid, Bp.has_ds ? &dd : nullptr, srows, Min, B.cin, (float)Min, eps, mom, bp.y, c.stream));
         a.x = yin;
@@ -735,7 +737,7 @@ extern "C" int tf_detnet_forward_ctx(tf_detnet_ctx* xctx, int single_stream, int
     // forward chain but LOSES 1.3 % on the step (A/B 1101 vs 1116 img/s): each of the 4-16 channel tiles of a pixel tile repeats the
     // activation and the table derivation, and the extra barrier per stage sits in a launch that is latency-bound already.
     // TINYFACES_BNF=1 turns it on (kept for the eval-sized shapes where pixel tiles >> channel tiles).
-    static const bool bnf_on = getenv("TINYFACES_BNF") != nullptr;
+    const bool bnf_on = TF_EXP && tf::tuning().bnf;
     const bool bnf = fused && bnf_on && dtype != TF_F32 && pl <= 256;
     tf_bn_fwd_desc d2;
     if (fused) d2 = fwd_desc(c, B.c2, b.b2);
@@ -757,7 +759,7 @@ extern "C" int tf_detnet_forward_ctx(tf_detnet_ctx* xctx, int single_stream, int
     // (bf16 training, conv1 with 128 / 256 output channels and 128 ... 1024 input channels: layers 2 and 3).  OPT-IN (TINYFACES_PWX_FWD=1): measured
     // r5, it LOSES -- alone 37.4 us against 29.1 for the two launches at layer 3, 45.5 against 40.7 at layer 2 (profiles/r05_conv_pwx.txt); in the
     // step 1238-1240 img/s against 1277-1279 without it (same box).  DESIGN.md 7.
-    static const bool pwx_fwd_off = getenv("TINYFACES_PWX_FWD") == nullptr;
+    const bool pwx_fwd_off = !(TF_EXP && tf::tuning().pwx_fwd);
     if (fused && !pwx_fwd_off && dtype == TF_BF16 && i + 1 < A.blocks.size()) {
       const Block& Bn = A.blocks[i + 1];
       tail_deferred = Bn.cin == c4 && Bn.planes % 128 == 0 && Bn.cin % 64 == 0 && Bn.cin >= 128 && Bn.cin <= 1024;
@@ -824,7 +826,7 @@ tf_wgrad_args wgrad_args(const Ctx& c, const ConvUnit& u, int cout, int N, int H
 void wgrad(Ctx& c, const ConvUnit& u, int cout, int N, int H, int W, int OH, int OW, const void* x, int ldx, const void* dy, int lddy,
            const BnBuf* pro, int cin_override = 0, int k_override = 0, int dw_ld = 0, float* packed_scratch = nullptr, size_t scratch_floats = 0) {
   // timing-ablation knob (RESULTS INVALID): the step without any weight gradient = what the data-gradient chain costs when it owns the GPU
-  static const bool skip = [] { const bool s = getenv("TINYFACES_DBG_SKIP_WGRAD") != nullptr; if (s) fprintf(stderr, "tinyfaces: TINYFACES_DBG_SKIP_WGRAD -- weight gradients NOT computed, timing only\n"); return s; }();
+  const bool skip = tf::tuning().dbg_skip_wgrad;
   if (skip) return;
   const int cin = cin_override ? cin_override : u.cin, k = k_override ? k_override : u.k;
   tf_wgrad_args w = wgrad_args(c, u, cout, N, H, W, OH, OW, x, ldx, dy, lddy, cin_override, k_override, dw_ld);
@@ -834,7 +836,7 @@ void wgrad(Ctx& c, const ConvUnit& u, int cout, int N, int H, int W, int OH, int
     // gradient: no memset, no atomics, no transposing copy
     w.partial_ws = packed_scratch; w.partial_ws_bytes = scratch_floats * 4;
     if (tf_wgrad_workspace_bytes(&w) != 0 && tf_wgrad_workspace_bytes(&w) <= w.partial_ws_bytes) {
-      static const bool w3_off = getenv("TINYFACES_WGRAD3_OFF") != nullptr;
+      const bool w3_off = tf::tuning().wgrad3_off;
       if (!w3_off) { c.chk(tf_conv2d_wgrad(&w, c.wstream())); return; }
     }
     w.partial_ws = nullptr; w.partial_ws_bytes = 0;
@@ -898,14 +900,14 @@ extern "C" int tf_detnet_backward_ctx(tf_detnet_ctx* xctx, const tf_detnet_hooks
   build_plan(P, ar, dtype, N, H, W, nout, 1);
   if (!ar.ok) return TF_ERR_WORKSPACE;
   Ctx c{dtype, (hipStream_t)stream_, params, grads, TF_OK};   // (grads_zeroed / jobs default-initialised)
-  static const bool g_single_env = getenv("TINYFACES_SINGLE_STREAM") != nullptr;
+  const bool g_single_env = tf::tuning().single_stream;
   if (!g_single_env && !(hooks && hooks->single_stream) && xctx) {
     hipStream_t g_side = ctx_side(xctx);
     c.side = g_side; c.events = &xctx->events;
     // r4, measured NEGATIVE, opt-in (TINYFACES_GROUP_STREAM=1): the grouped launches on a third queue, so that the per-block gradients of
     // layer 3.0 / layers 1-2 do not queue up behind a group: 1170 / 1164 img/s against 1177 / 1181 on the second stream (A/B on one box,
     // main-queue idle time of the backward pass 508 instead of 379 us): a third busy queue costs more than the queueing it removes.
-    static const bool gstream_on = getenv("TINYFACES_GROUP_STREAM") != nullptr;
+    const bool gstream_on = tf::tuning().group_stream;
     if (g_side && gstream_on) c.gside = ctx_gside(xctx);
   }
   tf_conv_args a;
@@ -914,13 +916,13 @@ extern "C" int tf_detnet_backward_ctx(tf_detnet_ctx* xctx, const tf_detnet_hooks
   const void* res4 = P.blk[A.layer_end[2]].y;
 
   const int srows = tf_get_stat_rows();
-  static const bool g_unfused_env = getenv("TINYFACES_UNFUSED_BN") != nullptr;
+  const bool g_unfused_env = tf::tuning().unfused_bn;
   const bool fused = srows <= TF_STAT_ROWS && !g_unfused_env;   // see tf_detnet_forward
   // statistic rows start at zero: the per-BN backward regions + the head of this pass's partial buffer right behind them, ONE memset
   if (hipMemsetAsync(P.stat_bwd, 0, (size_t)((char*)P.partial_b - (char*)P.stat_bwd) + (size_t)TF_STAT_ROWS * 3 * 1024 * 4, c.stream) != hipSuccess) c.chk(TF_ERR_LAUNCH);
   // the forward pass took conv1 straight from the image.  Its weight gradient does too (tf_stem_wgrad); with TINYFACES_STEM_WGRAD_IM2COL=1 it
   // reduces over the im2col matrix as in rounds 1-3, built here on the second stream (beside the head's backward)
-  static const bool stem_wgrad_im2col = getenv("TINYFACES_STEM_WGRAD_IM2COL") != nullptr;
+  const bool stem_wgrad_im2col = tf::tuning().stem_wgrad_im2col;
   const bool stem_direct = stem_direct_mode(dtype, true, fused);
   if (stem_direct && stem_wgrad_im2col) {
     if (c.side) { c.fork(); c.chk(tf_stem_im2col(x, N, H, W, dtype, P.col, kStemK, c.side)); }
@@ -951,7 +953,7 @@ extern "C" int tf_detnet_backward_ctx(tf_detnet_ctx* xctx, const tf_detnet_hooks
       }
       split = split && mine;
     }
-    static const bool split_off = getenv("TINYFACES_GRAD_MEMSET_FULL") != nullptr;     // A/B + safety knob
+    const bool split_off = tf::tuning().grad_memset_full;     // A/B + safety knob
     if (split && !split_off) {
       if (lo > g0 && hipMemsetAsync(g0, 0, (size_t)(lo - g0), c.stream) != hipSuccess) c.chk(TF_ERR_LAUNCH);
       if (g1 > hi && hipMemsetAsync(hi, 0, (size_t)(g1 - hi), c.stream) != hipSuccess) c.chk(TF_ERR_LAUNCH);
@@ -1000,13 +1002,13 @@ extern "C" int tf_detnet_backward_ctx(tf_detnet_ctx* xctx, const tf_detnet_hooks
   c.chk(tf_conv2d(&a, c.stream));
 
   // one fork per weight gradient (default) or, TINYFACES_FORK_PER_BLOCK=1, one per block: measured 948 vs 943 img/s
-  static const bool fork_each = getenv("TINYFACES_FORK_PER_BLOCK") == nullptr;
+  const bool fork_each = !tf::tuning().fork_per_block;
   // Every fork makes its producer kernel carry a completion signal, which costs ~6 us of main-queue bubble behind that kernel
   // (profiles/r02b_step_timeline.txt: 90 x 5.9 us).  The 22 identity bottlenecks of layer 3 therefore fork ONCE, behind the
   // BN1-backward apply, when the dY operands of all three weight gradients exist: conv3's and conv2's gradients start ~100 us
   // later and overlap the next bottleneck instead, far from the end of the pass (layer 1 / 2 and the stem keep one fork per
   // gradient so that the tail of the weight-gradient stream stays short).  TINYFACES_L3_FORK_PER_WGRAD=1: the old schedule.
-  static const bool l3_single_fork = getenv("TINYFACES_L3_FORK_PER_WGRAD") == nullptr;
+  const bool l3_single_fork = !tf::tuning().l3_fork_per_wgrad;
   // r4: GROUPED weight gradients of the identity bottlenecks of layer 3.  Their three gradients are not launched
   // per block any more: the block's dY operands go to buffers of its own (Plan::Blk::gT1 / gT2 / gU1), the problems are queued, and when
   // a group is complete -- behind the BN1-backward apply of its LAST (lowest) block, the kernel that produces the group's last operand --
@@ -1022,7 +1024,7 @@ extern "C" int tf_detnet_backward_ctx(tf_detnet_ctx* xctx, const tf_detnet_hooks
   std::vector<int> pend_blocks;
   auto flush_group = [&]() {
     if (pend_blocks.empty()) return;
-    static const bool skip = getenv("TINYFACES_DBG_SKIP_WGRAD") != nullptr;
+    const bool skip = tf::tuning().dbg_skip_wgrad;
     if (!skip) {
       // the 3x3 group first: 16 tiles per problem = half a machine for a group of eight; the pointwise launch behind it fills the CUs its
       // tail leaves (both are enqueued behind the same fork)
@@ -1036,14 +1038,14 @@ extern "C" int tf_detnet_backward_ctx(tf_detnet_ctx* xctx, const tf_detnet_hooks
           c.chk(tf_conv2d_wgrad(&w, c.gstream()));
         }
       };
-      static const bool force_refuse = getenv("TINYFACES_DBG_GROUP_REFUSE") != nullptr;      // test knob: exercise the fallback at any size
+      const bool force_refuse = tf::tuning().dbg_group_refuse;      // test knob: exercise the fallback at any size
       int rc = force_refuse ? TF_ERR_UNSUPPORTED : tf_conv2d_wgrad_group(pend_c3.data(), (int)pend_c3.size(), c.gstream());
       if (rc == TF_ERR_UNSUPPORTED) fallback(pend_c3);
       else c.chk(rc);
       // r5: the pointwise group in `pw_split` launches (default 1).  A group of eight bottlenecks is 256 tiles = one block on EVERY CU for
       // ~150 us, and beside it the chain's kernels crawl (profiles/r05_step_timeline.txt: the data gradient that normally takes 22 us
       // takes 118-130 us while the group runs); split, each launch leaves CUs to the chain.  TINYFACES_WGRADG_SPLIT=n.
-      static const int pw_split = [] { const char* e = getenv("TINYFACES_WGRADG_SPLIT"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : v; }();
+      const int pw_split = tf::tuning().wgradg_split;
       const int npw = (int)pend_pw.size(), per = (npw + pw_split - 1) / pw_split;
       rc = TF_OK;
       for (int at = 0; at < npw && rc == TF_OK; at += per)
@@ -1084,15 +1086,15 @@ extern "C" int tf_detnet_backward_ctx(tf_detnet_ctx* xctx, const tf_detnet_hooks
     // Measured r5 (profiles/r05_conv_pwx.txt): alone 27.8 us against 29.9 for the two launches at layer 3 but 46.8 against 40.9 at layer 2 (one block
     // per CU with the deep rings); in the step: off 1287-1294, layer 2 only 1280-1287, layers 2 + 3 1277-1279 img/s.  So the fused form is
     // OPT-IN now: TINYFACES_PWX_BWD=1 (layer 2) / TINYFACES_PWX_ALL=1 (layers 2 and 3).
-    static const bool pwx_all = getenv("TINYFACES_PWX_ALL") != nullptr;
-    static const bool pwx_off = getenv("TINYFACES_PWX_OFF") != nullptr || (getenv("TINYFACES_PWX_BWD") == nullptr && !pwx_all);
+    const bool pwx_all = TF_EXP && tf::tuning().pwx_all;
+    const bool pwx_off = !TF_EXP || tf::tuning().pwx_off || (!tf::tuning().pwx_bwd && !pwx_all);
     bool fused24 = false;
     if (fused && !pwx_off && dtype == TF_BF16 && !B.has_ds && pl % 128 == 0 && (pl == 128 || pwx_all)) {
       const tf_bn_bwd_desc d = bwd_desc(c, B.c3, b.b3, b.b3.bst, nk, 1);
       conv_fill(a, dtype, 1, N, b.Hout, b.Wout, c4, b.Hout, b.Wout, pl, 1, 1, 0, pl, Gcur, b.w3t, T2);
       a.epi = TF_EPI_MASK | TF_EPI_STATS2; a.aux = b.c2; a.mask_scale = b.b2.scale; a.mask_shift = b.b2.shift; a.stat_out = b.b2.bst;
       if (fork_each && !late && !grouped) c.arm_fork();
-      const int rc = tf_conv2d_bnbwd(&a, &d, b.c3, T1, srows, (float)Mout, c.stream);
+      const int rc = tf_conv_pwx_launch(&a, &d, b.c3, T1, srows, (float)Mout, c.stream);
       if (rc == TF_OK) fused24 = true;
       else if (rc != TF_ERR_UNSUPPORTED) c.chk(rc);
       else if (tf::take_next_stop_event()) c.pending = nullptr;       // the armed event was not consumed: arm again below
@@ -1158,7 +1160,7 @@ extern "C" int tf_detnet_backward_ctx(tf_detnet_ctx* xctx, const tf_detnet_hooks
     //      its BN3-backward sums (STATS3 with aux3 = its c3), so the next iteration starts at step (2).
     auto hand_over = [&](tf_conv_args& q) {
       if (!fused || i == 0) return;                        // block 0's input is the max-pool output: no ReLU in between
-      static const int ho_tile = [] { const char* e = getenv("TINYFACES_HANDOVER_TILE"); return e ? atoi(e) : 0; }();     // A/B knob: tile code of the hand-over data gradients
+      const int ho_tile = tf::tuning().handover_tile;     // A/B knob: tile code of the hand-over data gradients
       if (ho_tile) q.tile = ho_tile;
       q.epi |= TF_EPI_MASK2; q.aux2 = yin;
       if (!A.blocks[i - 1].has_ds) { q.epi |= TF_EPI_STATS3; q.aux3 = P.blk[i - 1].c3; q.stat_out = P.blk[i - 1].b3.bst; }
@@ -1211,7 +1213,7 @@ extern "C" int tf_detnet_backward_ctx(tf_detnet_ctx* xctx, const tf_detnet_hooks
   void* gz = P.T4;                          // main-stream scratch (its last reader, block 0's conv1 dgrad, is ahead on this stream)
   // r4: the statistic sums of the stem's BN backward ride in the max-pool backward (gz and x are in its registers): one pass over two 96 MB
   // tensors and one launch fewer at the very end of the chain (TINYFACES_POOL_STATS_OFF=1: the two-pass form)
-  static const bool pool_stats_off = getenv("TINYFACES_POOL_STATS_OFF") != nullptr;
+  const bool pool_stats_off = tf::tuning().pool_stats_off;
   int nb = 0;
   if (fused && !pool_stats_off) {
     c.chk(tf_maxpool_bwd_stats(dtype, Gcur, P.pool_idx, P.cstem, P.bn_stem.scale, P.bn_stem.shift, N, P.H1, P.W1, 64, gz, P.partial_b, &nb, c.stream));
@@ -1223,7 +1225,7 @@ extern "C" int tf_detnet_backward_ctx(tf_detnet_ctx* xctx, const tf_detnet_hooks
   bn_backward_coefs(c, A.stem, 64, P.bn_stem, P.partial_b, nb, 2, 1, 64, (float)M1);
   // (r4: with the direct weight gradient the apply rides in that kernel's staging -- its output has no other reader)
   const bool stem_wgrad_direct = stem_direct && !stem_wgrad_im2col;
-  static const bool stem_apply_off = getenv("TINYFACES_STEM_APPLY_SEPARATE") != nullptr;
+  const bool stem_apply_off = tf::tuning().stem_apply_separate;
   const bool stem_apply_fused = stem_wgrad_direct && !stem_apply_off;
   if (!stem_apply_fused) c.chk(tf_bn_bwd_apply(dtype, gz, nullptr, P.cstem, P.bn_stem.cA, P.bn_stem.cB, P.bn_stem.cD, M1, 64, gz, c.stream));
   // P.col still holds the im2col matrix of this forward (nothing else is carved from that range)

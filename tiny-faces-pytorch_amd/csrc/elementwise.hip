@@ -6,6 +6,7 @@
 
 #include <cstdlib>
 #include "common.h"
+#include "tuning.h"
 
 namespace {
 
@@ -781,7 +782,7 @@ extern "C" int tf_maxpool_bwd_stats(int dtype, const void* g, const uint8_t* arg
   const size_t total = (size_t)N * H * W * (C / eps);
   // (every block folds 2 * C sums into the rows with atomics; capping the grid below the plain kernel's 8192 blocks was measured slower --
   //  103 us at 8192, 116 us at 1024 -- the longer grid-stride loops cost more than the atomics: TINYFACES_POOL_STATS_BLOCKS re-measures)
-  static const unsigned cap = [] { const char* e = getenv("TINYFACES_POOL_STATS_BLOCKS"); return e ? (unsigned)atoi(e) : 8192u; }();
+  const unsigned cap = (unsigned)tf::tuning().pool_stats_blocks;
   unsigned grid = grid_for(total);
   if (grid > cap && cap >= 1) grid = cap;
   const int srows = tf_get_stat_rows();

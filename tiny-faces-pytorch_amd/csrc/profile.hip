@@ -4,6 +4,7 @@
 #include <vector>
 
 #include "common.h"
+#include "tuning.h"
 #include "profile.h"
 
 namespace {
@@ -27,7 +28,7 @@ tf::ProfScope::ProfScope(int kind, double flops, double bytes, hipStream_t s, in
                          bool kernel_mode)
     : slot(-1), stream(s), state(0) {
   if (!g_every) return;
-  static const bool force_bracket = getenv("TINYFACES_PROFILE_BRACKET") != nullptr;
+  const bool force_bracket = tf::tuning().profile_bracket;
   std::lock_guard<std::mutex> lk(g_mu);
   if (g_seq++ % (unsigned long long)g_every) return;
   Rec r{kind, flops, bytes, exec_flops < 0 ? flops : exec_flops, get_event(), get_event(), M, N, K, taps, mode, epi};

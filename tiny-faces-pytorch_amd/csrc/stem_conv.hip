@@ -13,6 +13,7 @@
 // channels of one pixel.
 #include <cstdlib>
 #include "common.h"
+#include "tuning.h"
 #include "profile.h"
 
 namespace {
@@ -483,7 +484,7 @@ extern "C" int tf_stem_wgrad(int dtype, const float* x_nchw, int N, int H, int W
   k.ntiles = (int)nt;
   // 384 blocks: 1.5 per CU -- more blocks overlap their staging and MFMA phases better but every block adds 9408 atomics (microbenchmark at
   // bs = 12: 256 blocks 118 us, 384: 91, 512: 95, 768: 126)
-  static const unsigned want = [] { const char* e = getenv("TINYFACES_STEM_WGRAD_BLOCKS"); return e ? (unsigned)atoi(e) : 384u; }();
+  const unsigned want = (unsigned)tf::tuning().stem_wgrad_blocks;
   unsigned grid = want < 1 ? 1 : want;
   if ((long)grid > nt) grid = (unsigned)nt;
   hipStream_t stream = (hipStream_t)stream_;

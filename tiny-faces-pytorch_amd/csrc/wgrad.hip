@@ -14,6 +14,7 @@
 // Split-K partial tiles are combined with fp32 atomics straight into the OIHW gradient
 // (coalesced 64-byte runs along ci for 1x1 convs).
 #include "common.h"
+#include "tuning.h"
 #include "profile.h"
 
 int tf_wgrad_dma_launch(const tf_wgrad_args* a, hipStream_t stream);
@@ -231,7 +232,7 @@ extern "C" int tf_conv2d_wgrad(const tf_wgrad_args* a, void* stream_) {
   // tile: 0 = auto (bf16, no prologue: the all-taps kernel for 3x3 / stride 1 / pad 1, else the per-tap LDS-DMA pipeline),
   //       1 = force the per-tap DMA kernel, 3 = force the all-taps kernel, 64 / 128 = register-staged kernel
   if ((a->tile == 0 || a->tile == 3) && a->dtype == TF_BF16 && !a->pro_scale) {
-    static const bool w3_off = getenv("TINYFACES_WGRAD3_OFF") != nullptr;          // A/B knob
+    const bool w3_off = tf::tuning().wgrad3_off;          // A/B knob
     const int rc = (w3_off && a->tile == 0) ? TF_ERR_UNSUPPORTED : tf_wgrad3x3_launch(a, stream);
     if (rc != TF_ERR_UNSUPPORTED || a->tile == 3) return rc;
   }

@@ -24,6 +24,7 @@
 // bf16 only, no prologue.
 #include <cstdlib>
 #include "common.h"
+#include "tuning.h"
 #include "profile.h"
 #include "lds_dma.h"
 
@@ -349,7 +350,7 @@ bool w3_plan(const tf_wgrad_args* A, W3K& k) {
   if (sk <= 0) {
     // one block per CU (88 KiB of LDS): split the padded pixel range until ~256 blocks exist, but keep >= 6 stages per block
     // so that the 2*hb halo chunks and the nine-tap epilogue stay a small part of a block
-    static const int target = [] { const char* e = getenv("TINYFACES_WGRAD3_BLOCKS"); return e ? atoi(e) : 256; }();
+    const int target = tf::tuning().wgrad3_blocks;
     sk = (target + tiles - 1) / tiles;
     const int maxsk = (k.Mp + 6 * PK - 1) / (6 * PK);
     if (sk > maxsk) sk = maxsk;
@@ -374,9 +375,9 @@ int tf_wgrad3x3_launch(const tf_wgrad_args* A, hipStream_t stream) {
   W3K k;
   if (!w3_plan(A, k)) return TF_ERR_UNSUPPORTED;
   const size_t need = (size_t)k.splitk * k.nco * k.nci * TILE_FLOATS * sizeof(float);
-  static const bool atomics_only = getenv("TINYFACES_WGRAD3_ATOMICS") != nullptr;      // A/B knob
+  const bool atomics_only = tf::tuning().wgrad3_atomics;      // A/B knob
   if (A->partial_ws && A->partial_ws_bytes >= need && !atomics_only) k.partial = (float*)A->partial_ws;
-  static const int dbg = [] { const char* e = getenv("TINYFACES_WGRAD3_DBG"); return e ? atoi(e) : 0; }();     // timing ablation: 1 = no MFMA loop body, 2 = no partial stores (results invalid)
+  const int dbg = tf::tuning().wgrad3_dbg;     // timing ablation: 1 = no MFMA loop body, 2 = no partial stores (results invalid)
   k.dbg = dbg;
   const size_t lds = (size_t)NS * YT + XBYTES;
   static bool attr_set = false;

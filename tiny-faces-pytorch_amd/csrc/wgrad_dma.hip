@@ -7,6 +7,7 @@
 // 64 banks exactly once.  No producer-BN prologue: the executor hands materialised activations.
 #include <cstdlib>
 #include "common.h"
+#include "tuning.h"
 #include "profile.h"
 #include "lds_dma.h"
 
@@ -184,7 +185,7 @@ int tf_wgrad_dma_launch(const tf_wgrad_args* A, hipStream_t stream) {
   const int ntaps = A->KH * A->KW, tiles = k.nco * k.nci * ntaps;
   int sk = A->splitk;
   if (sk <= 0) {
-    static const int target = [] { const char* e = getenv("TINYFACES_WGRAD_BLOCKS"); return e ? atoi(e) : 512; }();
+    const int target = tf::tuning().wgrad_blocks;
     sk = (target + tiles - 1) / tiles;                      // ~512 blocks measured best (scripts/microbench.py wgrad)
     const int maxsk = (k.M + 4 * PK - 1) / (4 * PK);
     if (sk > maxsk) sk = maxsk;
@@ -194,7 +195,7 @@ int tf_wgrad_dma_launch(const tf_wgrad_args* A, hipStream_t stream) {
   k.splitk = (k.M + k.chunk - 1) / k.chunk;
   // ring depth: the weight gradients share every CU's 160 KiB of LDS with the data-gradient chain on the other stream
   // (profiles/r03_contention.txt); TINYFACES_WGRAD_NS=2 trades a shallower ring for a third less LDS per block
-  static const int ns = [] { const char* e = getenv("TINYFACES_WGRAD_NS"); const int v = e ? atoi(e) : 3; return v == 2 ? 2 : 3; }();
+  const int ns = tf::tuning().wgrad_ns;
   const size_t lds = (size_t)ns * BUF;
   auto lds3 = [] { return (size_t)3 * BUF; };
   const bool pointwise = ntaps == 1 && A->stride == 1 && A->pad == 0 && A->H == A->OH && A->W == A->OW;
@@ -202,7 +203,7 @@ int tf_wgrad_dma_launch(const tf_wgrad_args* A, hipStream_t stream) {
   tf::ProfScope prof(14, 2.0 * Md * A->Cout * A->Cin * ntaps,
                      (Md * A->Cout + (double)A->N * A->H * A->W * A->Cin) * 2 + (double)A->Cout * A->Cin * ntaps * 4, stream, k.M, A->Cout,
                      A->Cin * ntaps, ntaps, 2, 0, -1.0, true);
-  static const bool builtin_dma = getenv("TINYFACES_DMA_BUILTIN") != nullptr;       // A/B: the compiler-visible DMA of rounds 1-3 (drained every stage)
+  const bool builtin_dma = tf::tuning().dma_builtin;       // A/B: the compiler-visible DMA of rounds 1-3 (drained every stage)
   const dim3 grid(tiles * k.splitk);
   if (builtin_dma) {
     if (pointwise) TF_LAUNCH_TIMED((wgrad_dma_kernel<1, 3, false>), grid, dim3(256), lds3(), stream, k);

@@ -24,6 +24,7 @@
 // torchvision's Bottleneck); bf16 only (the fp32 parity path keeps wgrad.hip).
 #include <cstdlib>
 #include "common.h"
+#include "tuning.h"
 #include "profile.h"
 #include "lds_dma.h"
 
@@ -356,7 +357,7 @@ int tf_wgrad_pw_group_launch(const tf_wgrad_args* A, int n, hipStream_t stream) 
   }
   // kind 18 = grouped pointwise weight gradient (bench.py tables); the GEMM view is the SUM over the group
   tf::ProfScope prof(18, flops, bytes, stream, k.M, A[0].Cout, A[0].Cin, 1, 2, 0, -1.0, true);
-  static const int fast_ns = [] { const char* e = getenv("TINYFACES_WGRADG_FAST"); return e ? atoi(e) : 8; }();      // 0: the generic kernel (A/B); 4 / 8: ring depth of the fast one
+  const int fast_ns = tf::tuning().wgradg_fast;      // 0: the generic kernel (A/B); 4 / 8: ring depth of the fast one
   if (full && fast_ns == 4 && (k.M / GP_PK) % 4 == 0) {
     TF_LAUNCH_TIMED((wgrad_group_fast_kernel<4>), dim3(tiles), dim3(256), (size_t)4 * GP_STAGE, stream, k);
   } else if (full && fast_ns == 8 && (k.M / GP_PK) % 8 == 0) {

@@ -8,6 +8,7 @@ Additions (existing flags keep their names and defaults): --fused / --no-fused (
 autograd), --dtype bf16|fp32, --synthetic-len.  The schedule is the reference's: SGD(momentum, weight decay), StepLR(20),
 a checkpoint every --save-every epochs (main.py:39-104)."""
 import argparse
+import os
 from pathlib import Path
 
 import torch
@@ -38,7 +39,22 @@ EXTRA_FLAGS = [
     ("--seed", dict(default=0, type=int, help="synthetic data / sampling seed (each rank derives its own from it)")),
     ("--pretrained", dict(default="", help="local torchvision-format resnet101 state_dict (.pth) for the trunk: the reference starts "
                                            "from ResNet101_Weights.IMAGENET1K_V1 (model.py:13-14), which it downloads; there is no network here")),
+    ("--init", dict(default="tame", choices=["tame", "kaiming"],
+                    help="from-scratch runs only (no --resume / --pretrained): `tame` = the last BN of every bottleneck at 0.1 and the head weights x 0.05 "
+                         "(plain kaiming saturates the sigmoid of a 101-layer random trunk: SURVEY.md 7.1); `kaiming` = torch's defaults")),
+    ("--save-path", dict(dest="save_path", default="weights", help="directory of the checkpoints (the reference writes ./weights, trainer.py:20-28)")),
 ]
+
+
+def tame_init_(model):
+    """From-scratch initialisation that trains: bn3.weight = 0.1 in every bottleneck (the residual branches start small), head weights x 0.05."""
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if name.endswith("bn3.weight"):
+                p.fill_(0.1)
+        for name in ("score_res3", "score_res4"):
+            getattr(model, name).weight.mul_(0.05)
+    return model
 
 
 def arguments(argv=None):
@@ -82,7 +98,7 @@ def main():
     args = arguments()
     if not torch.cuda.is_available():
         raise SystemExit("this build of the tiny-faces hot path runs on MI355X only (no CPU fallback)")
-    parallel.init_from_env()
+    parallel.init_from_env(os.environ.get("TINYFACES_DIST_BACKEND"))      # (gloo: several ranks on one device, the functional tests of a 1-GPU box)
     device = torch.device("cuda", torch.cuda.current_device())
     preprocess = transforms.Compose([transforms.ToTensor(), transforms.Normalize(mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225])])
     train_loader, _ = get_dataloader(args.traindata, args, NUM_TEMPLATES, img_transforms=preprocess)
@@ -97,9 +113,12 @@ def main():
         first_epoch = first_epoch or state["epoch"]
     elif args.pretrained:
         load_pretrained_trunk(model, args.pretrained)
-    elif parallel.rank() == 0:
-        print("WARNING: training starts from RANDOM (kaiming) weights. The reference starts from ImageNet ResNet-101 "
-              "(model.py:13-14); its lr / schedule will not reproduce its results from scratch. Pass --pretrained <resnet101.pth>.")
+    else:
+        if args.init == "tame":
+            tame_init_(model)
+        if parallel.rank() == 0:
+            print(f"WARNING: training starts from RANDOM ({args.init}) weights. The reference starts from ImageNet ResNet-101 "
+                  "(model.py:13-14); its lr / schedule will not reproduce its results from scratch. Pass --pretrained <resnet101.pth>.")
 
     engine = optimizer = scheduler = None
     if args.fused:
@@ -142,7 +161,7 @@ def main():
                 engine.set_lr(lr_at(args.lr, done))                       # what StepLR would have left in the param groups
             snapshot = {"epoch": done, "batch_size": train_loader.batch_size, "model": model.state_dict(),          # main.py:97-102
                         "optimizer": optimizer.state_dict() if optimizer is not None else engine.optimizer_state_dict(base_lr=args.lr)}
-            trainer.save_checkpoint(snapshot, filename=f"checkpoint_{done}.pth", save_path=Path("weights"))
+            trainer.save_checkpoint(snapshot, filename=f"checkpoint_{done}.pth", save_path=Path(args.save_path))
 
 
 if __name__ == "__main__":

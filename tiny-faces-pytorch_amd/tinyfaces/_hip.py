@@ -125,8 +125,6 @@ _SIGNATURES = {
     "tf_bn_relu_fused": (i32, [i32, vp, C.POINTER(BnFwdDesc), i32, i64, i32, f32, f32, f32, vp, vp]),
     "tf_bn_add_relu_fused": (i32, [i32, vp, C.POINTER(BnFwdDesc), vp, C.POINTER(BnFwdDesc), i32, i64, i32, f32, f32, f32, vp, vp]),
     "tf_bn_bwd_apply_fused": (i32, [i32, vp, vp, vp, C.POINTER(BnBwdDesc), i32, i64, i32, f32, vp, vp]),
-    "tf_conv2d_bnbwd": (i32, [C.POINTER(ConvArgs), C.POINTER(BnBwdDesc), vp, vp, i32, f32, vp]),
-    "tf_conv2d_bnfwd": (i32, [C.POINTER(ConvArgs), C.POINTER(BnFwdDesc), vp, C.POINTER(BnFwdDesc), vp, i32, f32, f32, f32, vp]),
     "tf_upsample_add_crop": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
     "tf_upsample_add_crop_bwd": (i32, [i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
     "tf_reduce_partials": (i32, [vp, i32, i32, i32, i32, i32, vp, i32, vp]),
@@ -173,6 +171,18 @@ _DEBUG_SIGNATURES = {
 _lib = None
 
 
+# entry points of the EXPERIMENTAL build only (build.py --experimental; include/tinyfaces_hip.h `#ifdef TF_EXPERIMENTAL`): bound when the library has them
+_EXPERIMENTAL_SIGNATURES = {
+    "tf_conv2d_bnbwd": (i32, [C.POINTER(ConvArgs), C.POINTER(BnBwdDesc), vp, vp, i32, f32, vp]),
+    "tf_conv2d_bnfwd": (i32, [C.POINTER(ConvArgs), C.POINTER(BnFwdDesc), vp, C.POINTER(BnFwdDesc), vp, i32, f32, f32, f32, vp]),
+}
+
+
+def experimental():
+    """True when the loaded library was built with TF_EXPERIMENTAL (the measured-and-lost kernels compiled in)."""
+    return lib().tf_build_id().decode().endswith("+x")
+
+
 def lib():
     """The loaded library (raises HipLibraryMissing with build instructions if absent)."""
     global _lib
@@ -185,7 +195,7 @@ def lib():
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(l, name)          # AttributeError here == ABI mismatch with include/tinyfaces_hip.h
             fn.restype, fn.argtypes = res, args
-        for name, (res, args) in _DEBUG_SIGNATURES.items():
+        for name, (res, args) in list(_DEBUG_SIGNATURES.items()) + list(_EXPERIMENTAL_SIGNATURES.items()):
             fn = getattr(l, name, None)
             if fn is not None:
                 fn.restype, fn.argtypes = res, args

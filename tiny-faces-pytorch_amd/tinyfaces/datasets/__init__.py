@@ -9,7 +9,7 @@ import numpy as np
 import torch
 from torch.utils import data
 
-from .synthetic import SyntheticCrops, TargetAssigner  # noqa: F401
+from .synthetic import SyntheticCrops, SyntheticFaces, TargetAssigner  # noqa: F401
 from .templates import load_templates
 
 
@@ -25,6 +25,15 @@ def get_dataloader(datapath, args, num_templates=25, template_file="templates.js
     from .. import parallel
     templates = load_templates(num_templates)
     world, rank = (parallel.world_size(), parallel.rank()) if parallel.is_distributed() else (1, 0)
+    if str(datapath) == "synthetic-faces":
+        # r6: a small FIXED image list with pasted faces (datasets/synthetic.py: SyntheticFaces) -- the same images for training and evaluation,
+        # so that train -> checkpoint -> pyramid evaluation -> result files -> AP can be closed without WIDER assets.  Data parallel: rank r
+        # trains on images r, r + world, ... (disjoint shards of the fixed list) and evaluates the same stride.
+        length = getattr(args, "synthetic_len", 8)
+        ds = SyntheticFaces(templates, length=length, seed=getattr(args, "seed", 0), train=train, img_transforms=img_transforms)
+        idx = list(range(rank, length, world)) if world > 1 else None
+        loader = data.DataLoader(ds, batch_size=args.batch_size, shuffle=False, sampler=idx, num_workers=0, collate_fn=ds.collate)
+        return loader, templates
     if str(datapath) == "synthetic" or getattr(args, "synthetic", False):
         length = getattr(args, "synthetic_len", 256)
         if train:
