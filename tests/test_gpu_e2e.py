@@ -50,15 +50,17 @@ def test_train_checkpoint_evaluate_ap_on_pasted_faces(tmp_path, ranks):
         launch = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
                   "--master-port", str(29560 + ranks)]
     weights, results = str(tmp_path / "weights"), str(tmp_path / "results")
-    # 300 steps of the fused engine at a constant learning rate: 3 epochs of 800 samples (the eight images walked 100 times), batch 8
-    # (two ranks: 4 images each per step, gradients averaged -- the same 300 global steps)
-    bs = 8 // ranks
-    r = _run(launch + [os.path.join(PKG, "main.py"), "synthetic-faces", "synthetic-faces", "--epochs", "3", "--synthetic-len", "800", "--batch_size", str(bs),
-                       "--lr", "1e-3", "--save-every", "3", "--save-path", weights, "--dtype", "bf16"], str(tmp_path), env)
+    # 300 steps of the fused engine at a constant learning rate: 3 epochs of 3200 samples in batches of 32 = the eight images x their four views
+    # (the image itself and its x0.5 / x2 / x0.25 resamplings: what the evaluation pyramid will show), the same batch every step; two ranks: 16 each
+    # (four layouts per rank, gradients averaged -- the same 300 global steps).  --ohem-thresh 0: with the reference's mining (defect D7) a positive
+    # the classifier is sure of leaves the regression loss too, and the boxes of this from-scratch detector stay 10-20 pixels off (AP 0.3-0.8).
+    bs = 32 // ranks
+    r = _run(launch + [os.path.join(PKG, "main.py"), "synthetic-faces", "synthetic-faces", "--epochs", "3", "--synthetic-len", "3200", "--batch_size", str(bs),
+                       "--lr", "2e-4", "--save-every", "3", "--save-path", weights, "--dtype", "bf16", "--ohem-thresh", "0"], str(tmp_path), env)
     ckpt = os.path.join(weights, "checkpoint_3.pth")
     assert os.path.exists(ckpt), r.stdout[-2000:]
     _run(launch + [os.path.join(PKG, "evaluate_model.py"), "synthetic-faces", "--checkpoint", ckpt, "--num-images", "8", "--results_dir", results,
-                   "--prob_thresh", "0.1"], str(tmp_path), env)
+                   "--prob_thresh", "0.1", "--mask-axis", "template"], str(tmp_path), env)
     ap, ndet, nface = _ap(results)
     report(f"learn_and_detect[ranks={ranks}]", ap=float(ap), faces=nface, detections=str(ndet))
     assert ap > 0.9, (ap, ndet, nface)

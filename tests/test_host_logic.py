@@ -365,11 +365,12 @@ def test_entry_script_flags_match_the_reference(golden):
             assert got[k] == "" and v is False
         else:
             assert got[k] == v, k
-    assert set(got) - set(ref) == {"fused", "dtype", "synthetic_len", "seed", "pretrained", "init", "save_path"}      # r6: --init tame|kaiming, --save-path
+    assert set(got) - set(ref) == {"fused", "dtype", "synthetic_len", "seed", "pretrained", "init", "save_path", "ohem_thresh"}      # r6: --init, --save-path, --ohem-thresh (default = loss.py:62)
+    assert got["ohem_thresh"] == 0.03
     ref = json.loads(str(g["evaluate_model"]))
     got = ours("evaluate_model.py", ["DATA"])
     assert {k: got[k] for k in ref} == ref
-    assert set(got) - set(ref) == {"num_images"}
+    assert set(got) - set(ref) == {"num_images", "mask_axis"} and got["mask_axis"] == "w"       # r6: --mask-axis (default = the reference's behaviour, defect D1)
 
 
 def test_wider_evaluator_reads_official_mat_layout_and_filters_by_setting(tmp_path):
@@ -794,6 +795,7 @@ def test_synthetic_faces_dataset_is_fixed_and_consistent():
     """tinyfaces/datasets/synthetic.py: SyntheticFaces (r6, the data set of the learn-and-detect test): the image list is a function of the seed alone,
     the validation view is the training image at twice the size with boxes scaled alike, and no two faces of an image overlap."""
     import numpy as np
+    import torch
     from tinyfaces.datasets.synthetic import SyntheticFaces
     from tinyfaces.datasets.templates import load_templates
     t = load_templates()
@@ -801,18 +803,27 @@ def test_synthetic_faces_dataset_is_fixed_and_consistent():
     assert len(a) == 800 and len(a.samples) == 8 and len(b.samples) == 8
     x0, name0 = a[0]
     x8, name8 = a[8]                                             # sample i = image i % 8
-    assert name0 == name8 == "faces/img_0.jpg" and bool((x0 == x8).all()) and tuple(x0.shape) == (3, 1000, 1000)
+    z = SyntheticFaces.VAL_ZOOM
+    assert name0 == name8 == "faces/img_0.jpg" and bool((x0 == x8).all()) and tuple(x0.shape) == (3, 500 * z, 500 * z)
     assert all(np.array_equal(p[0], q[0]) and np.array_equal(p[1], q[1]) for p, q in zip(a.samples, b.samples))
     gt = b.ground_truth()
+    # the training view: the SAME faces on a background of its own per sample, at zoom x1 / x0.5 / x2 (boxes follow the zoom)
+    tr = SyntheticFaces(t, length=800, seed=0, train=True)
+    views = [tr[8 * k] for k in range(4)]                       # the four views of layout 0: the evaluation image, x0.5, x2, x0.25
+    assert bool((views[0][0] == torch.from_numpy(np.stack([SyntheticFaces._LUTN[c][b.samples[0][0][:, :, c]] for c in range(3)]))).all())
+    assert all(tuple(v[0].shape) == (3, 500, 500) for v in views)
+    sizes = sorted({round(float(v[1][0, 2] - v[1][0, 0]) / float(b.samples[0][1][0, 2] - b.samples[0][1][0, 0]), 1) for v in views if v[1].shape[0] == b.samples[0][1].shape[0]})
+    assert set(sizes) <= {0.2, 0.3, 0.5, 1.0, 2.0} and len(sizes) >= 2, sizes
+    assert not bool((views[0][0] == views[1][0]).all())
     for i, (u8, boxes) in enumerate(b.samples):
         assert u8.shape == (500, 500, 3) and u8.dtype == np.uint8 and 1 <= boxes.shape[0] <= 5
         g = gt[f"img_{i}"]
-        assert np.allclose(g[:, :2], 2 * boxes[:, :2]) and np.allclose(g[:, 2], 2 * (boxes[:, 2] - boxes[:, 0]) + 1)
+        assert np.allclose(g[:, :2], z * boxes[:, :2]) and np.allclose(g[:, 2], z * (boxes[:, 2] - boxes[:, 0]) + 1)
         for p in range(boxes.shape[0]):
             for q in range(p):
                 iw = min(boxes[p, 2], boxes[q, 2]) - max(boxes[p, 0], boxes[q, 0])
                 ih = min(boxes[p, 3], boxes[q, 3]) - max(boxes[p, 1], boxes[q, 1])
                 assert iw < 0 or ih < 0
-        # the zoomed view is pixel replication of the training pixels
-        z = (a[i][0] * 255).round().byte().permute(1, 2, 0).numpy()
-        assert np.array_equal(z[::2, ::2], u8) and np.array_equal(z[1::2, 1::2], u8)
+        # the validation view is pixel replication (x VAL_ZOOM) of the stored pixels
+        v = (a[i][0] * 255).round().byte().permute(1, 2, 0).numpy()
+        assert np.array_equal(v[::z, ::z], u8) and np.array_equal(v[z - 1::z, z - 1::z], u8)

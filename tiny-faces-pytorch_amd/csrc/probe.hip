@@ -16,6 +16,7 @@
 //               window > 4 KiB every thread also writes 16 bytes before and reads another block's 16 bytes after each barrier
 //               -> what a persistent ("cooperative") conv -> BN -> conv kernel would pay INSTEAD of a kernel boundary (r4)
 // Not part of the product path (debug symbol of the C ABI, like tf_debug_conv3x3h_trace).
+#include <hip/hip_ext.h>
 #include "common.h"
 #include "debug_api.h"
 
@@ -334,6 +335,48 @@ int launch_mix(int blocks, char* buf, size_t window, int iters, int dma, hipStre
   return hipGetLastError() == hipSuccess ? TF_OK : TF_ERR_LAUNCH;
 }
 
+
+// kind 13 (r6): what does an edge of a dependent-kernel chain cost WITHOUT the AQL barrier bit?  `iters` kernels of `blocks` x 256 threads;
+// kernel k writes 16 B per thread into slab k % 2, then (one lane per block, behind an agent-scope release) bumps the completion counter of ITS XCD in
+// row k; before that it waits -- one lane per block, bounded spin with s_sleep, then an agent-scope acquire -- until the eight counters of row k - 1 add
+// up to the grid, and checks one value its predecessor wrote.  mode 0: plain launches on one stream, no in-kernel wait (the kernel boundary);
+// mode 1: the same launches WITH the in-kernel wait (what the protocol costs on top when the boundary is there anyway); mode 2: hipExtLaunchKernelGGL with
+// hipExtAnyOrderLaunch on one stream (hip_ext.h says the flag is not supported on gfx9xx: this measures whether it does anything); mode 3: kernels
+// alternate between TWO streams with no event between them (the only way to really drop the barrier bit if mode 2 is ignored).
+// ctl[0] = spins that gave up, ctl[1] = stale reads, ctl[2] = waits that found the predecessor already complete.
+__global__ void __launch_bounds__(256) chain_probe_kernel(unsigned* counters, unsigned* ctl, uint4* slabs, size_t slab_elems, int k, int wait, unsigned expect) {
+  __shared__ int ok;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (wait && k > 0) {
+    if (threadIdx.x == 0) {
+      const unsigned* row = counters + (size_t)(k - 1) * 32;
+      int spins = 0; unsigned sum = 0;
+      for (;;) {
+        sum = 0;
+        for (int x = 0; x < 8; ++x) sum += __hip_atomic_load(row + x * 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (sum >= expect || ++spins > 200000) break;
+        __builtin_amdgcn_s_sleep(2);
+      }
+      if (sum < expect) atomicAdd(ctl + 0, 1u);
+      if (spins == 0) atomicAdd(ctl + 2, 1u);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      ok = 1;
+    }
+    __syncthreads();
+    const uint4 v = slabs[(size_t)((k - 1) & 1) * slab_elems + i % slab_elems];
+    if (v.x != (unsigned)(k - 1)) atomicAdd(ctl + 1, 1u);
+  }
+  slabs[(size_t)(k & 1) * slab_elems + i % slab_elems] = make_uint4((unsigned)k, (unsigned)i, 0u, 0u);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    __hip_atomic_fetch_add(counters + (size_t)k * 32 + (xcc & 7) * 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 template <int KIND>
 int launch(int blocks, int lds, char* buf, size_t window, int iters, hipStream_t s) {
   static bool attr = false;
@@ -410,6 +453,25 @@ extern "C" int tf_debug_probe(int kind, int blocks, int lds_bytes, void* buf, si
         case 103: return launch_mix<103>(blocks, b, window_bytes, iters, dma, s); case 43: return launch_mix<43>(blocks, b, window_bytes, iters, dma, s);
       }
       return TF_ERR_ARG;
+    }
+    case 13: {                                              // iters = kernels in the chain (<= 4096); lds_bytes = mode 0..3; window >= 1 MiB + 2 slabs
+      const int n = iters, mode = lds_bytes;
+      const size_t slab_elems = (size_t)blocks * 256;
+      if (n < 1 || n > 4096 || mode < 0 || mode > 3 || window_bytes < (1u << 20) + 2 * slab_elems * 16) return TF_ERR_ARG;
+      unsigned* counters = (unsigned*)b;                    // n rows of 32 words (8 counters 16 B apart) = 512 KiB at most
+      unsigned* ctl = (unsigned*)(b + (1u << 20) - 64);
+      uint4* slabs = (uint4*)(b + (1u << 20));
+      if (hipMemsetAsync(b, 0, 1u << 20, s) != hipSuccess) return TF_ERR_LAUNCH;
+      static hipStream_t s2 = nullptr;
+      if (mode == 3 && !s2 && hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess) return TF_ERR_LAUNCH;
+      if (mode == 3) { hipEvent_t e; if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return TF_ERR_LAUNCH; (void)hipEventRecord(e, s); (void)hipStreamWaitEvent(s2, e, 0); (void)hipEventDestroy(e); }
+      for (int k = 0; k < n; ++k) {
+        hipStream_t q = mode == 3 && (k & 1) ? s2 : s;
+        if (mode == 2) hipExtLaunchKernelGGL(chain_probe_kernel, dim3(blocks), dim3(256), 0, q, nullptr, nullptr, hipExtAnyOrderLaunch, counters, ctl, slabs, slab_elems, k, 1, (unsigned)blocks);
+        else hipLaunchKernelGGL(chain_probe_kernel, dim3(blocks), dim3(256), 0, q, counters, ctl, slabs, slab_elems, k, mode >= 1 ? 1 : 0, (unsigned)blocks);
+      }
+      if (mode == 3) { hipEvent_t e; if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return TF_ERR_LAUNCH; (void)hipEventRecord(e, s2); (void)hipStreamWaitEvent(s, e, 0); (void)hipEventDestroy(e); }
+      return hipGetLastError() == hipSuccess ? TF_OK : TF_ERR_LAUNCH;
     }
     case 7: case 8:
       if (blocks > 1024 || blocks % 8) return TF_ERR_ARG;   // every block must be resident at once (256 CUs x 4)

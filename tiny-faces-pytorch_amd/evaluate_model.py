@@ -22,6 +22,9 @@ FLAGS = [
     ("--workers", dict(default=8, type=int)), ("--batch_size", dict(default=1, type=int)),
     ("--results_dir", dict(default=None)), ("--debug", dict(action="store_true")),
     ("--num-images", dict(default=4, type=int, help="synthetic dataset only")),
+    ("--mask-axis", dict(dest="mask_axis", default="w", choices=["w", "template"],
+                         help="`w` (default) = the reference's template mask as written (it indexes the heat-map WIDTH: defect D1, tinyfaces/models/utils.py:44); "
+                              "`template` = the mask on the template axis it was meant for")),
 ]
 
 
@@ -40,13 +43,13 @@ def dataloader(args):
     return get_dataloader(args.dataset, largs, train=False, split=args.split, img_transforms=tf)
 
 
-def run(model, val_loader, templates, prob_thresh, nms_thresh, device, split, results_dir=None, debug=False):
+def run(model, val_loader, templates, prob_thresh, nms_thresh, device, split, results_dir=None, debug=False, mask_axis="w"):
     """evaluate_model.py:48-68, statement for statement: `img[0]` / `filename[0]` undo the batch axis the loader adds.  The
     only addition is the keyword that builds the pyramid levels on the GPU (same detections bit for bit)."""
     dets = None
     for _, (img, filename) in enumerate(val_loader):
         dets = get_detections(model, img[0], templates, val_loader.dataset.rf, val_loader.dataset.transforms, prob_thresh, nms_thresh,
-                              device=device, pyramid_on_gpu=True)
+                              device=device, pyramid_on_gpu=True, mask_axis=mask_axis)
         write_results(dets, filename[0], split, results_dir)
         if debug:
             print(f"{filename[0]}: {dets.shape[0]} detections")
@@ -71,7 +74,7 @@ def main():
     model = model.to(device).eval()
     with torch.no_grad(), model.constant_weights():          # the checkpoint does not change between images: pack the weights once
         run(model, val_loader, templates, args.prob_thresh, args.nms_thresh, device, args.split, results_dir=args.results_dir,
-            debug=args.debug or args.dataset == "synthetic")
+            debug=args.debug or args.dataset == "synthetic", mask_axis=args.mask_axis)
     if distributed:
         torch.distributed.barrier()
         if parallel.rank() == 0:

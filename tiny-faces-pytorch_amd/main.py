@@ -43,6 +43,10 @@ EXTRA_FLAGS = [
                     help="from-scratch runs only (no --resume / --pretrained): `tame` = the last BN of every bottleneck at 0.1 and the head weights x 0.05 "
                          "(plain kaiming saturates the sigmoid of a 101-layer random trunk: SURVEY.md 7.1); `kaiming` = torch's defaults")),
     ("--save-path", dict(dest="save_path", default="weights", help="directory of the checkpoints (the reference writes ./weights, trainer.py:20-28)")),
+    ("--ohem-thresh", dict(dest="ohem_thresh", default=0.03, type=float,
+                           help="loss.py:62 zeroes every label -- positives too -- whose soft-margin loss is below this (0.03: y*logit > 3.49; defect D7): a positive "
+                                "the classifier is sure of also leaves the REGRESSION loss, so the boxes of a detector trained from scratch stop improving as soon "
+                                "as its scores are confident (tests/test_gpu_e2e.py).  0 switches the mining off")),
 ]
 
 
@@ -104,6 +108,7 @@ def main():
     train_loader, _ = get_dataloader(args.traindata, args, NUM_TEMPLATES, img_transforms=preprocess)
     model = DetectionModel(num_objects=1, num_templates=NUM_TEMPLATES).set_compute_dtype(args.dtype)
     loss_fn = DetectionCriterion(NUM_TEMPLATES, seed=args.seed * parallel.world_size() + parallel.rank(), lazy_meters=True)
+    loss_fn.ohem_thresh = args.ohem_thresh
 
     first_epoch = args.start_epoch
     state = None
