@@ -185,8 +185,13 @@ typedef struct tf_conv_args {
   float* stat_out;    /* [mtiles][2][ldy] fp32 partial sums, mtiles = tf_conv_mtiles() */
   int tile;           /* 0 = auto (recommended).  Else a kernel / tile code, pixels x channels: 11 128x128, 12 128x64, 13 64x64 on the LDS-DMA
                          kernel (3-deep ring; 2x = 4-deep, 3x = ring-less, 4x = 2-deep; x4 / x5 / x6 = 128x128 / 128x64 / 64x128 on 32x32x16
-                         fragments), 50 = halo-resident 3x3 kernel, 60 = conv_pwx, 70 = conv_pws (r5: wave-streaming pointwise kernel with resident weights: Cin <= 256,
-                         M >= 16 384 pixels, ldy == Cout; what 0 picks for those launches unless TINYFACES_PWS_OFF is set).  Codes 1-3 (the register-staged kernel of round 1) were
+                         fragments), 50 = halo-resident 3x3 kernel, 60 = conv_pwx, 70 = conv_pws (r5: wave-streaming pointwise kernel with resident weights).
+                         conv_pws takes EXACTLY: 1x1 / stride 1 / pad 0, bf16 or fp16, no prologue, ldy == Cout, M >= 16 384 pixels,
+                         (Cin, Cout) in {(64, 256), (256, 64), (64, 64), (256, 128)}, epilogue sets AFFINE[+RELU], AFFINE+RES+RELU (both types) and, bf16
+                         only, none, STATS, MASK+STATS2, RES[+MASK2[+STATS3]]; statistic epilogues only with folded rows (tf_get_stat_rows() <=
+                         TF_STAT_ROWS).  0 picks it for those launches (TINYFACES_PWS_OFF=1: never); tile = 70 on anything else is TF_ERR_UNSUPPORTED from
+                         tf_conv2d and from tf_conv_mtiles (negative return).  Output-channel slices (Cout > 256) exist in the TF_EXPERIMENTAL build only.
+                         Codes 1-3 (the register-staged kernel of round 1) were
                          removed in r4: TF_ERR_UNSUPPORTED, like a prologue (pro_scale != NULL) -- tf_conv2d_wgrad keeps its prologue. */
   /* TF_EPI_STATS only (r3): per-channel value subtracted from every output BEFORE it enters the two sums, so that the consumer computes
    * var = E[(x-s)^2] - E[x-s]^2 around a shift s close to the mean instead of E[x^2] - mean^2 (which loses (mean/std)^2 of the

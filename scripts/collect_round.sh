@@ -16,4 +16,5 @@ cpf $G/timeline.txt                 $P/${r}_step_timeline.txt
 cpf $G/parity_report_full.txt       $P/${r}_parity_report.txt
 cpf $G/gridbar.txt                  $P/${r}_gridbar.txt
 cpf $G/pytest_gpu.log               $P/${r}_pytest_gpu.log
+cpf $G/stamp.json                   $P/${r}_stamp.json
 python scripts/kernel_resources.py > $P/${r}_kernel_resources.txt 2>/dev/null && echo "  $P/${r}_kernel_resources.txt"

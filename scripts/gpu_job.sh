@@ -88,8 +88,9 @@ print(d['value'], d['ms_per_step'], 'frac', r.get('frac'), 'fwd', r.get('forward
   final)
     # the profile passes FIRST: bench.py quotes the committed kernel-stats / PMC files, so they are refreshed in the box's copy of profiles/
     # (and come home through gpurun_out/) before the bench line is taken with the same binary
-    rp=${ROUND:-r05}
+    rp=${ROUND:-r06}
     bash "$0" prof train; cp "$R/gpurun_out/prof/train_kernel_stats.csv" "$R/profiles/${rp}_train_bs12_bf16_kernel_stats.csv"
+    python scripts/stamp_profiles.py "$R/profiles/${rp}_stamp.json" > /dev/null; cp "$R/profiles/${rp}_stamp.json" "$R/gpurun_out/stamp.json"     # the library these profiles belong to
     bash "$0" pmc-traffic; cp "$R/gpurun_out/pmc_bench/traffic.json" "$R/profiles/${rp}_pmc_traffic.json"; cp "$R/gpurun_out/pmc_bench/traffic_fp32.json" "$R/profiles/${rp}_pmc_traffic_fp32.json"
     bash "$0" bench
     bash "$0" tests; cp "$R/gpurun_out/parity_report.txt" "$R/gpurun_out/parity_report_full.txt" 2>/dev/null

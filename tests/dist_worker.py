@@ -1,5 +1,5 @@
 """Worker of tests/test_gpu_dist.py: one data-parallel rank of the fused TrainEngine (gloo rendezvous, every rank on cuda:0 of a
-1-GPU box).  Rank r trains on its own micro-batch for STEPS steps; rank 0 writes the flat parameter buffer after every step."""
+1-GPU box).  Rank r trains on micro-batch r % 2 for STEPS steps; rank 0 writes the flat parameter buffer after every step."""
 import os
 import sys
 
@@ -41,7 +41,7 @@ def main():
     m, c, batches = build(golden_path)
     eng = TrainEngine(m, c, lr=1e-4, momentum=0.9, weight_decay=5e-4, device="cuda:0", bucket_mb=10)
     assert eng._overlap is not None and len(eng._overlap["ranges"]) >= 8, "the bucketed, event-driven exchange must be active"
-    img, cm, rm = [t.cuda() for t in batches[rank]]
+    img, cm, rm = [t.cuda() for t in batches[rank % 2]]
     snaps = []
     for s in range(steps):
         eng.step(img, cm.clone(), rm)

@@ -114,6 +114,10 @@ def test_kernel_selection_queries_host_side(hip):
     assert conv(1, 8, 8, 64, 64, 1) == 1                         # 64 pixels: one 64 x 64 / 128 x 64 tile
     # fp32 (the parity path) never takes the 2-byte kernels
     assert conv(1, 16, 16, 256, 256, 3, dtype=hip.TF_F32) == min(rows, 4)      # 256 pixels / 64
+    # conv_pws (tile 70): the layer-1 launches take it (folded rows); an explicit 70 on a launch it does not take is refused here as in tf_conv2d,
+    # never answered with a row count the caller would size a buffer from
+    assert conv(12, 125, 125, 64, 256, 1) == rows and conv(12, 125, 125, 64, 256, 1, tile=70) == rows
+    assert conv(12, 32, 32, 1024, 256, 1, tile=70) == -3 and conv(1, 8, 8, 64, 64, 1, tile=70) == -3      # TF_ERR_UNSUPPORTED: Cin 1024; 64 pixels
 
     def wgrad_ws(N, H, W, Cin, Cout, K, stride=1):
         a = hip.WgradArgs()
@@ -235,59 +239,23 @@ def test_no_lds_read_is_in_flight_across_a_barrier_that_frees_its_ring_slot(tmp_
 
 def test_conv_pws_tile_loop_keeps_its_ring_rules(tmp_path):
     """csrc/conv_pws.hip (r5): every wave walks its own 16-pixel tiles through a private two-slot LDS ring with NO block barrier in the loop, so
-    the two orderings a barrier would have given are kept by wait counts alone.  ISA audit of every instantiation: no scratch; every DMA is
-    inline asm; in the tile loop every wait on the VM counter is the hand-counted one (a `vmcnt(0)` of hipcc's own in front of the output
-    stores would drain the prefetch of the next tile); and no DMA of the loop - they refill the slot the previous iteration read - is issued
-    with an LDS access of this wave outstanding."""
+    the two orderings a barrier would have given are kept by wait counts alone.  The ISA audit (tiny-faces-pytorch_amd/isa_audit.py, also run by
+    build.py whenever the file is compiled: ADVICE r5) over every instantiation: no scratch; every DMA is inline asm; in the tile loop every wait
+    on the VM counter is the hand-counted one and its count equals the stores + DMAs the loop body really holds; no DMA of the loop is issued with
+    an LDS access of this wave outstanding.  And the audit itself can fail: a loop with one store fewer is reported."""
     import re
-    import subprocess
+    import isa_audit
     src = os.path.join(ROOT, "tiny-faces-pytorch_amd", "csrc", "conv_pws.hip")
-    r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", src, "-o", str(tmp_path / "pws.s")],
-                       capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
-    asm = open(tmp_path / "pws.s").read()
-    names = re.findall(r"^(_ZN12_GLOBAL__N_115conv_pws_kernel\w+):", asm, re.M)
-    assert len(names) >= 30           # 4 shapes x the epilogue sets x {bf16, f16}
-    for name in names:
-        body = re.search(re.escape(name) + r":(.*?)\.Lfunc_end", asm, re.S).group(1)
-        assert "scratch_" not in body, name
-        lines = [l.strip() for l in body.split("\n")]
-        in_asm, hand = False, set()
-        for i, l in enumerate(lines):
-            if l.startswith(";;#ASMSTART"):
-                in_asm = True
-            elif l.startswith(";;#ASMEND"):
-                in_asm = False
-            elif in_asm:
-                hand.add(i)
-        dmas = [i for i, l in enumerate(lines) if l.startswith("global_load_lds")]
-        assert dmas and all(i in hand for i in dmas), name
-        owner, cur = {}, None
-        for i, l in enumerate(lines):
-            m = re.match(r"\.L(BB\d+_\d+):\s*;(.*)", l)
-            if m:
-                h = re.search(r"Header=(BB\d+_\d+)", m.group(2))
-                cur = h.group(1) if h else (m.group(1) if "Loop Header" in m.group(2) else None)
-            elif re.match(r"\.L(BB\d+_\d+):", l):
-                cur = None
-            owner[i] = cur
-        loops = {owner[i] for i, l in enumerate(lines) if l.startswith("v_mfma")} - {None}      # (None: the first tile, peeled in front of the loop)
-        assert len(loops) == 1, (name, loops)
-        loop = [i for i in range(len(lines)) if owner[i] in loops]
-        waits = [i for i in loop if lines[i].startswith("s_waitcnt") and "vmcnt" in lines[i]]
-        assert waits and all(i in hand for i in waits), (name, [lines[i] for i in waits if i not in hand])
-        # two trips around the loop body: LDS accesses outstanding at every DMA issue
-        pend = 0
-        for i in loop + loop:
-            l = lines[i]
-            if re.match(r"ds_(read|write|load|store)", l):
-                pend += 1
-            elif l.startswith("s_waitcnt"):
-                w = re.search(r"lgkmcnt\((\d+)\)", l)
-                if w:
-                    pend = min(pend, int(w.group(1)))
-            elif l.startswith("global_load_lds"):
-                assert pend == 0, (name, i, pend)
+    asm = isa_audit.emit_isa("/opt/rocm/bin/hipcc", src, str(tmp_path / "pws.s"))
+    assert isa_audit.audit(asm) == []
+    # negative control: drop ONE output store from the first kernel's tile loop -> the count check must notice
+    name = re.search(r"^(_ZN12_GLOBAL__N_115conv_pws_kernel\w+):", asm, re.M).group(1)
+    m = re.search(re.escape(name) + r":(.*?)\.Lfunc_end", asm, re.S)
+    body = m.group(1).split("\n")
+    loops, owner = isa_audit.mfma_loops([l.strip() for l in body])
+    st = next(i for i, l in enumerate(body) if owner[i] in loops and l.strip().startswith("global_store"))
+    broken = asm[:m.start(1)] + "\n".join(body[:st] + body[st + 1:]) + asm[m.end(1):]
+    assert any("stores" in b for b in isa_audit.audit(broken))
 
 
 def test_round4_entry_points_refuse_bad_arguments_without_launching(hip):

@@ -17,15 +17,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STEPS = 3
 
 
-def test_two_rank_engine_equals_single_process_gradient_average(tmp_path):
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_two_rank_engine_equals_single_process_gradient_average(tmp_path, ranks):
+    """`ranks` gloo ranks sharing cuda:0 (rank r trains on micro-batch r % 2) against ONE process that sums the gradients of the same micro-batches.
+    Four ranks put more than two contributions into every bucket, including the buckets whose boundaries fall inside a
+    weight-gradient group of layer 3."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import dist_worker
     from tinyfaces import _hip, ops
     golden = os.path.join(ROOT, "tests", "golden", "trainer.npz")
     out = str(tmp_path / "rank0.npz")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", os.path.join(ROOT, "tests", "dist_worker.py"), golden, out, str(STEPS)]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(29539 + ranks), os.path.join(ROOT, "tests", "dist_worker.py"), golden, out, str(STEPS)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=500, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     dist = np.load(out)
@@ -57,18 +61,18 @@ def test_two_rank_engine_equals_single_process_gradient_average(tmp_path):
                 _, g, _ = ops.criterion_fwd_bwd(o, cm.clone(), rm, c.n_templates, c.reg_weight, c.ohem_thresh, c.max_pos, c.max_neg,
                                                 c._pos_keep, c._neg_keep, c._next_seed())
                 grads.append(m._run_backward(img, g, persistent=True).clone())
-            gsum = grads[0] + grads[1]
+            gsum = (grads[0] + grads[1]) * (ranks // 2)               # every micro-batch is trained by ranks / 2 ranks
             for rp in reps:
                 for a, b, mult in groups:
                     if mult != 0.0:
-                        ops.sgd_step(rp["flat"][a:b], gsum[a:b], rp["mom"][a:b], 1e-4 * mult, 0.9, 5e-4, 0.5)
+                        ops.sgd_step(rp["flat"][a:b], gsum[a:b], rp["mom"][a:b], 1e-4 * mult, 0.9, 5e-4, 1.0 / ranks)
             torch.cuda.synchronize()
             ref = reps[0]["flat"].cpu().numpy()
             d = np.abs(dist[s] - ref)
             worst.append(float(d.max() / (np.abs(ref).max() + 1e-30)))
     finally:
         _hip.lib().tf_set_stat_rows(prev if prev <= 16 else 0)
-    report("dist_two_ranks_vs_single", worst_rel=str([f"{w:.2e}" for w in worst]))
+    report(f"dist_{ranks}_ranks_vs_single", worst_rel=str([f"{w:.2e}" for w in worst]))
     # step 1: only the fp32-atomic summation order of the weight gradients differs between two runs (1e-7); later steps amplify it
     # through batch-statistics BN on these 2-image batches exactly as between two single-process runs (test_gpu_model.py)
     assert all(np.isfinite(d).all() for d in dist) and all(np.isfinite(w) for w in worst), worst

@@ -657,6 +657,34 @@ def test_frozen_parameter_tables_skip_the_walk_until_the_module_moves():
     m._tables_frozen = True
     flat = m.flatten_parameters()                         # re-points every parameter: must rebuild even when frozen
     assert len(walks) >= 3 and m._table_key != key and flat.numel() > 27_000_000
+    # a frozen table notices ANY replaced tensor, not only the first / middle / last one
+    import pickle
+    m._tables_frozen = True
+    m._sync_tables(dev); n0 = len(walks)
+    m._sync_tables(dev)
+    assert len(walks) == n0                               # frozen again: no walk
+    bn = m.model.layer2[1].bn2
+    bn.running_var = torch.ones_like(bn.running_var)      # a buffer somewhere in the middle, replaced through Module.__setattr__
+    m._sync_tables(dev)
+    assert len(walks) == n0 + 1
+    conv = m.model.layer3[7].conv2
+    conv.weight = torch.nn.Parameter(conv.weight.detach().clone())       # a Parameter object replaced
+    m._sync_tables(dev)
+    assert len(walks) == n0 + 2
+    m.model.layer1[2].bn3.bias.data = torch.zeros(256)    # .data re-pointed: same object, new storage
+    m._sync_tables(dev)
+    assert len(walks) == n0 + 3
+    m._sync_tables(dev)
+    assert len(walks) == n0 + 3
+    # no lambdas, no ctypes tables in the pickled state: a copy rebuilds its own.  (A fresh, un-flattened model: plain pickle writes the whole
+    # storage of every view, i.e. the 108 MB flat buffer once per parameter.)
+    f = DetectionModel(num_templates=25)
+    f._sync_tables(dev)
+    f._tables_frozen = True
+    f2 = pickle.loads(pickle.dumps(f))
+    assert f2._table_key is None and not f2._tables_frozen
+    f2._sync_tables(dev)
+    assert f2._table_key is not None and f2._table_key != f._table_key
 
 
 def test_stem_wgrad_patch_copies_address_the_right_input_pixels():

@@ -11,6 +11,8 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+if HERE not in sys.path:
+    sys.path.insert(0, HERE)
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "tinyfaces", "libtinyfaces_hip.so")
@@ -58,9 +60,19 @@ def build(force=False, verbose=True):
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_m) or (f == "capi.hip" and restamp):
             cmd = [HIPCC] + COMMON + (["-ffp-contract=off"] if f in EXACT else []) + ([f'-DTF_BUILD_ID="{digest}"'] if f == "capi.hip" else []) + ["-c", src, "-o", obj]
             jobs.append((f, cmd))
+            if f == "conv_pws.hip":
+                jobs.append(("conv_pws.hip [ISA audit]", None))
 
     def run(job):
         f, cmd = job
+        if cmd is None:                                      # the ISA audit of conv_pws (isa_audit.py): a library whose tile loop breaks its ring rules is never linked
+            import isa_audit
+            try:
+                bad = isa_audit.audit(isa_audit.emit_isa(HIPCC, os.path.join(CSRC, "conv_pws.hip"), os.path.join(OBJ, "conv_pws.s"), [x for x in COMMON if x.startswith("-D")]),
+                                      min_kernels=30)
+            except Exception as e:                           # noqa: BLE001
+                return f, 1, str(e)
+            return f, (1 if bad else 0), "\n".join(bad)
         r = subprocess.run(cmd, capture_output=True, text=True)
         return f, r.returncode, r.stdout + r.stderr
 

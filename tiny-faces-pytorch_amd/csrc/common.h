@@ -176,4 +176,20 @@ __device__ __host__ __forceinline__ uint64_t hash4(uint64_t a, uint64_t b, uint6
 }
 __device__ __host__ __forceinline__ double u01(uint64_t h) { return (double)(h >> 11) * (1.0 / 9007199254740992.0); }
 
+
+// Function attributes (hipFuncSetAttribute: dynamic LDS above 64 KiB) and the CU count belong to a DEVICE, not to the process: a host
+// that drives more than one GPU from one process sets them once per device.  `PerDevice` is the flag array of one launch site.
+struct PerDevice {
+  bool done[64] = {};
+  // true exactly once per device (the caller then sets its attributes on the current device)
+  bool first() { int dev = 0; (void)hipGetDevice(&dev); bool& d = done[dev & 63]; const bool f = !d; d = true; return f; }
+};
+inline int device_cus() {
+  static int cus[64] = {};
+  int dev = 0; (void)hipGetDevice(&dev);
+  int& n = cus[dev & 63];
+  if (n == 0) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256; n = v; }
+  return n;
+}
+
 }  // namespace tf

@@ -81,7 +81,10 @@ extern "C" int tf_conv_mtiles(const tf_conv_args* a) {
   const int t = pick_tile(a);
   if (t == 50) { const int mt = tf_conv3x3h_mtiles(a); return mt > tf_get_stat_rows() ? tf_get_stat_rows() : mt; }
   if (t == 60) { const int mt = tf_conv_pwx_mtiles(a); return mt > tf_get_stat_rows() ? tf_get_stat_rows() : mt; }
-  if (t == 70) return tf_get_stat_rows();            // (only chosen with folded rows: its blocks add into row blockIdx % rows)
+  // 70 = conv_pws: its blocks add into row blockIdx % rows of the FOLDED statistic rows.  An explicit tile = 70 on a launch the kernel does not
+  // take (tf_conv2d then returns TF_ERR_UNSUPPORTED) must not size the caller's buffer from it -- with tf_set_stat_rows(0) that would be 1 << 30
+  // rows: such a request is an argument error here too.
+  if (t == 70) return tf_conv_pws_applicable(a) ? tf_get_stat_rows() : TF_ERR_UNSUPPORTED;
   const int bm = tile_bm(t);
   const int mt = (int)((M + bm - 1) / bm);
   return (t >= 10 && mt > tf_get_stat_rows()) ? tf_get_stat_rows() : mt;     // the DMA kernel folds its tiles into <= TF_STAT_ROWS rows

@@ -427,12 +427,8 @@ int min_blocks() {
 
 template <typename T, bool TRACE, int EPIC = -1>
 void launch_var(const HK& k, hipStream_t stream) {
-  static bool attr_set[64] = {};                     // per DEVICE: the attribute belongs to the current device's copy of the function
-  int dev = 0; (void)hipGetDevice(&dev);
-  if (!attr_set[dev & 63]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3h_kernel<T, TRACE, EPIC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set[dev & 63] = true;
-  }
+  static tf::PerDevice attr_set;                     // per DEVICE: the attribute belongs to the current device's copy of the function
+  if (attr_set.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3h_kernel<T, TRACE, EPIC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   TF_LAUNCH_TIMED((conv3x3h_kernel<T, TRACE, EPIC>), dim3(k.mtiles * k.ntiles), dim3(NT), TRACE && RING_BYTES + TRACE_BYTES > LDS_BYTES ? RING_BYTES + TRACE_BYTES : LDS_BYTES, stream, k);
 }
 

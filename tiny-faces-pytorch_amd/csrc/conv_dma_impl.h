@@ -620,10 +620,9 @@ int launch_kind(const tf_conv_args* A, hipStream_t stream, int pcls = -1) {
   const size_t stg = (size_t)BM * (BN + 4) * 4;
   if (stg > lds) lds = stg;
   if (k.pro) lds += 2048;                            // scale / shift of up to 256 input channels behind the staging tile
-  static bool attr_set = false;
-  if (!attr_set) {
+  static tf::PerDevice attr_set;
+  if (attr_set.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<T, BM, BN, NS, KIND, MMA>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
   }
   {
     const double es = sizeof(T), M = k.M, Kt = k.Ktot;
@@ -664,8 +663,8 @@ int launch_kind(const tf_conv_args* A, hipStream_t stream, int pcls = -1) {
       if (!spec_off && !k.pro) {
         auto go = [&](auto epic) {
           constexpr int E = decltype(epic)::value;
-          static bool set = false;
-          if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<T, BM, BN, NS, KIND, MMA, E>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+          static tf::PerDevice set;
+          if (set.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<T, BM, BN, NS, KIND, MMA, E>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
           TF_LAUNCH_TIMED((conv_dma_kernel<T, BM, BN, NS, KIND, MMA, E>), grid, dim3(256), lds, stream, k);
           done = true;
         };

@@ -85,6 +85,7 @@ __global__ void __launch_bounds__(NW * 64) conv_pws_kernel(const PwK a) {
   constexpr int NIX = 2 * KS, NI1 = AUXT / 1024, NIA = NAUX * NI1;  // DMA instructions per tile
   constexpr int CPR = N / EPS, RPP = 64 / CPR, NPASS = 8 / RPP;     // 16-byte chunks per pixel row, rows per pass, passes per 8 pixels
   constexpr int NST = 2 * NPASS;                                    // output stores of a wave per tile (they count on the VM counter like the DMAs)
+  static_assert(NST + 2 * (NIX + NIA) <= 63, "conv_pws: a tile's stores and two tiles' DMAs must fit the 6-bit VM counter");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -302,13 +303,12 @@ int launch_one(const tf_conv_args* A, const PwK& k, hipStream_t stream) {
   constexpr size_t lds = slab + NW * per;
   static_assert(lds <= 160 * 1024, "conv_pws: the weight slice and two waves' rings must fit the LDS of a CU");
   {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static tf::PerDevice attr_set;
+  if (attr_set.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pws_kernel<T, KS, NF, EPIC, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
   }
   // persistent grid: as many blocks as fit (LDS decides), at most one wave per tile
-  static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+  const int cus = tf::device_cus();               // (per device: ADVICE r5)
   const int per_cu = (int)((160 * 1024) / lds) < 1 ? 1 : (int)((160 * 1024) / lds);
   PwK kk = k;
   kk.nsl = A->Cout / N;

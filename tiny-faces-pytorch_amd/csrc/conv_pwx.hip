@@ -502,10 +502,9 @@ int launch(const tf_conv_args* A, const PK& k, hipStream_t stream) {
   const size_t stg = (size_t)2 * 32 * (BN + 4) * 4;
   const size_t lds = ring > stg ? ring : stg;
   if (lds > 160 * 1024) return TF_ERR_UNSUPPORTED;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static tf::PerDevice attr_set;
+  if (attr_set.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pwx_kernel<BN, PRO, NSW, NSX, EPIC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
   }
   const double M = k.M, Kt = k.K;
   double bytes = (M * Kt * (PRO ? 3.0 : 1.0) + (double)A->Cout * Kt + M * A->Cout) * 2;     // PRO: two operands read, the transformed one written

@@ -322,11 +322,10 @@ extern "C" int tf_nms_f64_batched(const double* boxes, const double* scores, con
   hipLaunchKernelGGL(nms_mask_kernel, dim3(nwmax, nwmax, S), dim3(64), 0, stream, sboxes, sg, iou_thresh, mask);
   // two-level scan: per super-chunk of 1024 boxes one resolve launch (one workgroup per segment, the diagonal block in LDS) and,
   // while later super-chunks exist, one push launch over the chip
-  static bool attr_set = false;
+  static tf::PerDevice attr_set;
   const size_t lds = ((size_t)1024 * kDiagPitch + 2 * kSC) * 8;         // 139.5 KiB
-  if (!attr_set) {
+  if (attr_set.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nms_resolve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
   }
   const int nsc = (nwmax + kSC - 1) / kSC;
   for (int sc = 0; sc < nsc; ++sc) {

@@ -379,8 +379,8 @@ __global__ void __launch_bounds__(256) chain_probe_kernel(unsigned* counters, un
 
 template <int KIND>
 int launch(int blocks, int lds, char* buf, size_t window, int iters, hipStream_t s) {
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&probe_kernel<KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  static tf::PerDevice attr;
+  if (attr.first()) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&probe_kernel<KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
   hipLaunchKernelGGL(probe_kernel<KIND>, dim3(blocks), dim3(256), lds, s, buf, window, iters, reinterpret_cast<float*>(buf));
   return hipGetLastError() == hipSuccess ? TF_OK : TF_ERR_LAUNCH;
 }
@@ -427,12 +427,12 @@ extern "C" int tf_debug_probe(int kind, int blocks, int lds_bytes, void* buf, si
       const int in = shape ? 512 : 128, out = shape ? 128 : 512, ntiles = px / 16;
       if (window_bytes < (size_t)px * (in + out)) return TF_ERR_ARG;
       const size_t l = (size_t)nw * (2 * 16 * in + 16 * out);
-      static bool a0 = false, a1 = false;
+      static tf::PerDevice a0, a1;
       if (!shape) {
-        if (!a0) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wave_stream_probe_kernel<128, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a0 = true; }
+        if (a0.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wave_stream_probe_kernel<128, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipLaunchKernelGGL((wave_stream_probe_kernel<128, 512>), dim3(blocks), dim3(nw * 64), l, s, b, b + (size_t)px * in, ntiles);
       } else {
-        if (!a1) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wave_stream_probe_kernel<512, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a1 = true; }
+        if (a1.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wave_stream_probe_kernel<512, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipLaunchKernelGGL((wave_stream_probe_kernel<512, 128>), dim3(blocks), dim3(nw * 64), l, s, b, b + (size_t)px * in, ntiles);
       }
       return hipGetLastError() == hipSuccess ? TF_OK : TF_ERR_LAUNCH;

@@ -208,10 +208,9 @@ int launch_wgrad(const tf_wgrad_args* A, hipStream_t stream) {
   k.splitk = (k.M + k.chunk - 1) / k.chunk;
   constexpr int PITCH = BC * (int)sizeof(T) + 32;
   const size_t lds = (size_t)4 * PK * PITCH + (A->pro_scale ? (size_t)A->Cin * 8 : 0);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static tf::PerDevice attr_set;
+  if (attr_set.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, BC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
   }
   const double es = sizeof(T), Md = k.M;
   tf::ProfScope prof(8 + (sizeof(T) == 2 ? 2 : 0) + (BC == 128 ? 1 : 0), 2.0 * Md * A->Cout * A->Cin * k.ntaps,

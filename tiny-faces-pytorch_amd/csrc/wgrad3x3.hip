@@ -380,11 +380,10 @@ int tf_wgrad3x3_launch(const tf_wgrad_args* A, hipStream_t stream) {
   const int dbg = tf::tuning().wgrad3_dbg;     // timing ablation: 1 = no MFMA loop body, 2 = no partial stores (results invalid)
   k.dbg = dbg;
   const size_t lds = (size_t)NS * YT + XBYTES;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static tf::PerDevice attr_set;
+  if (attr_set.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
   }
   const double Md = (double)A->N * A->H * A->W;
   // kind 16 = wgrad3x3 (its own row in bench.py's tables); the bracket spans BOTH launches of the two-phase form: the summing
@@ -422,11 +421,10 @@ int tf_wgrad3x3_group_launch(const tf_wgrad_args* A, int n, hipStream_t stream) 
   for (int i = n; i < W3_MAXG; ++i) { g.x[i] = nullptr; g.dy[i] = nullptr; g.dw[i] = nullptr; }
   k.direct = 1;
   const size_t lds = (size_t)NS * YT + XBYTES;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static tf::PerDevice attr_set;
+  if (attr_set.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_group_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_group_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
   }
   const double Md = (double)first.N * first.H * first.W;
   // kind 19 = grouped all-taps 3x3 weight gradient; the GEMM view is the SUM over the group

@@ -348,12 +348,11 @@ int tf_wgrad_pw_group_launch(const tf_wgrad_args* A, int n, hipStream_t stream) 
   // 38 %, issue-stalled 44 %).  The step does not see the difference any more (A/B 1177.7 / 1177.7 img/s): the second stream is off the
   // critical path since the grouping.
   const size_t lds = (size_t)4 * GP_STAGE;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static tf::PerDevice attr_set;
+  if (attr_set.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_group_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_group_fast_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_group_fast_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
   }
   // kind 18 = grouped pointwise weight gradient (bench.py tables); the GEMM view is the SUM over the group
   tf::ProfScope prof(18, flops, bytes, stream, k.M, A[0].Cout, A[0].Cin, 1, 2, 0, -1.0, true);

@@ -99,6 +99,24 @@ class _DetNetFunction(torch.autograd.Function):
         return (None, None) + tuple(grads)
 
 
+# Every register_parameter / register_buffer of ANY module in the process (Module.__setattr__ goes through them too) bumps this counter: a frozen
+# pointer table (DetectionModel._sync_tables) is only trusted while nothing was registered since it was built.
+_REGISTRATIONS = [0]
+
+
+def _count_registration(module, name, value):
+    _REGISTRATIONS[0] += 1
+
+
+torch.nn.modules.module.register_module_parameter_registration_hook(_count_registration)
+torch.nn.modules.module.register_module_buffer_registration_hook(_count_registration)
+
+
+def _invalidate_tables(module, incompatible_keys):
+    """load_state_dict post-hook (a module-level function: the model stays picklable)."""
+    module._table_key = None
+
+
 class DetectionModel(nn.Module):
     """Hybrid-resolution Tiny Faces detector (model.py:7-128) on the MI355X executor."""
 
@@ -117,11 +135,12 @@ class DetectionModel(nn.Module):
         self._ws = None
         self._ws_generation = 0
         self._table_key = None
+        self._frozen_tensors, self._frozen_version = (), -1
         self._session_depth = 0          # constant_weights() nesting
         self._ready_key = None           # (workspace ptr, dtype, table key) whose packed eval weights sit in the workspace
         self._lanes = []                 # forward_levels: extra (workspace, HIP stream, ready key) triples beside the model's own
         # load_state_dict(assign=True) re-points parameters without _apply: the pointer tables are rebuilt on the next call
-        self.register_load_state_dict_post_hook(lambda module, incompatible: setattr(module, "_table_key", None))
+        self.register_load_state_dict_post_hook(_invalidate_tables)
         if isinstance(pretrained_weights, (str, os.PathLike)):           # no network here: a local file only
             sd = torch.load(pretrained_weights, map_location="cpu", weights_only=True)
             sd = sd.get("model", sd)
@@ -255,6 +274,15 @@ class DetectionModel(nn.Module):
         d.update(dict(self.named_buffers()))
         return d
 
+    def __getstate__(self):
+        # pickling / copy.deepcopy: the executor's derived state (ctypes pointer tables, workspaces, streams) belongs to THIS object's storages;
+        # a copy rebuilds it on its first call
+        d = dict(self.__dict__)
+        d.update(_table_key=None, _tables_frozen=False, _frozen_tensors=(), _frozen_version=-1, _ws=None, _ready_key=None, _lanes=[], _session_depth=0)
+        for k in ("_param_ptrs", "_grad_params", "_bn_modules"):
+            d.pop(k, None)
+        return d
+
     def _apply(self, fn, *a, **kw):
         # .to() / .cuda() / .float(): every storage may move -> the pointer tables are rebuilt on the next call even when frozen
         self._table_key = None
@@ -266,11 +294,11 @@ class DetectionModel(nn.Module):
         (~0.4 ms of Python): an owner that pins the storages (TrainEngine after flatten_parameters) sets `_tables_frozen` and the walk is
         skipped until something moves the module (`_apply`, flatten_parameters)."""
         if getattr(self, "_tables_frozen", False) and self._table_key is not None:
-            # frozen: three sentinels (first / a middle / the last tensor of the table) instead of the walk -- replacing a Parameter, a BN
-            # buffer or `.data` without going through _apply still moves at least the storage it touched; load_state_dict(assign=True)
-            # is caught by the post-hook registered in __init__ (ADVICE r4)
-            sent = self._sentinels
-            if all(t.data_ptr() == self._table_key[i] for i, t in sent()):
+            # frozen: no walk over the module tree, but EVERY tensor of the table is still checked (ADVICE r5: three sentinels missed a
+            # replaced tensor in between).  Replacing a Parameter or a buffer anywhere registers it with its module, which bumps the global
+            # registration counter below; re-pointing `.data` keeps the object and moves its storage, which the pointer comparison over the
+            # cached tensor objects sees (571 data_ptr() calls, ~40 us); load_state_dict(assign=True) is caught by the post-hook (ADVICE r4)
+            if self._frozen_version == _REGISTRATIONS[0] and all(t.data_ptr() == p for t, p in zip(self._frozen_tensors, self._table_key)):
                 return
         named = self._named_tensors()
         n = lib().tf_detnet_num_params()
@@ -302,8 +330,8 @@ class DetectionModel(nn.Module):
         self._grad_numels = [pd[k].numel() for k in self._grad_names]
         self._bn_modules = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
         self._table_key = key
-        picks = (0, n // 2, n - 1)
-        self._sentinels = lambda names=names, picks=picks: [(i, self._named_tensor(names[i])) for i in picks]
+        self._frozen_tensors = [named[k] for k in names]
+        self._frozen_version = _REGISTRATIONS[0]
 
     def _named_tensor(self, dotted):
         obj = self

@@ -393,6 +393,7 @@ def conv2d_nhwc(x, w_packed, Cout, KH, KW, stride, pad, mode=0, out_hw=None, ldy
     stats = None
     if want_stats:
         mt = lib().tf_conv_mtiles(C.byref(a))
+        check(min(mt, 0), "tf_conv_mtiles")              # negative: the requested tile code does not take this launch
         stats = torch.zeros(mt, 2, ldy, dtype=torch.float32, device=x.device)
         a.stat_out = ptr(stats)
     with torch.cuda.device(x.device):
