@@ -195,6 +195,34 @@ def test_get_detections_pyramid_on_gpu_is_identical(golden, models):
         get_detections(m, torch.from_numpy(g["img"]), templates, RF, lambda im: transforms.ToTensor()(im), pyramid_on_gpu=True, **kw)
 
 
+def test_get_detections_inside_a_session_repacks_nothing(golden, models):
+    """r6: evaluate_model.py calls get_detections once per image inside ONE constant_weights() session.  get_detections used to call
+    model.to(device) unconditionally; nn.Module.to walks `_apply` even as a no-op, DetectionModel._apply must then assume that every storage
+    moved, and the pointer tables + the packed evaluation weights were rebuilt for every image (80 of 87 ms end to end at 1280 x 960).
+    Now a model that already is on the device is left alone: the table key and the packed-weights key survive the calls, and a model that IS
+    elsewhere still gets moved."""
+    from tinyfaces import transforms
+    from tinyfaces.evaluation import _on_device, get_detections
+    from tinyfaces.models.model import DetectionModel
+    from oracle.targets import RF
+    m, _ = models
+    g = golden("detections")
+    templates = golden("targets")["templates"]
+    tf = transforms.Compose([transforms.ToTensor(), transforms.Normalize([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])])
+    m.set_compute_dtype(torch.bfloat16)
+    kw = dict(prob_thresh=float(g["thr"]), nms_thresh=0.3, scales=tuple(g["scales"].tolist()), device="cuda", pyramid_on_gpu=True)
+    img = torch.from_numpy(g["img"])
+    with torch.no_grad(), m.constant_weights(reserve=(1, img.shape[1] * 2, img.shape[2] * 2)):
+        a = get_detections(m, img, templates, RF, tf, **kw)
+        table, ready = m._table_key, m._ready_key
+        assert table is not None and ready is not None
+        b = get_detections(m, img, templates, RF, tf, **kw)
+        assert m._table_key is table and m._ready_key == ready          # nothing was invalidated, nothing re-packed
+    assert np.array_equal(a, b)
+    cpu = DetectionModel(num_templates=25)
+    assert next(_on_device(cpu, torch.device("cuda")).parameters()).is_cuda and _on_device(m, torch.device("cuda:0")) is m
+
+
 def test_trainer_two_steps_vs_reference_golden(golden):
     """trainer.train (trainer.py:68-90) with torch.optim.SGD exactly as main.py:67-70 builds it."""
     from tinyfaces import trainer

@@ -29,18 +29,28 @@ def _normalize_of(img_transforms):
     return None
 
 
+def _on_device(model, device):
+    """model.to(device) only when something has to move: nn.Module.to walks `_apply` even when it is a no-op, and DetectionModel._apply must then
+    assume that every storage moved -- the pointer tables and the packed evaluation weights of an open constant_weights() session were rebuilt on
+    EVERY get_detections call (r6: 80 of the 87 ms per image of the end-to-end path)."""
+    p = next(model.parameters(), None)
+    if p is not None and p.device.type == device.type and (device.index is None or p.device.index == device.index):
+        return model
+    return model.to(device)
+
+
 def _pyramid_levels(img, scales, img_transforms, pyramid_on_gpu, device):
     """evaluation.py:37-53: [(scale, normalised (1,3,H,W) tensor)] for every pyramid level of one image."""
     scales_list = [2 ** x for x in scales]
-    image = transforms.to_pil_image(img)                                  # :40
-    min_side = np.min(image.size)
     levels = []
     if pyramid_on_gpu:
         ms = _normalize_of(img_transforms)
         if ms is None:
             raise ValueError("pyramid_on_gpu needs img_transforms = Compose([ToTensor(), Normalize(mean, std)])")
-        u8 = torch.from_numpy(np.array(image, dtype=np.uint8)).to(device)      # (H, W, 3), the only upload of the image
-        w, h = image.size
+        pixels = transforms.to_uint8_hwc(img)                                  # the pixels of to_pil_image(img) (:40), no PIL object in between
+        u8 = torch.from_numpy(pixels).to(device)                               # (H, W, 3), the only upload of the image
+        h, w = pixels.shape[:2]
+        min_side = min(w, h)
         for scale in scales_list:
             size = int(min_side * scale)                                       # :46 -> transforms.resize(image, int)
             short, long = (w, h) if w <= h else (h, w)
@@ -48,6 +58,8 @@ def _pyramid_levels(img, scales, img_transforms, pyramid_on_gpu, device):
             new_w, new_h = (new_short, new_long) if w <= h else (new_long, new_short)
             levels.append((scale, ops.image_prepare(u8, resized_hw=(new_h, new_w), mean=ms[0], std=ms[1]).unsqueeze(0)))
     else:
+        image = transforms.to_pil_image(img)                              # :40
+        min_side = np.min(image.size)
         # the resize + normalise of :46-53 is host work: do it for every level first, then keep the GPU busy
         for scale in scales_list:
             scaled = transforms.resize(image, int(min_side * scale))
@@ -87,7 +99,7 @@ def get_detections(model, img, templates, rf, img_transforms, prob_thresh=0.65, 
     device = torch.device(device if device is not None else "cuda")
     if device.type != "cuda":
         raise RuntimeError("get_detections: the detector only runs on MI355X (no CPU fallback)")
-    model = model.to(device)
+    model = _on_device(model, device)
     model.eval()
     nt = templates.shape[0]
     t_d = torch.as_tensor(np.asarray(templates), dtype=torch.float64).contiguous().to(device)
@@ -123,7 +135,7 @@ def get_detections_batch(model, imgs, templates, rf, img_transforms, prob_thresh
     imgs = list(imgs)
     if not 1 <= len(imgs) <= ops.NMS_MAX_SEGMENTS:
         raise ValueError(f"get_detections_batch: 1..{ops.NMS_MAX_SEGMENTS} images per call, got {len(imgs)}")
-    model = model.to(device)
+    model = _on_device(model, device)
     model.eval()
     nt = templates.shape[0]
     t_d = torch.as_tensor(np.asarray(templates), dtype=torch.float64).contiguous().to(device)
