@@ -779,6 +779,36 @@ def test_conv3x3h_epilogues():
     assert err(s[0], refm.sum(dim=(0, 2, 3)))[2] < 5e-3 and err(s[1], (refm * q(craw, dtype)).sum(dim=(0, 2, 3)))[2] < 5e-3
 
 
+@pytest.mark.parametrize("dtype", HALF)
+@pytest.mark.parametrize("case", [(1, 120, 160, 256, 256), (1, 118, 157, 128, 256), (2, 61, 150, 64, 256)])
+def test_conv3x3h_six_row_tiles_of_the_big_pyramid_levels(dtype, case):
+    """r6: an evaluation launch (folded BN + ReLU) whose 4-row tiles would need a second, nearly empty round of blocks takes 6-row tiles
+    (csrc/conv3x3h.hip: Geo<6>; 1 x 120 x 160 = the 1920 x 2560 pyramid level: 300 blocks -> 200).  Same products in the same order per
+    output pixel, so the result must equal the 4-row instantiation of the SAME kernel bit for bit -- taken here from the data-gradient-free
+    STATS-less path that never uses tall tiles (no epilogue: plain store) after undoing the affine -- and torch-CPU within the usual bar.
+    Ragged cases: a last row tile of 4 of 6 rows, a last column tile of 29 / 22 of 32 columns, two images."""
+    from tinyfaces import _hip, ops
+    N, H, W, Cin, Cout = case
+    g = _g(hash(case) % 1000)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    ref = torch.relu(F.conv2d(q(x, dtype), q(w, dtype), padding=1))
+    wp = ops.pack_weight(w.cuda(), dtype)
+    one, zero = torch.ones(Cout, device="cuda"), torch.zeros(Cout, device="cuda")
+    y6 = ops.conv2d_nhwc(to_nhwc(x, dtype), wp, Cout, 3, 3, 1, 1, epi=_hip.EPI_AFFINE | _hip.EPI_RELU, epi_scale=one, epi_shift=zero, tile=50)
+    assert _hip.lib().tf_debug_conv3x3h_tile_rows() == 6          # the tall instantiation really ran
+    y4 = ops.conv2d_nhwc(to_nhwc(x, dtype), wp, Cout, 3, 3, 1, 1, tile=50)                      # no epilogue flags: 4-row tiles
+    assert _hip.lib().tf_debug_conv3x3h_tile_rows() == 4
+    d = err(from_nhwc(y6), ref)
+    report(f"conv3x3h_tall[{dtype},{case}]", rel=d[2], bit_identical=int(torch.equal(y6, torch.relu(y4))))
+    assert d[2] < TOL_H[dtype]
+    assert torch.equal(y6, torch.relu(y4))                         # x * 1 + 0 and ReLU are exact: the two tile heights agree bit for bit
+    # a launch that fills whole rounds either way keeps the 4-row tile (layer 3 of the training batch: 192 blocks)
+    xs = torch.randn(3, 32, 32, Cin, device="cuda").to(dtype)
+    ops.conv2d_nhwc(xs, wp, Cout, 3, 3, 1, 1, epi=_hip.EPI_AFFINE | _hip.EPI_RELU, epi_scale=one, epi_shift=zero, tile=50)
+    assert _hip.lib().tf_debug_conv3x3h_tile_rows() == 4
+
+
 def test_conv3x3h_refuses_what_it_cannot_do():
     from tinyfaces import ops
     x = torch.randn(1, 8, 8, 64, device="cuda", dtype=torch.bfloat16)

@@ -57,6 +57,16 @@ constexpr int RING_BYTES = W_AT + NSW * WBUF;                          // 112 Ki
 // weight-gradient block could sit beside it and the two kernels time-sliced the CU; two passes of 64 pixels (2 x 33 KiB, overlaying
 // the rings) cost two more barriers per block.
 constexpr int LDS_BYTES = 2 * STG_FLOATS * 4 > RING_BYTES ? 2 * STG_FLOATS * 4 : RING_BYTES;
+// r6: the tile HEIGHT is a template parameter of the kernel (the constants above are those of TR = 4, the training tile).  A launch whose
+// 4-row tiles need a second, nearly empty round of blocks -- 300 blocks on 256 CUs at the 1920 x 2560 pyramid level (M = 19 200) -- takes
+// 6-row tiles instead: 200 blocks of 1.5x the work in ONE round (launch(): the height with the smaller rounds x rows product).
+template <int TR_> struct Geo {
+  static constexpr int TR = TR_, FR = (TR_ + 2) * FW, BM = TR_ * TC;
+  static constexpr int XPASS = (FR + 63) / 64, XBUF = XPASS * 64 * 128, W_AT = 2 * XBUF;
+  static constexpr int STG_FLOATS = (BM / 2) * PITCH, RING_BYTES = W_AT + NSW * WBUF;
+  static constexpr int LDS_BYTES = 2 * STG_FLOATS * 4 > RING_BYTES ? 2 * STG_FLOATS * 4 : RING_BYTES;
+};
+static_assert(Geo<4>::XPASS == XPASS && Geo<4>::LDS_BYTES == LDS_BYTES && Geo<6>::LDS_BYTES <= 160 * 1024, "conv3x3h geometry");
 
 struct HK {
   const char* x; const char* w; char* y;
@@ -100,10 +110,13 @@ __device__ __forceinline__ void dma16(const void* gsrc, void* lds_wave_base) {
 constexpr int TRACE_BYTES = 8 * 64 * 8 * 8;
 // EPIC (r4): the epilogue flag set as a compile-time constant (-1: read a.epi), like conv_dma_kernel's: the three sets a training step and
 // an evaluation forward use get their own instantiation, the dead modes of the generic epilogue fold away.
-template <typename T, bool TRACE, int EPIC = -1>
+template <typename T, bool TRACE, int EPIC = -1, int TR_ = 4>
 __global__ void __launch_bounds__(NT, 2) conv3x3h_kernel(const HK a) {
   const int epi_flags = EPIC >= 0 ? EPIC : a.epi;
   typedef typename Frag<T>::t frag;
+  typedef Geo<TR_> G;                                  // (the names below shadow the TR = 4 constants of the file scope)
+  constexpr int TR = G::TR, FR = G::FR, XPASS = G::XPASS, XBUF = G::XBUF, W_AT = G::W_AT, STG_FLOATS = G::STG_FLOATS, RING_BYTES = G::RING_BYTES;
+  constexpr int MH = TR / 2;                           // tile rows (= 32-pixel fragments) per pixel half
   constexpr int EPS = 8, TRACE_AT = RING_BYTES;       // (the stamps are dumped before the epilogue overlays them)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned long long t_start = 0, r_start = 0;
@@ -167,18 +180,18 @@ __global__ void __launch_bounds__(NT, 2) conv3x3h_kernel(const HK a) {
   issue_w(std::integral_constant<int, 0>{}, 0);
   issue_w(std::integral_constant<int, 1>{}, tapC);
 
-  // ---- MFMA roles: wave = (K half kg, pixel half wm, channel half wn); 2 x 2 fragments of 32 pixels x 32 channels
+  // ---- MFMA roles: wave = (K half kg, pixel half wm, channel half wn); 2 x MH fragments of 32 channels x 32 pixels (MH = 2 tile rows at TR = 4)
   const int kg = wave >> 2, wm = wave & 1, wn = (wave >> 1) & 1;
   const int l = tid & 63, r32 = l & 31, h = l >> 5;
   // fragment byte offsets, all of them: x fragment m of tap t at k-step j lives at frame row fbase(m) + shift(t) (a tap is a constant
-  // row shift inside the frame; the swizzle follows the shifted row), in frame buffer 0 -- XOR with XBUF selects buffer 1
-  int xo[9][2][2], woff[2][2];
+  // row shift inside the frame; the swizzle follows the shifted row), in frame buffer 0 -- + XBUF selects buffer 1
+  int xo[9][MH][2], woff[2][2];
 #pragma unroll
   for (int t = 0; t < 9; ++t) {
     const int shift = a.sign * ((t / 3 - 1) * FW + (t % 3 - 1));
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      const int f = (wm * 2 + m + 1) * FW + r32 + 1 + shift, sz = swz(f);       // output pixel (tile row wm*2+m, column r32)
+    for (int m = 0; m < MH; ++m) {
+      const int f = (wm * MH + m + 1) * FW + r32 + 1 + shift, sz = swz(f);      // output pixel (tile row wm*MH+m, column r32)
 #pragma unroll
       for (int j = 0; j < 2; ++j) xo[t][m][j] = f * 128 + ((((kg * 2 + j) * 2 + h) ^ sz) << 4);
     }
@@ -189,11 +202,11 @@ __global__ void __launch_bounds__(NT, 2) conv3x3h_kernel(const HK a) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) woff[n][j] = W_AT + row * 128 + ((((kg * 2 + j) * 2 + h) ^ swz(row)) << 4);
   }
-  f32x16 acc[2][2];
+  f32x16 acc[2][MH];
 #pragma unroll
   for (int n = 0; n < 2; ++n)
 #pragma unroll
-    for (int m = 0; m < 2; ++m) acc[n][m] = f32x16(0.f);
+    for (int m = 0; m < MH; ++m) acc[n][m] = f32x16(0.f);
 
   int st = 0;
   for (int chunk = 0; chunk < cpt; ++chunk) {
@@ -225,15 +238,15 @@ __global__ void __launch_bounds__(NT, 2) conv3x3h_kernel(const HK a) {
         const char* wb = smem + (tap % 3) * WBUF;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          frag xf[2], wf[2];
+          frag xf[MH], wf[2];
 #pragma unroll
-          for (int m = 0; m < 2; ++m) xf[m] = *reinterpret_cast<const frag*>(smem + xo[tap][m][j]);
+          for (int m = 0; m < MH; ++m) xf[m] = *reinterpret_cast<const frag*>(smem + xo[tap][m][j]);
 #pragma unroll
           for (int n = 0; n < 2; ++n) wf[n] = *reinterpret_cast<const frag*>(wb + woff[n][j]);
 #pragma unroll
           for (int n = 0; n < 2; ++n)
 #pragma unroll
-            for (int m = 0; m < 2; ++m) acc[n][m] = Frag<T>::mma(wf[n], xf[m], acc[n][m]);
+            for (int m = 0; m < MH; ++m) acc[n][m] = Frag<T>::mma(wf[n], xf[m], acc[n][m]);
         }
       }
       stamp(st, 4);
@@ -242,13 +255,15 @@ __global__ void __launch_bounds__(NT, 2) conv3x3h_kernel(const HK a) {
     stage(std::integral_constant<int, 0>{}); stage(std::integral_constant<int, 1>{}); stage(std::integral_constant<int, 2>{});
     stage(std::integral_constant<int, 3>{}); stage(std::integral_constant<int, 4>{}); stage(std::integral_constant<int, 5>{});
     stage(std::integral_constant<int, 6>{}); stage(std::integral_constant<int, 7>{}); stage(std::integral_constant<int, 8>{});
-    // the next chunk's frame sits in the other buffer
+    // the next chunk's frame sits in the other buffer (r6: by addition -- the 40 KiB buffer of the 6-row tile is not a power of two, the XOR of
+    // rounds 2-5 only toggled the 32 KiB one)
+    const int other = (chunk & 1) ? -XBUF : XBUF;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
+      for (int m = 0; m < MH; ++m)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) xo[t][m][j] ^= XBUF;
+        for (int j = 0; j < 2; ++j) xo[t][m][j] += other;
   }
   // (r5, measured and removed: TWO taps per barrier -- the 18 taps of two channel chunks unrolled into 9 two-tap stages, a 2-slot ring of
   //  two-tap weight slabs (128 KiB), the next frame requested behind the weights so that one counted wait leaves it in flight; parity-green,
@@ -282,7 +297,7 @@ __global__ void __launch_bounds__(NT, 2) conv3x3h_kernel(const HK a) {
 #pragma unroll
     for (int n = 0; n < 2; ++n)
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
+      for (int m = 0; m < MH; ++m)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
           *reinterpret_cast<f32x4*>(mine + (m * 32 + r32) * PITCH + wn * 64 + n * 32 + g * 8 + h * 4) =
@@ -420,16 +435,19 @@ __global__ void __launch_bounds__(NT, 2) conv3x3h_kernel(const HK a) {
 }
 
 unsigned long long* g_trace = nullptr;
+int g_last_tile_rows = 0;          // tile height of the most recent launch (tf_debug_conv3x3h_tile_rows: which instantiation a test just ran)
 int dbg_flags() { return tf::tuning().conv3h_dbg; }
 int min_blocks() {
   return tf::tuning().conv3h_minblocks;
 }
 
-template <typename T, bool TRACE, int EPIC = -1>
+template <typename T, bool TRACE, int EPIC = -1, int TR_ = 4>
 void launch_var(const HK& k, hipStream_t stream) {
+  typedef Geo<TR_> G;
   static tf::PerDevice attr_set;                     // per DEVICE: the attribute belongs to the current device's copy of the function
-  if (attr_set.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3h_kernel<T, TRACE, EPIC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  TF_LAUNCH_TIMED((conv3x3h_kernel<T, TRACE, EPIC>), dim3(k.mtiles * k.ntiles), dim3(NT), TRACE && RING_BYTES + TRACE_BYTES > LDS_BYTES ? RING_BYTES + TRACE_BYTES : LDS_BYTES, stream, k);
+  if (attr_set.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3h_kernel<T, TRACE, EPIC, TR_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  TF_LAUNCH_TIMED((conv3x3h_kernel<T, TRACE, EPIC, TR_>), dim3(k.mtiles * k.ntiles), dim3(NT),
+                  TRACE && G::RING_BYTES + TRACE_BYTES > G::LDS_BYTES ? G::RING_BYTES + TRACE_BYTES : G::LDS_BYTES, stream, k);
 }
 
 template <typename T>
@@ -442,7 +460,19 @@ int launch(const tf_conv_args* A, hipStream_t stream) {
   k.stat_shift = A->stat_shift; k.stat_shift_out = A->stat_shift_out;
   k.H = A->OH; k.W = A->OW; k.C = A->Cin; k.ldy = A->ldy; k.Ktot = 9 * A->Cin; k.cpt = A->Cin / 64; k.nst = 9 * k.cpt;
   k.ntiles = A->Cout / BN; k.epi = A->epi; k.srows = tf_get_stat_rows();
-  k.rtiles = (A->OH + TR - 1) / TR; k.ctiles = (A->OW + TC - 1) / TC; k.mtiles = A->N * k.rtiles * k.ctiles;
+  // tile height (r6): evaluation launches (folded BN + ReLU) whose 4-row tiles leave a mostly empty last round of blocks take 6-row tiles when
+  // that makes rounds x rows smaller -- 1 x 120 x 160 (the 1920 x 2560 level): 300 blocks = 2 rounds x 4 rows against 200 blocks = 1 round x 6 rows.
+  // The statistic epilogues of the training step keep TR = 4 (tf_conv3x3h_mtiles sizes their partial rows).  TINYFACES_CONV3H_TR6=0: never.
+  k.ctiles = (A->OW + TC - 1) / TC;
+  bool tall = false;
+  if (A->epi == (TF_EPI_AFFINE | TF_EPI_RELU) && !g_trace && !tf::tuning().epi_spec_off && tf::tuning().conv3h_tr6) {
+    const long cus = tf::device_cus();
+    auto cost = [&](int tr) { const long blocks = (long)A->N * ((A->OH + tr - 1) / tr) * k.ctiles * k.ntiles; return ((blocks + cus - 1) / cus) * tr; };
+    tall = cost(6) < cost(4);
+  }
+  const int tr = tall ? 6 : TR;
+  g_last_tile_rows = tr;
+  k.rtiles = (A->OH + tr - 1) / tr; k.mtiles = A->N * k.rtiles * k.ctiles;
   k.sign = A->mode == 0 ? 1 : -1;                    // forward reads pixel + (kh-1, kw-1); the data gradient reads pixel - (kh-1, kw-1)
   k.dbg = dbg_flags(); k.trace = g_trace;
   const double es = sizeof(T), M = (double)A->N * A->OH * A->OW, Kt = k.Ktot;
@@ -457,6 +487,7 @@ int launch(const tf_conv_args* A, hipStream_t stream) {
   else if (spec_off) launch_var<T, false>(k, stream);
   else if (A->epi == TF_EPI_STATS) launch_var<T, false, TF_EPI_STATS>(k, stream);                                           // training forward
   else if (A->epi == (TF_EPI_MASK | TF_EPI_STATS2)) launch_var<T, false, TF_EPI_MASK | TF_EPI_STATS2>(k, stream);           // training data gradient
+  else if (A->epi == (TF_EPI_AFFINE | TF_EPI_RELU) && tall) launch_var<T, false, TF_EPI_AFFINE | TF_EPI_RELU, 6>(k, stream);
   else if (A->epi == (TF_EPI_AFFINE | TF_EPI_RELU)) launch_var<T, false, TF_EPI_AFFINE | TF_EPI_RELU>(k, stream);           // evaluation (folded BN + ReLU)
   else launch_var<T, false>(k, stream);
   return hipGetLastError() == hipSuccess ? TF_OK : TF_ERR_LAUNCH;
@@ -483,6 +514,7 @@ bool tf_conv3x3h_applicable(const tf_conv_args* a, bool forced) {
 // debugging: register (or clear, nullptr) a device buffer of 8 blocks x 8 waves x 64 stages x 8 u64 for the stage stamps of the
 // NEXT launches (scripts/trace_conv3x3h.py); not part of the product path
 extern "C" int tf_debug_conv3x3h_trace(void* device_buf) { g_trace = (unsigned long long*)device_buf; return TF_OK; }
+extern "C" int tf_debug_conv3x3h_tile_rows(void) { return g_last_tile_rows; }
 int tf_conv3x3h_mtiles(const tf_conv_args* a) { return a->N * ((a->OH + TR - 1) / TR) * ((a->OW + TC - 1) / TC); }
 int tf_conv3x3h_launch(const tf_conv_args* a, hipStream_t stream) {
   return a->dtype == TF_BF16 ? launch<tf::bf16_t>(a, stream) : launch<tf::f16_t>(a, stream);

@@ -10,6 +10,8 @@ extern "C" {
  * 8 blocks x 8 waves x 64 stages x 8 uint64; the next launches run an instrumented instantiation that stamps s_memtime at the
  * five points of every K stage (scripts/trace_conv3x3h.py).  Not part of the product path. */
 int tf_debug_conv3x3h_trace(void* device_buf);
+/* rows of the output tile (4 or 6) the most recent conv3x3h launch of this process used (r6: tests/test_gpu_conv.py) */
+int tf_debug_conv3x3h_tile_rows(void);
 /* interference probe of the two-stream contention measurement (csrc/probe.hip, scripts/contention.py): `blocks` workgroups of 256
  * threads that hog ONE CU resource for `iters` rounds -- kind 0 park (LDS capacity + wave slots only), 1 L2 loads, 2 HBM loads,
  * 3 MFMA, 4 LDS-DMA, 5 fp32 atomics, 6 LDS reads, 9 (r5) operand-streaming pattern probe (iters = run bytes | depth << 16), 10 (r5) tile-shaped epilogue traffic alone (iters = input matrices), 7 (r4) `iters` device-wide barriers in one launch (blocks <= 1024); `buf` / `window_bytes`: device window of the memory kinds.  Not part of the

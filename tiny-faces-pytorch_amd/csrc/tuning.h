@@ -20,6 +20,7 @@ struct Tuning {
   bool epi_spec_off = false;             // TINYFACES_EPI_SPEC_OFF
   bool conv3h_off = false;               // TINYFACES_CONV3H_OFF
   int conv3h_mincin = 256;               // TINYFACES_CONV3H_MINCIN
+  bool conv3h_tr6 = true;                // TINYFACES_CONV3H_TR6 (0: evaluation launches never take the 6-row tile)
   bool pws_sliced = false;               // TINYFACES_PWS_SLICED
   bool stem_direct_off = false;          // TINYFACES_STEM_DIRECT_OFF
   int wgrad_group = 8;                   // TINYFACES_WGRAD_GROUP

@@ -25,6 +25,7 @@ Tuning parse() {
   t.epi_spec_off = flag("TINYFACES_EPI_SPEC_OFF");
   t.conv3h_off = flag("TINYFACES_CONV3H_OFF");
   t.conv3h_mincin = (int)num("TINYFACES_CONV3H_MINCIN", 256);
+  t.conv3h_tr6 = num("TINYFACES_CONV3H_TR6", 1) != 0;
   t.pws_sliced = flag("TINYFACES_PWS_SLICED");
   t.stem_direct_off = flag("TINYFACES_STEM_DIRECT_OFF");
   t.wgrad_group = (int)num("TINYFACES_WGRAD_GROUP", 8);

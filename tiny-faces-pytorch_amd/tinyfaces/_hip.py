@@ -164,6 +164,7 @@ _SIGNATURES = {
 _DEBUG_SIGNATURES = {
     "tf_probe_tr16": (i32, [vp, vp]),
     "tf_debug_conv3x3h_trace": (i32, [vp]),
+    "tf_debug_conv3x3h_tile_rows": (i32, []),
     "tf_debug_probe": (i32, [i32, i32, i32, vp, sz, i32, vp]),
     "tf_debug_probe_chain": (i32, [i32, i32, i32, vp, sz, i32, i32, vp]),
 }
