@@ -27,11 +27,18 @@ def get_dataloader(datapath, args, num_templates=25, template_file="templates.js
     world, rank = (parallel.world_size(), parallel.rank()) if parallel.is_distributed() else (1, 0)
     if str(datapath) == "synthetic-faces":
         # r6: a small FIXED image list with pasted faces (datasets/synthetic.py: SyntheticFaces) -- the same images for training and evaluation,
-        # so that train -> checkpoint -> pyramid evaluation -> result files -> AP can be closed without WIDER assets.  Data parallel: rank r
-        # trains on images r, r + world, ... (disjoint shards of the fixed list) and evaluates the same stride.
+        # so that train -> checkpoint -> pyramid evaluation -> result files -> AP can be closed without WIDER assets.  Data parallel: every global
+        # batch is split into disjoint rank shards (rotating, see below); evaluation: rank r takes images r, r + world, ...
         length = getattr(args, "synthetic_len", 8)
         ds = SyntheticFaces(templates, length=length, seed=getattr(args, "seed", 0), train=train, img_transforms=img_transforms)
         idx = list(range(rank, length, world)) if world > 1 else None
+        if world > 1 and train:
+            # the shard of a rank ROTATES with the global batch: a fixed stride would show rank 0 the even layouts only, and the BatchNorm running
+            # statistics it writes into the checkpoint (per-device statistics, like the reference's) would never have seen the odd ones -- the
+            # 2-rank learn-and-detect run then evaluated at AP 0.77-1.0 from run to run.  Like a DistributedSampler that reshuffles: every rank
+            # meets every image, every global batch is still split into disjoint halves of equal size.
+            gb = args.batch_size * world
+            idx = [k for k in range(length) if (k + k // gb) % world == rank]
         loader = data.DataLoader(ds, batch_size=args.batch_size, shuffle=False, sampler=idx, num_workers=0, collate_fn=ds.collate)
         return loader, templates
     if str(datapath) == "synthetic" or getattr(args, "synthetic", False):
