@@ -78,7 +78,7 @@ def run_fused_epoch(engine, loss_fn, loader, epoch, device, base_lr):
     for idx, batch in enumerate(loader):
         engine.step(*(t.float().to(device, non_blocking=True) for t in batch))
         if parallel.rank() == 0:
-            loss_fn.flush_meters()
+            loss_fn.flush_meters(lag=0 if idx + 1 == total else 1)      # one step behind: the host prepares batch idx + 1 while the GPU runs step idx
             trainer.print_state(idx, epoch, total, loss_fn.class_average.average, loss_fn.reg_average.average)
 
 

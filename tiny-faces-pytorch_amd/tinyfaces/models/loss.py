@@ -80,12 +80,16 @@ class DetectionCriterion(nn.Module):
         each image, (B, nt*H*W) uint8 -- replays the reference's np.random.permutation draws."""
         self._pos_keep, self._neg_keep = pos_keep, neg_keep
 
-    def flush_meters(self):
-        for loss2, size in self._pending:
+    def flush_meters(self, lag=0):
+        """Feed the loss meters from the device values of the steps enqueued so far.  `lag` = the number of MOST RECENT steps left pending: reading a
+        step's loss waits for that step, so a training loop that flushes everything after every step (lag = 0) never has the next batch in preparation
+        while the GPU works; with lag = 1 the host stays one step ahead and the printed averages trail by one step."""
+        n = max(0, len(self._pending) - lag)
+        for loss2, size in self._pending[:n]:
             v = loss2.tolist()
             self.class_average.update(v[0], size)
             self.reg_average.update(v[1], size)
-        self._pending = []
+        self._pending = self._pending[n:]
 
     def forward(self, output, class_map, regression_map):
         if not output.is_cuda:
