@@ -130,7 +130,7 @@ class WIDERFace(dataset.Dataset):
             x = torch.empty(B, 3, *self.input_size, dtype=torch.float32, device=self.device)
             boxes, pastes, flips = [], [], []
             for i, (img, bb) in enumerate(samples):
-                u8 = torch.from_numpy(img).to(self.device, non_blocking=True)
+                u8 = torch.from_numpy(img).to(self.device)      # blocking on THIS stream only: the decoded (pageable) array is not ours to keep alive
                 _, b, paste, flip = augment.process_inputs(u8, bb, self.input_size, self.neg_thresh, out=x[i], mean=mean, std=std)
                 boxes.append(b); pastes.append(paste); flips.append(int(flip))
             self._step += 1
