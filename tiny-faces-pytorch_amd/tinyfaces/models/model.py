@@ -293,7 +293,8 @@ class DetectionModel(nn.Module):
         """(Re)build the device-pointer tables the executor reads, keyed on storage identity.  The check itself walks 571 tensors
         (~0.4 ms of Python): an owner that pins the storages (TrainEngine after flatten_parameters) sets `_tables_frozen` and the walk is
         skipped until something moves the module (`_apply`, flatten_parameters)."""
-        if getattr(self, "_tables_frozen", False) and self._table_key is not None:
+        # (a constant_weights() session is the same promise as a frozen owner: the cheap check instead of the walk for every image of an evaluation loop)
+        if (getattr(self, "_tables_frozen", False) or self._session_depth > 0) and self._table_key is not None:
             # frozen: no walk over the module tree, but EVERY tensor of the table is still checked (ADVICE r5: three sentinels missed a
             # replaced tensor in between).  Replacing a Parameter or a buffer anywhere registers it with its module, which bumps the global
             # registration counter below; re-pointing `.data` keeps the object and moves its storage, which the pointer comparison over the

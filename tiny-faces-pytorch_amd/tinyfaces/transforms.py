@@ -40,14 +40,19 @@ def to_tensor(pic):
     return ToTensor()(pic)
 
 
-def to_uint8_hwc(t):
-    """float CHW tensor -> (x*255) truncated to uint8, HWC ndarray: the pixels of to_pil_image(t) without the PIL object."""
+def to_uint8_chw(t):
+    """float CHW tensor -> (x*255) truncated to uint8, still CHW (ndarray): the pixels of to_pil_image(t), planar."""
     a = t.detach().cpu().numpy()
     if t.is_floating_point():
         # pic.mul(255).byte() of torchvision's to_pil_image, in numpy: the same IEEE product and the same truncation, without torch's intra-op thread
         # fan-out (r6: 90 ms per 1280 x 960 image on a 256-thread host against 5 ms -- it was 94 % of get_detections end to end)
         a = (a * a.dtype.type(255)).astype(np.uint8)
-    return np.ascontiguousarray(a.transpose(1, 2, 0))
+    return np.ascontiguousarray(a)
+
+
+def to_uint8_hwc(t):
+    """... interleaved (H, W, 3): what PIL holds."""
+    return np.ascontiguousarray(to_uint8_chw(t).transpose(1, 2, 0))
 
 
 def to_pil_image(t):
