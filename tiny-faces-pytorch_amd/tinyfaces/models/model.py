@@ -214,7 +214,7 @@ class DetectionModel(nn.Module):
         self._sync_tables(dev)
         order, lane_of = self.assign_lanes([x.shape[0] * x.shape[2] * x.shape[3] for x in xs], n_lanes)
         while len(self._lanes) < n_lanes - 1:
-            self._lanes.append({"ws": None, "stream": torch.cuda.Stream(device=dev), "ready": None})
+            self._lanes.append({"ws": None, "stream": torch.cuda.Stream(device=dev, priority=int(os.environ.get("TINYFACES_EVAL_LANE_PRIO", "0"))), "ready": None})
         cur = torch.cuda.current_stream(dev)
         inputs_ready = cur.record_event()                                 # the level tensors were produced on the caller's stream
         outs = [None] * len(xs)
