@@ -253,7 +253,10 @@ inline dim3 fused_grid(int64_t M, int C, int dtype) {
   const int rpp = 256 / (cs / eps);
   const int slices = C / cs;
   int64_t gx = (M + rpp - 1) / rpp;
-  const int total_cap = tf::tuning().ew_blocks;
+  // r6: a block re-derives the BN coefficients of its channel slice from the statistic rows (rows x 2..3 x C floats + gamma / beta: 16+ KB at C = 256)
+  // before it touches its 8-row passes of 4 KB: with ~2k blocks the coefficient reads outweighed a layer-3 tensor itself.  Two caps, by tensor size.
+  const double bytes = (double)M * C * (dtype == TF_F32 ? 4 : 2);
+  const int total_cap = bytes < tf::tuning().ew_small_mb * 1048576.0 ? tf::tuning().ew_blocks_small : tf::tuning().ew_blocks;
   const int64_t cap = std::max(1, total_cap / slices);   // ~2k blocks: enough loads in flight, bounded coefficient re-derivation
   if (gx > cap) gx = cap;
   if (gx < 1) gx = 1;

@@ -4,7 +4,9 @@
 #pragma once
 namespace tf {
 struct Tuning {
-  int ew_blocks = 2048;                  // TINYFACES_EW_BLOCKS
+  int ew_blocks = 1024;                  // TINYFACES_EW_BLOCKS: block cap of the fused BN passes (r6: 2048 -> 1024, +1.0 % on the step)
+  int ew_blocks_small = 768;             // TINYFACES_EW_BLOCKS_SMALL: the cap for tensors below ew_small_mb
+  int ew_small_mb = 40;                  // TINYFACES_EW_SMALL_MB
   bool comm_fail_init = false;           // TINYFACES_COMM_FAIL_INIT
   int comm_fail_bucket = -1;             // TINYFACES_COMM_FAIL_BUCKET
   bool pws_off = false;                  // TINYFACES_PWS_OFF

@@ -9,7 +9,9 @@ bool flag(const char* name) { return getenv(name) != nullptr; }
 long num(const char* name, long dflt) { const char* e = getenv(name); return e ? atol(e) : dflt; }
 Tuning parse() {
   Tuning t;
-  t.ew_blocks = (int)num("TINYFACES_EW_BLOCKS", 2048);
+  t.ew_blocks = (int)num("TINYFACES_EW_BLOCKS", 1024);
+  t.ew_blocks_small = (int)num("TINYFACES_EW_BLOCKS_SMALL", 768);
+  t.ew_small_mb = (int)num("TINYFACES_EW_SMALL_MB", 40);
   t.comm_fail_init = flag("TINYFACES_COMM_FAIL_INIT");
   t.comm_fail_bucket = (int)num("TINYFACES_COMM_FAIL_BUCKET", -1);
   t.pws_off = flag("TINYFACES_PWS_OFF");
