@@ -59,7 +59,7 @@ Tuning parse() {
   t.pool_stats_blocks = (int)num("TINYFACES_POOL_STATS_BLOCKS", 8192);
   t.profile_bracket = flag("TINYFACES_PROFILE_BRACKET");
   t.stem_wgrad_blocks = (int)num("TINYFACES_STEM_WGRAD_BLOCKS", 384);
-  t.wgrad3_blocks = (int)num("TINYFACES_WGRAD3_BLOCKS", 256);
+  t.wgrad3_blocks = (int)num("TINYFACES_WGRAD3_BLOCKS", 128);
   t.wgrad3_atomics = flag("TINYFACES_WGRAD3_ATOMICS");
   t.wgrad3_dbg = (int)num("TINYFACES_WGRAD3_DBG", 0);
   t.wgrad_blocks = (int)num("TINYFACES_WGRAD_BLOCKS", 512);
