@@ -257,6 +257,45 @@ def test_conv_real_layer_shapes(dtype, case):
     assert dwe[2] < (1e-4 if dtype == torch.float32 else 3e-3)
 
 
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", [(2, 16, 16, 128, 64), (3, 32, 32, 1024, 512), (1, 63, 63, 128, 64)])
+def test_scattered_downsample_gradient_accumulates_in_place(dtype, case):
+    """r6: the data gradient of a 1x1 / stride-2 conv (downsample branch of layer2.0 / layer3.0) with aux == y: its rows are ADDED to the even-even
+    pixels of a raster another launch already wrote -- no zero fill, no residual copy of the 2x larger raster --, with the hand-over epilogue
+    riding along: ReLU mask of the previous block's output (MASK2) and the BN-backward sums (STATS3) taking only what THIS launch adds.
+    Reference: torch conv_transpose2d on the same rounded operands; the raster holds an already masked gradient g1 and the sum rows hold g1's sums."""
+    from tinyfaces import _hip, ops
+    N, h, w_, Cgrad, Cin = case                       # gradient raster (N, h, w_, Cgrad) -> input raster (N, 2h-1, 2w_-1, Cin)
+    H, W = 2 * h - 1, 2 * w_ - 1
+    g = _g(hash(case) % 1000)
+    wt = torch.randn(Cgrad, Cin, 1, 1, generator=g) / Cgrad ** 0.5          # the forward conv: Cin -> Cgrad, stride 2
+    gy = torch.randn(N, Cgrad, h, w_, generator=g)
+    yprev = torch.randn(N, Cin, H, W, generator=g)                            # the previous block's output: its sign is the ReLU mask
+    x3 = torch.randn(N, Cin, H, W, generator=g)                               # its conv3 output (the BN-backward sum operand)
+    mask = (q(yprev, dtype) > 0).float()
+    g1 = q(torch.randn(N, Cin, H, W, generator=g), dtype) * mask              # what the hand-over conv left in the raster (masked)
+    gds = F.conv_transpose2d(q(gy, dtype), q(wt, dtype), stride=2)            # (N, Cin, 2h-1, 2w_-1): nonzero on even-even pixels only
+    ref = (g1 + gds) * mask
+    raster = to_nhwc(g1, dtype)
+    rows = _hip.lib().tf_get_stat_rows()
+    sums0 = torch.stack([(g1 * 1.0).sum(dim=(0, 2, 3)), (g1 * q(x3, dtype)).sum(dim=(0, 2, 3))])          # (2, Cin): already counted by the hand-over
+    stats = torch.zeros(rows, 2, Cin, device="cuda")
+    stats[0] = sums0.cuda()
+    wp = ops.pack_weight(wt.cuda(), dtype, transpose=True)
+    out, st = ops.conv2d_nhwc(to_nhwc(gy, dtype), wp, Cin, 1, 1, 2, 0, mode=1, out_hw=(H, W), epi=_hip.EPI_RES | _hip.EPI_MASK2 | _hip.EPI_STATS3,
+                              aux=raster, aux2=to_nhwc(yprev, dtype), aux3=to_nhwc(x3, dtype), want_stats=True, out=raster, stats_into=stats)
+    assert out.data_ptr() == raster.data_ptr()
+    d = err(from_nhwc(out), ref)
+    tot = st.sum(0).cpu()
+    want = torch.stack([ref.sum(dim=(0, 2, 3)), (ref * q(x3, dtype)).sum(dim=(0, 2, 3))])
+    # odd pixels must be untouched bit for bit
+    odd = from_nhwc(out)[:, :, 1::2, :]
+    report(f"scatter_inplace[{dtype},{case}]", rel=d[2], sum_rel=err(tot[0], want[0])[2], sumx_rel=err(tot[1], want[1])[2])
+    assert torch.equal(odd, g1[:, :, 1::2, :].to(odd.dtype))
+    assert d[2] < TOL[dtype]
+    assert err(tot[0], want[0])[2] < 5e-3 and err(tot[1], want[1])[2] < 5e-3
+
+
 WG_CASES = [
     # N, H, W, Cin, Cout, K, stride
     (1, 9, 7, 64, 64, 1, 1),

@@ -41,6 +41,8 @@ struct DmaK {
   int M, OHW, ldy, Ktot, cpt, nstages, ntiles, mode, epi, srows, mtiles, dbg;
   int scat, sc_hw, sc_w, sc_OH, sc_OW;   // scattered rows (stride-2 data gradients): GEMM row p = (n, h, w) of a half-resolution raster -> output pixel (n, 2h + ph, 2w + pw)
   int ph, pw, kh0, kw0;                  // scat == 2 (KIND 2): parity class of the output pixels and its first tap (taps kh0, kh0+2, .. x kw0, kw0+2, ..)
+  int inplace;                           // r6, scat == 1 with aux == y: the scattered rows ACCUMULATE into a raster another launch already wrote (no initialisation;
+                                         // statistic sums take the increment only)
   // pro == 1 (ring-less pointwise, 2-byte types): x := relu(bn(x)) applied to the pixel tile in LDS after its DMA landed (tf_conv_args.bnf)
   int pro, pf_rows; float pf_count, pf_eps, pf_mom;
   const float* pf_stat; const float* pf_gamma; const float* pf_beta; const float* pf_sshift;
@@ -530,7 +532,12 @@ __global__ void __launch_bounds__(256, MMA == 32 ? 2 : (NS <= 2 && BM == 128 && 
         float x3[EPS];
         if constexpr (PF_COLD3) tf::unpack16<T>(pf1[ps], x3); else tf::unpack16<T>(*reinterpret_cast<const uint4*>(a.aux3 + o), x3);
 #pragma unroll
-        for (int j = 0; j < EPS; ++j) { s1[j] += v[j]; s2[j] += v[j] * x3[j]; }
+        for (int j = 0; j < EPS; ++j) {
+          // in place (r6): the launch that wrote the raster already counted ax = its (masked) value here; this launch adds what IT adds.
+          // (ax is zero wherever the mask is: v - ax == mask ? acc : 0)
+          const float d = a.inplace ? v[j] - ax[j] : v[j];
+          s1[j] += d; s2[j] += d * x3[j];
+        }
       }
       *reinterpret_cast<uint4*>(a.y + o) = tf::pack16<T>(v);
     }
@@ -566,7 +573,7 @@ __global__ void __launch_bounds__(256, MMA == 32 ? 2 : (NS <= 2 && BM == 128 && 
         // rows start at zero: the finalize kernels clear what they consumed), so the finalize reads 64 rows, not thousands
         const float v = red[(0 * 2 + k) * BN + cl] + red[(1 * 2 + k) * BN + cl] + red[(2 * 2 + k) * BN + cl] + red[(3 * 2 + k) * BN + cl];
         // (several launches of a parity-decomposed gradient fold into the same rows: always accumulate there)
-        if (a.mtiles > a.srows || a.scat == 2) atomicAdd(&a.stat_out[((size_t)(mt % a.srows) * 2 + k) * a.ldy + c], v);
+        if (a.mtiles > a.srows || a.scat) atomicAdd(&a.stat_out[((size_t)(mt % a.srows) * 2 + k) * a.ldy + c], v);
         else a.stat_out[((size_t)mt * 2 + k) * a.ldy + c] = v;
       }
     }
@@ -602,6 +609,7 @@ int launch_kind(const tf_conv_args* A, hipStream_t stream, int pcls = -1) {
   if (KIND == 1 && A->mode == 1 && A->stride == 2) {      // scattered pointwise data gradient (see launch()): rows = the GRADIENT raster
     k.scat = 1; k.M = A->N * A->H * A->W; k.sc_hw = A->H * A->W; k.sc_w = A->W; k.sc_OH = A->OH; k.sc_OW = A->OW;
   }
+  k.inplace = (k.scat == 1 && (A->epi & TF_EPI_RES) && A->aux == (const void*)A->y) ? 1 : 0;
   k.cpt = A->Cin / KCH; k.Ktot = A->KH * A->KW * A->Cin; k.nstages = A->KH * A->KW * k.cpt;
   if (KIND == 2 && pcls >= 0) {                           // one parity class of the output raster (see launch())
     k.scat = 2; k.ph = pcls >> 1; k.pw = pcls & 1;
@@ -643,7 +651,7 @@ int launch_kind(const tf_conv_args* A, hipStream_t stream, int pcls = -1) {
     if (pcls >= 0) bytes = ((double)A->N * A->H * A->W * A->Cin + (double)A->Cout * Kt) * es / 4 + M * A->Cout * es * (1 + ((A->epi & (TF_EPI_RES | TF_EPI_MASK | TF_EPI_STATS2)) ? 1 : 0));
     tf::ProfScope prof(A->dtype == TF_F32 ? 12 : (A->dtype == TF_BF16 ? 13 : 15), alg_fl, bytes, stream, k.M, A->Cout, k.Ktot,
                        A->KH * A->KW, A->mode, A->epi, exec_fl, true);   // 12 = conv_dma f32, 13 = conv_dma bf16, 15 = conv_dma f16
-    if (k.scat == 1) {
+    if (k.scat == 1 && !k.inplace) {
       prof.begin_bracket();                          // the initialisation of the raster is part of this launch's cost
       // the three other parities of the output raster: zero, or the residual operand itself (y = 0 + aux there)
       const size_t ybytes = (size_t)A->N * A->OH * A->OW * A->ldy * sizeof(T);
@@ -672,6 +680,7 @@ int launch_kind(const tf_conv_args* A, hipStream_t stream, int pcls = -1) {
           if (A->epi == TF_EPI_STATS) go(std::integral_constant<int, TF_EPI_STATS>{});
           else if (A->epi == (TF_EPI_MASK | TF_EPI_STATS2)) go(std::integral_constant<int, TF_EPI_MASK | TF_EPI_STATS2>{});
           else if (KIND == 1 && A->epi == (TF_EPI_RES | TF_EPI_MASK2 | TF_EPI_STATS3)) go(std::integral_constant<int, TF_EPI_RES | TF_EPI_MASK2 | TF_EPI_STATS3>{});
+          else if (KIND == 1 && A->epi == (TF_EPI_MASK2 | TF_EPI_STATS3)) go(std::integral_constant<int, TF_EPI_MASK2 | TF_EPI_STATS3>{});      // r6: the hand-over of layer2.0 (its residual arrives in place, behind it)
         }
         if (!done && KIND != 2) {                      // the folded-BN epilogues of the evaluation graph (forward convs only)
           if (A->epi == (TF_EPI_AFFINE | TF_EPI_RELU)) go(std::integral_constant<int, TF_EPI_AFFINE | TF_EPI_RELU>{});
@@ -694,7 +703,12 @@ int launch(const tf_conv_args* A, hipStream_t stream) {
   // the output raster (statistics) or read a mask there keep the generic kernel; TINYFACES_SCATTER_DGRAD_OFF=1: A/B knob.
   const bool scat_off = tf::tuning().scatter_dgrad_off;
   if (!scat_off && A->mode == 1 && A->KH == 1 && A->KW == 1 && A->stride == 2 && A->pad == 0 && A->OH >= 2 * A->H - 1 && A->OW >= 2 * A->W - 1 &&
-      !(A->epi & ~(TF_EPI_RES | TF_EPI_AFFINE)) && A->ldy == A->Cout)
+      A->ldy == A->Cout &&
+      (!(A->epi & ~(TF_EPI_RES | TF_EPI_AFFINE)) ||
+       // r6: IN PLACE (aux == y): the raster already holds another launch's result and the scattered rows are added to it -- then the ReLU mask
+       // and the BN-backward sums of a hand-over may ride along: they see exactly the rows this launch changes (the executor's stride-2
+       // downsample gradients: no zero fill / residual copy of the 2x larger raster, no second read of it by the hand-over)
+       ((A->epi & TF_EPI_RES) && A->aux == (const void*)A->y && !(A->epi & ~(TF_EPI_RES | TF_EPI_MASK2 | TF_EPI_STATS3)))))
     return launch_kind<T, BM, BN, NS, 1, MMA>(A, stream);
   // r3: the data gradient of a 3x3 / stride-2 / pad-1 conv (conv2 of layer2.0 / layer3.0), by PARITY CLASS of the output pixel.  An output
   // pixel (ih, iw) only receives the taps with (ih + 1 - kh) and (iw + 1 - kw) even: 1, 2, 2 or 4 of the 9; the generic transposed gather

@@ -1174,6 +1174,23 @@ extern "C" int tf_detnet_backward_ctx(tf_detnet_ctx* xctx, const tf_detnet_hooks
         c.chk(tf_bn_bwd_apply(dtype, Gcur, b.y, b.d, b.bd.cA, b.bd.cB, b.bd.cD, Mout, c4, T3, c.stream));
       }
       if (fork_each) { c.fork_armed(); wgrad(c, B.ds, c4, N, b.Hin, b.Win, b.Hout, b.Wout, yin, B.cin, T3, c4, nullptr); }
+      // r6: the stride-2 downsample gradient is nonzero on the even-even pixels of the block's input raster only.  Rounds 3-5 zeroed (or, with
+      // the res3 head gradient, copied) a raster of that size, scattered into it, and the hand-over conv read it back as its residual: a
+      // 96 MB fill + 49 MB copy by blit kernels at 2.6 TB/s and two more passes over those rasters.  Now the hand-over writes the raster first
+      // (residual = the head gradient where there is one) and the scattered gradient ACCUMULATES IN PLACE (tf_conv2d: aux == y), applying the
+      // same ReLU mask and adding its own share to the same BN-backward sums.  TINYFACES_DS_INPLACE_OFF=1: the old order.
+      const bool ds_inplace = fused && i > 0 && B.stride == 2 && !tf::tuning().ds_inplace_off;
+      if (ds_inplace) {
+        conv_fill(a, dtype, 1, N, b.Hin, b.Win, pl, b.Hin, b.Win, B.cin, 1, 1, 0, B.cin, U1, b.w1t, Gnext);
+        if (extra) { a.epi = TF_EPI_RES; a.aux = extra; }
+        hand_over(a);
+        c.chk(tf_conv2d(&a, c.stream));
+        conv_fill(a, dtype, 1, N, b.Hout, b.Wout, c4, b.Hin, b.Win, B.cin, 1, B.stride, 0, B.cin, T3, b.wdt, Gnext);
+        a.epi = TF_EPI_RES; a.aux = Gnext;
+        hand_over(a);
+        a.tile = 0;                                          // (the hand-over tile knob is about the pointwise conv above)
+        c.chk(tf_conv2d(&a, c.stream));
+      } else {
       conv_fill(a, dtype, 1, N, b.Hout, b.Wout, c4, b.Hin, b.Win, B.cin, 1, B.stride, 0, B.cin, T3, b.wdt, P.T4);
       if (extra) { a.epi = TF_EPI_RES; a.aux = extra; }
       c.chk(tf_conv2d(&a, c.stream));
@@ -1181,6 +1198,7 @@ extern "C" int tf_detnet_backward_ctx(tf_detnet_ctx* xctx, const tf_detnet_hooks
       a.epi = TF_EPI_RES; a.aux = P.T4;
       hand_over(a);
       c.chk(tf_conv2d(&a, c.stream));
+      }
     } else {
       conv_fill(a, dtype, 1, N, b.Hin, b.Win, pl, b.Hin, b.Win, B.cin, 1, 1, 0, B.cin, U1, b.w1t, Gnext);
       if (fused) { a.epi = TF_EPI_RES; a.aux = Gcur; hand_over(a); }       // identity branch: Gcur is already g_y * (y > 0)

@@ -63,6 +63,7 @@ struct Tuning {
   int wgradg_fast = 8;                   // TINYFACES_WGRADG_FAST
   int conv_dbg = 0;                      // TF_CONV_DBG
   bool scatter_dgrad_off = false;        // TINYFACES_SCATTER_DGRAD_OFF
+  bool ds_inplace_off = false;           // TINYFACES_DS_INPLACE_OFF (1: zero / copy the raster, scatter, hand over with it as the residual: rounds 3-5)
   bool parity_dgrad_off = false;         // TINYFACES_PARITY_DGRAD_OFF
   int ns2_maxstages = 16;                // TINYFACES_NS2_MAXSTAGES
   int ns1_maxstages = 4;                 // TINYFACES_NS1_MAXSTAGES

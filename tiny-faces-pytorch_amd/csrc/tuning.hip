@@ -68,6 +68,7 @@ Tuning parse() {
   t.wgradg_fast = (int)num("TINYFACES_WGRADG_FAST", 8);
   t.conv_dbg = (int)num("TF_CONV_DBG", 0);
   t.scatter_dgrad_off = flag("TINYFACES_SCATTER_DGRAD_OFF");
+  t.ds_inplace_off = flag("TINYFACES_DS_INPLACE_OFF");
   t.parity_dgrad_off = flag("TINYFACES_PARITY_DGRAD_OFF");
   t.ns2_maxstages = (int)num("TINYFACES_NS2_MAXSTAGES", 16);
   t.ns1_maxstages = (int)num("TINYFACES_NS1_MAXSTAGES", 4);

@@ -363,8 +363,10 @@ def stem_wgrad(x_nchw, g_nhwc, x_conv=None, cA=None, cB=None, cD=None):
 
 
 def conv2d_nhwc(x, w_packed, Cout, KH, KW, stride, pad, mode=0, out_hw=None, ldy=None, pro=None, epi=0, epi_scale=None,
-                epi_shift=None, aux=None, aux2=None, aux3=None, mask=None, want_stats=False, tile=0):
-    """x (N,H,W,Cin) dtype bf16|f32 contiguous; returns y (N,OH,OW,ldy) [, stat partials (mtiles,2,ldy)]."""
+                epi_shift=None, aux=None, aux2=None, aux3=None, mask=None, want_stats=False, tile=0, out=None, stats_into=None):
+    """x (N,H,W,Cin) dtype bf16|f32 contiguous; returns y (N,OH,OW,ldy) [, stat partials (mtiles,2,ldy)].
+    out: write into this (N,OH,OW,ldy) tensor (with aux=out and TF_EPI_RES the scattered stride-2 data gradient accumulates in place);
+    stats_into: add the statistic sums into these existing rows instead of fresh zeros."""
     require_gpu(x, "conv2d_nhwc")
     N, H, W, Cin = x.shape
     if out_hw is None:
@@ -376,7 +378,7 @@ def conv2d_nhwc(x, w_packed, Cout, KH, KW, stride, pad, mode=0, out_hw=None, ldy
     a.dtype, a.mode = _hip.tf_dtype(x.dtype), mode
     a.N, a.H, a.W, a.Cin, a.OH, a.OW, a.Cout, a.KH, a.KW, a.stride, a.pad = N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad
     a.ldy, a.epi, a.tile = ldy, epi, tile
-    y = torch.empty(N, OH, OW, ldy, dtype=x.dtype, device=x.device)
+    y = torch.empty(N, OH, OW, ldy, dtype=x.dtype, device=x.device) if out is None else out
     a.x, a.w, a.y = ptr(x), ptr(w_packed), ptr(y)
     keep = [x, w_packed, y]
     if pro is not None:
@@ -394,7 +396,7 @@ def conv2d_nhwc(x, w_packed, Cout, KH, KW, stride, pad, mode=0, out_hw=None, ldy
     if want_stats:
         mt = lib().tf_conv_mtiles(C.byref(a))
         check(min(mt, 0), "tf_conv_mtiles")              # negative: the requested tile code does not take this launch
-        stats = torch.zeros(mt, 2, ldy, dtype=torch.float32, device=x.device)
+        stats = torch.zeros(mt, 2, ldy, dtype=torch.float32, device=x.device) if stats_into is None else stats_into
         a.stat_out = ptr(stats)
     with torch.cuda.device(x.device):
         check(lib().tf_conv2d(C.byref(a), stream()), "tf_conv2d")
