@@ -181,6 +181,9 @@ typedef struct tf_conv_args {
   const float* pro_scale; const float* pro_shift;
   const float* epi_scale; const float* epi_shift;
   const void* aux; const void* aux2; const void* aux3;
+                      /* r6: mode 1, 1x1, stride 2 (the data gradient of a downsample conv) with TF_EPI_RES and aux == y: IN PLACE -- the launch adds its rows to the
+                         even-even pixels of a raster that already holds another launch's result, touches no other pixel, and TF_EPI_MASK2 / TF_EPI_STATS3
+                         then apply to those rows only (the sums take the increment).  With aux != y the raster is initialised first (zero, or aux). */
   const float* mask_scale; const float* mask_shift;
   float* stat_out;    /* [mtiles][2][ldy] fp32 partial sums, mtiles = tf_conv_mtiles() */
   int tile;           /* 0 = auto (recommended).  Else a kernel / tile code, pixels x channels: 11 128x128, 12 128x64, 13 64x64 on the LDS-DMA
