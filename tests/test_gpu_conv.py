@@ -608,7 +608,7 @@ def test_bn_fused_consumers_chain(dtype, C, ds):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("hw", [(8, 8), (13, 17), (63, 63)])
+@pytest.mark.parametrize("hw", [(8, 8), (13, 17), (63, 63), (30, 40), (6, 10)])
 def test_upsample_add_crop_fwd_bwd(dtype, hw):
     """score4_upsample (ConvTranspose2d k4 s2 p1, bilinear diagonal) + crop + add, vs torch (model.py:104-126)."""
     from tinyfaces._hip import lib, ptr, stream, tf_dtype

@@ -557,46 +557,105 @@ template <typename T> __device__ __forceinline__ void load4(const T* p, float* f
 
 // out NCHW fp32 [B][C][H3][W3] = s3[(b,y,x)][c] + sum_{ky,kx} s4[(b,i,j)][c] * wup[c][ky][kx],  y = 2i-1+ky, x = 2j-1+kx
 // (model.py:104-126; only the channel diagonal of score4_upsample.weight is non-zero, model.py:61-65)
+constexpr int kUpPx = 64;                        // pixels per block (256-byte runs in every output plane; 128: slower, 2 blocks per CU)
+constexpr int kUpT = 512;                        // threads of upsample_add_kernel: 8 waves share one 41 KB staging tile (3 blocks = 24 waves per CU)
 template <typename T>
-__global__ void __launch_bounds__(256) upsample_add_kernel(const T* __restrict__ s3, const T* __restrict__ s4, const float* __restrict__ wup,
+__global__ void __launch_bounds__(kUpT) upsample_add_kernel(const T* __restrict__ s3, const T* __restrict__ s4, const float* __restrict__ wup,
                                                            int B, int C, int ldc, int H3, int W3, int H4, int W4, float* __restrict__ out) {
-  // block: 64 consecutive pixels of one image x all channels; LDS transpose for coalesced NCHW rows
-  extern __shared__ float tile[];                 // [C][65]
+  // block: 64 consecutive pixels of one image x all channels; LDS transpose for coalesced NCHW rows.
+  // r6 rewrite (the kernel ran at 0.6-0.8 TB/s: 110 us for the 63 MB of the 1920 x 2560 pyramid level, the LAST kernel of every evaluation forward):
+  //   * 16-byte operand loads, and ALL of a thread's loads (its s3 chunk + up to four s4 taps, for each of its four (pixel, chunk) items) are requested
+  //     before the first one is used -- the old loop walked eight items one after the other, five dependent round trips each;
+  //   * the 16 bilinear weights of a channel come from an LDS table ordered [pixel parity][tap][channel] (two float4 reads per tap) instead of
+  //     16 scalar global loads per item;
+  //   * the staging tile is [pixel][ldc + 1]: the chunk-major writes and the pixel-major reads of the transposition are both (nearly) conflict-free.
+  // Same sums in the same order as before: bit-identical outputs.
+  constexpr int EPS = tf::Elem<T>::kPer16B;
+  extern __shared__ float up_smem[];
+  float* const wtab = up_smem;                     // [py][px][a][b][ldc]
+  const int pitch = ldc + 1;
+  float* const tile = up_smem + 16 * ldc;          // [kUpPx][pitch]
   const int hw = H3 * W3;
-  const int tiles_per_img = (hw + 63) / 64;
-  const int b = blockIdx.x / tiles_per_img, p0 = (blockIdx.x % tiles_per_img) * 64;
-  const int cq = ldc / 4;                         // 4-channel groups per pixel
-  for (int e = threadIdx.x; e < 64 * cq; e += 256) {
-    const int px = e / cq, c4 = (e % cq) * 4;
-    const int p = p0 + px;
-    if (p >= hw) continue;
-    const int y = p / W3, x = p - y * W3;
-    float v[4], t[4];
-    load4(s3 + ((size_t)b * hw + p) * ldc + c4, v);          // (r4: one 8- / 16-byte load per 4-channel group instead of four element loads)
+  const int tiles_per_img = (hw + kUpPx - 1) / kUpPx;
+  const int b = blockIdx.x / tiles_per_img, p0 = (blockIdx.x % tiles_per_img) * kUpPx;
+  (void)B;
+  const int chunks = ldc / EPS, total = kUpPx * chunks;
+  constexpr int NI = (kUpPx * 16 + kUpT - 1) / kUpT;      // one batch covers a 2-byte tile (16 chunks per pixel); fp32 takes two
+  uint4 q3[NI], q4[NI][4];
+  bool ok[NI], tv[NI][4];
+  int ipx[NI], ich[NI], ipar[NI];
+  auto request = [&](int e0) {                     // every load of a batch of NI (pixel, chunk) items, none of them waited for
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      const int ky = ((y + 1) & 1) + 2 * a, ty = y + 1 - ky;
-      if (ty < 0) continue;
-      const int i = ty >> 1;
-      if (i >= H4) continue;
+    for (int k = 0; k < NI; ++k) {
+      const int e = e0 + k * kUpT;
+      const int px = e / chunks, ch = e - px * chunks, p = p0 + px;
+      ok[k] = e < total && p < hw;
+      const int pp = ok[k] ? p : 0;
+      const int y = pp / W3, x = pp - y * W3;
+      ipx[k] = px; ich[k] = ch; ipar[k] = ((y & 1) * 2 + (x & 1)) * 4;
+      const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+      q3[k] = ok[k] ? *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(s3 + ((size_t)b * hw + pp) * ldc) + ch * 16) : z;
 #pragma unroll
-      for (int bb = 0; bb < 2; ++bb) {
-        const int kx = ((x + 1) & 1) + 2 * bb, tx = x + 1 - kx;
-        if (tx < 0) continue;
-        const int jx = tx >> 1;
-        if (jx >= W4) continue;
-        load4(s4 + (((size_t)b * H4 + i) * W4 + jx) * ldc + c4, t);
+      for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) if (c4 + j < C) v[j] += t[j] * wup[(c4 + j) * 16 + ky * 4 + kx];
-      }
+        for (int bb = 0; bb < 2; ++bb) {
+          const int ky = ((y + 1) & 1) + 2 * a, ty = y + 1 - ky, i = ty >> 1;
+          const int kx = ((x + 1) & 1) + 2 * bb, tx = x + 1 - kx, jx = tx >> 1;
+          const bool v = ok[k] && ty >= 0 && i < H4 && tx >= 0 && jx < W4;
+          tv[k][a * 2 + bb] = v;
+          q4[k][a * 2 + bb] = v ? *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(s4 + (((size_t)b * H4 + i) * W4 + jx) * ldc) + ch * 16) : z;
+        }
     }
+  };
+  auto finish = [&]() {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) if (c4 + j < C) tile[(c4 + j) * 65 + px] = v[j];
+    for (int k = 0; k < NI; ++k) {
+      if (!ok[k]) continue;
+      float v[EPS], t[EPS];
+      tf::unpack16<T>(q3[k], v);
+#pragma unroll
+      for (int tp = 0; tp < 4; ++tp) {
+        if (!tv[k][tp]) continue;
+        tf::unpack16<T>(q4[k][tp], t);
+        const float* wt = wtab + (ipar[k] + tp) * ldc + ich[k] * EPS;
+#pragma unroll
+        for (int j = 0; j < EPS; ++j) v[j] += t[j] * wt[j];
+      }
+      float* dst = tile + ipx[k] * pitch + ich[k] * EPS;
+#pragma unroll
+      for (int j = 0; j < EPS; ++j) dst[j] = v[j];
+    }
+  };
+  // the first batch is requested BEFORE the weight table is built: the table's own (gathering) loads and the operand loads travel together, and a
+  // block pays one memory round trip in front of its arithmetic, not two
+  request(threadIdx.x);
+  for (int e = threadIdx.x; e < 16 * ldc; e += kUpT) {
+    const int c = e % ldc, k = e / ldc;
+    const int ky = ((((k >> 3) & 1) + 1) & 1) + 2 * ((k >> 1) & 1), kx = ((((k >> 2) & 1) + 1) & 1) + 2 * (k & 1);
+    wtab[e] = c < C ? wup[c * 16 + ky * 4 + kx] : 0.f;
   }
+  __syncthreads();                                 // the weight table
+  finish();
+  for (int e0 = threadIdx.x + NI * kUpT; e0 < total; e0 += NI * kUpT) { request(e0); finish(); }
   __syncthreads();
-  for (int e = threadIdx.x; e < C * 64; e += 256) {
-    const int c = e / 64, px = e % 64;
-    if (p0 + px < hw) out[((size_t)b * C + c) * hw + p0 + px] = tile[c * 65 + px];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int h0 = 0; h0 < kUpPx; h0 += 64) {
+    if ((hw & 3) == 0) {
+      // rows of 4 floats stay 16-byte aligned in every channel plane: a lane stores four pixels of one channel, a wave 4 channels x 64 pixels = 1 KiB
+      const int q = lane & 15, cw = lane >> 4;
+      if (p0 + h0 + 4 * q < hw) {                    // (hw % 4 == 0: a group of four is inside the image or outside as a whole)
+        float* o = out + (size_t)b * C * hw + p0 + h0 + 4 * q;
+        const float* src = tile + (h0 + 4 * q) * pitch;
+#pragma unroll 2
+        for (int c = wave * 4 + cw; c < C; c += kUpT / 16)
+          *reinterpret_cast<float4*>(o + (size_t)c * hw) = make_float4(src[c], src[pitch + c], src[2 * pitch + c], src[3 * pitch + c]);
+      }
+    } else if (p0 + h0 + lane < hw) {
+      float* o = out + (size_t)b * C * hw + p0 + h0 + lane;
+      const float* src = tile + (h0 + lane) * pitch;
+#pragma unroll 4
+      for (int c = wave; c < C; c += kUpT / 64) o[(size_t)c * hw] = src[c];
+    }
   }
 }
 
@@ -630,34 +689,44 @@ __global__ void __launch_bounds__(256) upsample_add_bwd_kernel(const float* __re
       }
     }
   }
+  // r6: the 16 upsample weights of the block's 32 channels, once, into LDS (the g4 loop read 16 scalars per element from global memory)
+  float* const wl = slab + 4 * kUpC * pitch;       // [kUpC][16]
+  for (int e = threadIdx.x; e < kUpC * 16; e += 256) wl[e] = (c0 + e / 16 < C) ? wup[(size_t)c0 * 16 + e] : 0.f;
   __syncthreads();
-  // g3 rows 2i, 2i+1 (slab rows 1, 2): thread -> channel threadIdx % 32, columns threadIdx / 32 + 8 k
-  {
-    const int cl = threadIdx.x % kUpC;
+  // r6: a thread finishes EPS consecutive channels of one pixel and stores 16 bytes (the first form stored one 2-byte element per lane: 64-byte runs
+  // assembled from 32 store lanes)
+  constexpr int EPS = tf::Elem<T>::kPer16B, GPP = kUpC / EPS;       // channel groups per pixel
+  // g3 rows 2i, 2i+1 (slab rows 1, 2)
 #pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-      const int y = 2 * i + rr;
-      if (y >= H3) continue;
-#pragma unroll 4
-      for (int x = threadIdx.x / kUpC; x < W3; x += 256 / kUpC)
-        tf::Elem<T>::store(g3 + (((size_t)b * H3 + y) * W3 + x) * ldc + c0 + cl, slab[((1 + rr) * kUpC + cl) * pitch + x]);
+  for (int rr = 0; rr < 2; ++rr) {
+    const int y = 2 * i + rr;
+    if (y >= H3) continue;
+    for (int e = threadIdx.x; e < W3 * GPP; e += 256) {
+      const int x = e / GPP, cl = (e % GPP) * EPS;
+      float f[EPS];
+#pragma unroll
+      for (int q = 0; q < EPS; ++q) f[q] = slab[((1 + rr) * kUpC + cl + q) * pitch + x];
+      *reinterpret_cast<uint4*>(g3 + (((size_t)b * H3 + y) * W3 + x) * ldc + c0 + cl) = tf::pack16<T>(f);
     }
   }
   // g4 row i
-  for (int e = threadIdx.x; e < W4 * kUpC; e += 256) {
-    const int cl = e % kUpC, jx = e / kUpC, c = c0 + cl;
-    float v = 0.f;
-    if (c < C) {
+  for (int e = threadIdx.x; e < W4 * GPP; e += 256) {
+    const int jx = e / GPP, cl = (e % GPP) * EPS;
+    float f[EPS];
+#pragma unroll
+    for (int q = 0; q < EPS; ++q) {
+      float v = 0.f;
 #pragma unroll
       for (int ky = 0; ky < 4; ++ky) {
 #pragma unroll
         for (int kx = 0; kx < 4; ++kx) {
           const int x = 2 * jx - 1 + kx;
-          if ((unsigned)x < (unsigned)W3) v += slab[(ky * kUpC + cl) * pitch + x] * wup[c * 16 + ky * 4 + kx];     // rows outside H3 hold zeros
+          if ((unsigned)x < (unsigned)W3) v += slab[(ky * kUpC + cl + q) * pitch + x] * wl[(cl + q) * 16 + ky * 4 + kx];     // rows outside H3 hold zeros
         }
       }
+      f[q] = v;
     }
-    tf::Elem<T>::store(g4 + (((size_t)b * H4 + i) * W4 + jx) * ldc + c, v);
+    *reinterpret_cast<uint4*>(g4 + (((size_t)b * H4 + i) * W4 + jx) * ldc + c0 + cl) = tf::pack16<T>(f);
   }
 }
 
@@ -893,9 +962,14 @@ extern "C" int tf_bn_relu(int dtype, const void* x, const float* scale, const fl
 extern "C" int tf_upsample_add_crop(int dtype, const void* s3, const void* s4, const float* wup_diag, int B, int C, int ldc, int H3, int W3,
                                     int H4, int W4, float* out_nchw, void* stream) {
   if (!s3 || !s4 || !wup_diag || !out_nchw || ldc % 4 || ldc < C) return TF_ERR_ARG;
-  const int tiles = (H3 * W3 + 63) / 64;
-  const size_t lds = (size_t)C * 65 * 4;
-  DISPATCH_T(dtype, hipLaunchKernelGGL(upsample_add_kernel<T>, dim3(B * tiles), dim3(256), lds, (hipStream_t)stream, (const T*)s3, (const T*)s4,
+  const int tiles = (H3 * W3 + kUpPx - 1) / kUpPx;
+  const size_t lds = ((size_t)16 * ldc + (size_t)kUpPx * (ldc + 1)) * 4;   // weight table + [kUpPx pixels][ldc + 1] staging tile
+  if (lds > 160 * 1024 || ldc % (dtype == TF_F32 ? 4 : 8)) return TF_ERR_UNSUPPORTED;
+  if (lds > 64 * 1024) {
+    static tf::PerDevice attr;
+    if (attr.first()) { DISPATCH_T(dtype, (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&upsample_add_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); }
+  }
+  DISPATCH_T(dtype, hipLaunchKernelGGL(upsample_add_kernel<T>, dim3(B * tiles), dim3(kUpT), lds, (hipStream_t)stream, (const T*)s3, (const T*)s4,
                                        wup_diag, B, C, ldc, H3, W3, H4, W4, out_nchw));
   TF_CHECK_LAUNCH();
   return TF_OK;
@@ -905,7 +979,7 @@ extern "C" int tf_upsample_add_crop_bwd(int dtype, const float* g_nchw, const fl
                                         int W4, void* g3, void* g4, void* stream) {
   if (!g_nchw || !wup_diag || !g3 || !g4) return TF_ERR_ARG;
   if (ldc % kUpC || ldc < C || 2 * H4 < H3) return TF_ERR_ARG;
-  const size_t lds = (size_t)4 * kUpC * (W3 | 1) * 4;
+  const size_t lds = ((size_t)4 * kUpC * (W3 | 1) + kUpC * 16) * 4;        // four slab rows + the weight table
   if (lds > 160 * 1024) return TF_ERR_UNSUPPORTED;
   if (lds > 64 * 1024) {
     DISPATCH_T(dtype, (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&upsample_add_bwd_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
