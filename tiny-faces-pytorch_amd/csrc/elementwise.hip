@@ -182,23 +182,32 @@ __global__ void __launch_bounds__(256) maxpool_fwd_kernel(const T* __restrict__ 
 #pragma unroll
       for (int j = 0; j < EPS; ++j) { fs[j] = sc[s * EPS + j]; fh[j] = sh[s * EPS + j]; }
     }
+    // r6: the nine taps are requested together (clamped addresses, the border taps skipped afterwards): inside the bounds test each load was a
+    // dependent round trip of its own
+    uint4 tq[9];
+    bool tok[9];
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
         const int ih = oh * 2 - 1 + kh, iw = ow * 2 - 1 + kw;
-        if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
-          const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(x) + ((((size_t)n * H + ih) * W + iw) * spr + s) * 16);
-          float f[EPS];
-          tf::unpack16<T>(v, f);
-#pragma unroll
-          for (int j = 0; j < EPS; ++j) {
-            float t = f[j];
-            if (sc) t = fmaxf(t * fs[j] + fh[j], 0.f);
-            if (t > best[j]) { best[j] = t; bi[j] = kh * 3 + kw; }     // first max wins (torch CPU max_pool2d)
-          }
-        }
+        const bool v = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+        tok[kh * 3 + kw] = v;
+        const size_t o = v ? (((size_t)n * H + ih) * W + iw) * spr + s : 0;
+        tq[kh * 3 + kw] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(x) + o * 16);
       }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      if (!tok[k]) continue;
+      float f[EPS];
+      tf::unpack16<T>(tq[k], f);
+#pragma unroll
+      for (int j = 0; j < EPS; ++j) {
+        float t = f[j];
+        if (sc) t = fmaxf(t * fs[j] + fh[j], 0.f);
+        if (t > best[j]) { best[j] = t; bi[j] = k; }     // first max wins (torch CPU max_pool2d)
+      }
+    }
     *reinterpret_cast<uint4*>(reinterpret_cast<char*>(y) + i * 16) = tf::pack16<T>(best);
     if (idx) {                                     // one EPS-byte store per chunk
       uint8_t ib[EPS];
@@ -232,32 +241,41 @@ __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const T* __restrict__ 
     float acc[EPS];
 #pragma unroll
     for (int j = 0; j < EPS; ++j) acc[j] = 0.f;
-    // windows (oh, ow) with ih = 2*oh - 1 + kh  ->  oh = (ih + 1 - kh) / 2
+    // windows (oh, ow) with ih = 2*oh - 1 + kh  ->  oh = (ih + 1 - kh) / 2: an odd row belongs to the windows kh = 0 and kh = 2, an even row to
+    // kh = 1 only (likewise the columns): 1, 2, 2 or 4 windows per pixel.  r6: the up to four (gradient, arg-max) pairs and the BN input are
+    // REQUESTED TOGETHER (clamped addresses, selected afterwards) -- the first form loaded them inside the window loops, one dependent round trip
+    // per window (2.1 TB/s for the 250 MB of the stem's max-pool backward).  Same sums in the same (kh, kw) order.
+    const int kh0 = (ih + 1) & 1, kw0 = (iw + 1) & 1;             // first window tap of this row / column; the second one (if any) is + 2
+    uint4 gq[4];
+    uint2 iq[4];
+    bool wv[4];
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-      const int th = ih + 1 - kh;
-      if (th < 0 || (th & 1)) continue;
-      const int oh = th >> 1;
-      if (oh >= OH) continue;
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        const int tw = iw + 1 - kw;
-        if (tw < 0 || (tw & 1)) continue;
-        const int ow = tw >> 1;
-        if (ow >= OW) continue;
-        const size_t o = (((size_t)n * OH + oh) * OW + ow) * spr + s;
-        const uint4 gv = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(g) + o * 16);
-        float gf[EPS];
-        tf::unpack16<T>(gv, gf);
-        // the EPS arg-max bytes of this chunk in ONE load (8 bytes bf16 / 4 bytes fp32) instead of EPS byte loads per window
-        uint8_t ib[EPS];
-        if constexpr (EPS == 8) { const uint2 q = *reinterpret_cast<const uint2*>(idx + o * EPS); __builtin_memcpy(ib, &q, 8); }
-        else { const uint32_t q = *reinterpret_cast<const uint32_t*>(idx + o * EPS); __builtin_memcpy(ib, &q, 4); }
-#pragma unroll
-        for (int j = 0; j < EPS; ++j) if (ib[j] == kh * 3 + kw) acc[j] += gf[j];
+      for (int bq = 0; bq < 2; ++bq) {
+        const int kh = kh0 + 2 * a, kw = kw0 + 2 * bq;
+        const int oh = (ih + 1 - kh) >> 1, ow = (iw + 1 - kw) >> 1;
+        const bool v = kh < 3 && kw < 3 && ih + 1 - kh >= 0 && iw + 1 - kw >= 0 && oh < OH && ow < OW;
+        wv[a * 2 + bq] = v;
+        const size_t o = v ? (((size_t)n * OH + oh) * OW + ow) * spr + s : 0;
+        gq[a * 2 + bq] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(g) + o * 16);
+        if constexpr (EPS == 8) iq[a * 2 + bq] = *reinterpret_cast<const uint2*>(idx + o * EPS);
+        else { iq[a * 2 + bq].x = *reinterpret_cast<const uint32_t*>(idx + o * EPS); iq[a * 2 + bq].y = 0u; }
       }
-    }
     const uint4 xv = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(x) + i * 16);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int bq = 0; bq < 2; ++bq) {
+        if (!wv[a * 2 + bq]) continue;
+        const int code = (kh0 + 2 * a) * 3 + kw0 + 2 * bq;
+        float gf[EPS];
+        tf::unpack16<T>(gq[a * 2 + bq], gf);
+        uint8_t ib[8];
+        __builtin_memcpy(ib, &iq[a * 2 + bq], 8);
+#pragma unroll
+        for (int j = 0; j < EPS; ++j) if (ib[j] == code) acc[j] += gf[j];
+      }
     float xf[EPS];
     tf::unpack16<T>(xv, xf);
 #pragma unroll
