@@ -34,5 +34,5 @@ for t, d in ev:
 print(f"GPU busy (union over queues) {busy / 1e3:.0f} us of {span / 1e3:.0f}")
 agg = collections.defaultdict(lambda: [0.0, 0])
 for r in img: agg[r["n"]][0] += (r["e"] - r["s"]) / 1e3; agg[r["n"]][1] += 1
-for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:14]:
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:34]:
     print(f"    {k:46s} {v[0]:8.1f} us n={v[1]:4d} avg {v[0] / v[1]:6.1f}")
